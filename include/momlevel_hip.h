@@ -1,0 +1,177 @@
+/*
+ * momlevel_hip.h -- C ABI of libmomlevel_hip.so, the MI355X (gfx950) implementation
+ * of momlevel's steric hot path.
+ *
+ * The reference (jkrasting/momlevel) is pure Python: it has no FFI.  Its boundary
+ * for this path is a set of Python call signatures over numpy/xarray arrays.  Each
+ * entry point below names the reference function(s) whose array arithmetic it
+ * replaces (file:line into the reference tree); momlevel_amd/ binds them with
+ * ctypes (INTEGRATION.md shows the stub a momlevel maintainer would add).
+ *
+ * Conventions
+ *  - Every function returns int: 0 = OK, <0 = argument error (MLX_E_*), >0 = a
+ *    hipError_t.  Nothing throws.  mlx_last_error() gives the text for the last
+ *    non-zero status returned on the calling thread.
+ *  - The caller owns every buffer.  All array pointers are DEVICE pointers (HBM),
+ *    C-contiguous, x fastest: 4-D (time, z_l, yh, xh), 3-D (z_l, yh, xh), 2-D (yh, xh).
+ *    "plane" is ny*nx.  Strides are in ELEMENTS.  The library allocates nothing:
+ *    scratch is a caller-provided workspace sized by the *_workspace_bytes() query.
+ *  - Kernels are enqueued asynchronously on the caller's hipStream_t (passed as
+ *    void*; NULL = the default stream).  No call synchronises.  No global mutable
+ *    state: calls on different streams may run from different host threads.
+ *  - NaN marks land / below-bottom cells.  Reductions are skipna (a NaN term
+ *    counts as 0; an all-NaN reduction gives 0.0), as xarray's default .sum().
+ *  - Pointwise outputs (rho, its derivatives, delta_rho, dz, local eta) are
+ *    bit-identical to the reference's numpy evaluation on finite inputs: the
+ *    device code keeps the reference's operator order with FMA contraction off.
+ *    Reductions over (z,y,x) differ from numpy's pairwise order at the 1e-15 level
+ *    and are deterministic (fixed order, no float atomics).
+ */
+#ifndef MOMLEVEL_HIP_H
+#define MOMLEVEL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLX_ABI_VERSION 1
+
+/* argument-error codes (negative) */
+#define MLX_E_NULL     (-1) /* a required pointer is NULL                      */
+#define MLX_E_SHAPE    (-2) /* a dimension is <= 0 or too large for the grid   */
+#define MLX_E_ENUM     (-3) /* eos / func / p_mode / dtype value not recognised */
+#define MLX_E_WORKSPACE (-4) /* workspace too small or misaligned              */
+#define MLX_E_ALIGN    (-5) /* pointer not aligned to its element size         */
+
+/* equation of state: momlevel.eos.<name>  (src/momlevel/util.py:227-249) */
+#define MLX_EOS_WRIGHT 0 /* src/momlevel/eos/wright.py */
+#define MLX_EOS_LINEAR 1 /* src/momlevel/eos/linear.py */
+
+/* EOS function: the attribute picked from the eos module */
+#define MLX_FUNC_DENSITY    0 /* eos/wright.py:23-50   */
+#define MLX_FUNC_DRHO_DTEMP 1 /* eos/wright.py:53-85   */
+#define MLX_FUNC_DRHO_DSAL  2 /* eos/wright.py:88-119  */
+#define MLX_FUNC_ALPHA      3 /* eos/wright.py:122-142 */
+#define MLX_FUNC_BETA       4 /* eos/wright.py:145-165 */
+
+/* how the pressure argument is laid out */
+#define MLX_P_SCALAR  0 /* p[0] for every cell (calc_pdens, scalar calls)            */
+#define MLX_P_ZPROF   1 /* p[nz]: the steric path, pres = z_l*1e4 + patm              */
+#define MLX_P_FULL3D  2 /* p[nz*plane]: patm given as a (yh,xh) DataArray             */
+#define MLX_P_FULL4D  3 /* p[nt*nz*plane]: same shape as the output (K0 only)         */
+
+/* dtype of the streamed theta/S fields */
+#define MLX_DTYPE_F64 0
+#define MLX_DTYPE_F32 1 /* numpy mixed precision of the reference: al0,p0,lam rounded
+                           in float32, the rest in float64        */
+#define MLX_DTYPE_F32_UPCAST 2 /* float32 storage, upcast to float64 before any math  */
+
+int mlx_version(void);
+/* copies the calling thread's last error text into buf (NUL-terminated); returns its length */
+int mlx_last_error(char *buf, size_t n);
+
+/* ---------------------------------------------------------------------------------
+ * K0  pointwise EOS map.  Replaces eos.wright.density/drho_dtemp/drho_dsal/alpha/beta
+ * (src/momlevel/eos/wright.py:23-165), eos.linear.density (eos/linear.py:26-58) and
+ * the apply_ufunc in derived.calc_rho (src/momlevel/derived.py:621-630).
+ * out[t,z,i] = f(T[t*t_stride_T + z*plane + i], S[t*t_stride_S + z*plane + i], p).
+ * t_stride_* == 0 broadcasts a (z,y,x) field over time (the held field of the
+ * thermosteric / halosteric variants).  out is always float64.
+ * ------------------------------------------------------------------------------- */
+int mlx_eos_map(const void *T, const void *S, int dtype,
+                const double *p, int p_mode, int eos, int func,
+                int64_t nt, int64_t nz, int64_t plane,
+                int64_t t_stride_T, int64_t t_stride_S,
+                double *out, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * K1  fused EOS + rho*vol0 + sum over (z,y,x) per time step: masso_out[t].
+ * Replaces calc_rho followed by calc_masso (src/momlevel/derived.py:597-639, 414-444)
+ * as called from steric() for domain="global" (src/momlevel/steric.py:128,135) and
+ * from setup_reference_state (src/momlevel/reference.py:71,77).
+ * vol0 is the REFERENCE volcello (z,y,x), used for every time step (steric.py:135).
+ * p_mode: MLX_P_SCALAR, MLX_P_ZPROF or MLX_P_FULL3D.
+ * In a multi-GPU run each rank passes its horizontal tile; the caller all-reduces
+ * masso_out (RCCL) -- the library never communicates.
+ * ------------------------------------------------------------------------------- */
+size_t mlx_steric_global_workspace_bytes(int64_t nt, int64_t nz, int64_t plane);
+int mlx_steric_global(const void *T, const void *S, int dtype,
+                      const double *vol0, const double *p, int p_mode, int eos,
+                      int64_t nt, int64_t nz, int64_t plane,
+                      int64_t t_stride_T, int64_t t_stride_S,
+                      double *masso_out, void *workspace, size_t workspace_bytes,
+                      void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * K2  fused EOS + delta_rho + dz-weighted column integral.
+ * Replaces steric.py:151-166 for domain="local":
+ *   delta_rho = where(vol0 notnull, rho - rho0, NaN)             (nt,nz,plane)
+ *   eta       = (-1/rhozero) * sum_z(dz * delta_rho) [skipna],   (nt,plane)
+ *               NaN where vol0[z=0] is NaN
+ * rho0m is rho0 with vol0's NaN mask folded in -- make it once per reference
+ * state with mlx_fold_mask().  vol0_surface is the z=0 plane of the reference
+ * volcello.  dz: either an explicit (nz,plane) array, or NULL -- then the kernel
+ * evaluates calc_dz(levels, z_i, deptho) with its default top/bottom
+ * (src/momlevel/derived.py:295-318) from z_i[nz+1] and deptho[plane] on the fly.
+ * delta_rho_out may be NULL: the 8 B/cell store is then skipped.
+ * neg_inv_rhozero is (-1.0/rhozero) evaluated by the caller in float64.
+ * ------------------------------------------------------------------------------- */
+int mlx_fold_mask(const double *rho0, const double *vol0, int64_t n,
+                  double *rho0m_out, void *stream);
+int mlx_steric_local(const void *T, const void *S, int dtype,
+                     const double *rho0m, const double *vol0_surface,
+                     const double *dz, const double *z_i, const double *deptho,
+                     const double *p, int p_mode, int eos, double neg_inv_rhozero,
+                     int64_t nt, int64_t nz, int64_t plane,
+                     int64_t t_stride_T, int64_t t_stride_S,
+                     double *delta_rho_out, double *eta_out, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * skipna sum of n float64 values -> out[0].  Replaces volcello.sum() in
+ * derived.calc_volo (src/momlevel/derived.py:789) and areacello.sum() in
+ * util.validate_areacello (src/momlevel/util.py:692) / steric.py:138.
+ * ------------------------------------------------------------------------------- */
+size_t mlx_nansum_workspace_bytes(int64_t n);
+int mlx_nansum(const double *x, int64_t n, double *out,
+               void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * sum(rho*vol) per time step for an ALREADY MATERIALISED rho: the standalone
+ * derived.calc_masso (src/momlevel/derived.py:414-444).  vol_t_stride == 0
+ * broadcasts a (z,y,x) volcello over time; otherwise volcello is 4-D like rho.
+ * n3 = nz*plane.  Workspace: mlx_steric_global_workspace_bytes(nt, 1, n3).
+ * ------------------------------------------------------------------------------- */
+int mlx_masso(const double *rho, const double *vol, int64_t nt, int64_t n3,
+              int64_t vol_t_stride, double *masso_out,
+              void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * derived.calc_dz (src/momlevel/derived.py:249-325): dz_out[z,i] from z_i[nz+1] and
+ * depth[plane] (NaN depth -> 0).  has_bottom=0 ignores `bottom`.  fraction != 0
+ * returns the cell fraction (NaN where dz or the cell thickness is 0).
+ * The sign checks (derived.py:284-292) stay on the host.
+ * ------------------------------------------------------------------------------- */
+int mlx_calc_dz(const double *z_i, const double *depth, int64_t nz, int64_t plane,
+                double top, double bottom, int has_bottom, int fraction,
+                double *dz_out, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * Synthetic MOM6-shaped fields for bench.py and the full-size tests (not a
+ * reference function).  out[t,z,y,x] = lo + scale*u, with
+ * u = (splitmix64(seed ^ (field_id << 60) ^ gidx) >> 11) * 2^-53 and gidx the
+ * linear index of the cell in the GLOBAL (NT?,nz,NY,NX) grid, so that a
+ * horizontal tile (y0,x0,ny,nx) of a rank reproduces its part of the global field.
+ * Cells where mask3d[z,y,x] is NaN get NaN (mask3d may be NULL).
+ * ------------------------------------------------------------------------------- */
+int mlx_synth_field(void *out, int dtype, int64_t nt, int64_t nz, int64_t ny, int64_t nx,
+                    int64_t t0, int64_t NY, int64_t NX, int64_t y0, int64_t x0,
+                    uint64_t seed, int field_id, double lo, double scale,
+                    const double *mask3d, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOMLEVEL_HIP_H */

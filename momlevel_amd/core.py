@@ -1,0 +1,275 @@
+"""Array-level API: the HIP kernels on torch device tensors.
+
+torch is used only as the device-array container (allocation, streams); every
+number is produced by libmomlevel_hip.so.  All functions enqueue on torch's
+current stream and return device tensors without synchronising.
+
+Layout: ``(time, z_l, yh, xh)`` C-contiguous, x fastest.  A
+``(z_l, yh, xh)`` tensor passed where a 4-D field is expected is broadcast over
+time (the held field of the thermosteric / halosteric variants).
+"""
+
+import torch
+
+from . import _lib
+from ._lib import (
+    DTYPE_F32,
+    DTYPE_F32_UPCAST,
+    DTYPE_F64,
+    EOS_IDS,
+    FUNC_IDS,
+    P_FULL3D,
+    P_FULL4D,
+    P_SCALAR,
+    P_ZPROF,
+    MomlevelHipError,
+)
+
+F32_MODES = {"faithful": DTYPE_F32, "upcast": DTYPE_F32_UPCAST}
+
+
+def require_device():
+    """The product path needs the HIP library AND a GPU; fail loudly otherwise."""
+    _lib.load()
+    if not torch.cuda.is_available():
+        raise MomlevelHipError(
+            "no HIP device visible: momlevel_amd computes on MI355X only (no CPU fallback)"
+        )
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _f64(x, device):
+    """Small time-invariant operand -> contiguous float64 device tensor."""
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=torch.float64).contiguous()
+    return torch.as_tensor(x, dtype=torch.float64).to(device).contiguous()
+
+
+def _dtype_code(t, f32_mode):
+    if t.dtype == torch.float64:
+        return DTYPE_F64
+    if t.dtype == torch.float32:
+        return F32_MODES[f32_mode]
+    raise TypeError(f"thetao/so must be float64 or float32, got {t.dtype}")
+
+
+def _field(x, nz, ny, nx, name):
+    """Validate a streamed field; return (tensor, nt or None, time stride in elements)."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda):
+        raise TypeError(f"{name} must be a CUDA/HIP torch tensor")
+    if x.dim() == 3:
+        if tuple(x.shape) != (nz, ny, nx):
+            raise ValueError(f"{name} has shape {tuple(x.shape)}, expected {(nz, ny, nx)}")
+        return x.contiguous(), None, 0
+    if x.dim() != 4 or tuple(x.shape[1:]) != (nz, ny, nx):
+        raise ValueError(f"{name} has shape {tuple(x.shape)}, expected (nt,{nz},{ny},{nx})")
+    inner_ok = x.stride(3) == 1 and x.stride(2) == nx and x.stride(1) == ny * nx
+    if not inner_ok or x.stride(0) < 0:
+        x = x.contiguous()
+    return x, x.shape[0], (x.stride(0) if x.shape[0] > 1 else nz * ny * nx)
+
+
+def _pair(T, S, f32_mode):
+    """Common shape logic of the (thetao, so) pair."""
+    if T.dtype != S.dtype:
+        raise TypeError("thetao and so must share a dtype")
+    shape3 = tuple(T.shape[-3:])
+    nz, ny, nx = shape3
+    T, ntT, sT = _field(T, nz, ny, nx, "thetao")
+    S, ntS, sS = _field(S, nz, ny, nx, "so")
+    if ntT is not None and ntS is not None and ntT != ntS:
+        raise ValueError("thetao and so disagree on the number of time steps")
+    nt = ntT if ntT is not None else ntS
+    squeeze = nt is None
+    if squeeze:
+        nt = 1
+    return T, S, nt, nz, ny, nx, sT, sS, _dtype_code(T, f32_mode), squeeze
+
+
+def _pressure(p, nt, nz, ny, nx, device, allow4d):
+    """Classify the pressure operand -> (tensor, p_mode)."""
+    if p is None:
+        return None, P_SCALAR
+    p = _f64(p, device)
+    if p.numel() == 1:
+        return p.reshape(1), P_SCALAR
+    shape = tuple(p.shape)
+    if shape in ((nz,), (nz, 1, 1)):
+        return p.reshape(nz), P_ZPROF
+    if shape == (nz, ny, nx):
+        return p, P_FULL3D
+    if allow4d and shape == (nt, nz, ny, nx):
+        return p, P_FULL4D
+    # anything else that broadcasts against (nz,ny,nx): materialise it (tiny vs the 4-D fields)
+    try:
+        return p.expand(nz, ny, nx).contiguous(), P_FULL3D
+    except RuntimeError:
+        pass
+    if allow4d:
+        return p.expand(nt, nz, ny, nx).contiguous(), P_FULL4D
+    raise ValueError(f"pressure of shape {shape} does not broadcast to {(nz, ny, nx)}")
+
+
+def eos_map(T, S, p, eos="wright", func="density", f32_mode="faithful"):
+    """K0: pointwise EOS function over a (nt,nz,ny,nx) or (nz,ny,nx) grid -> float64."""
+    require_device()
+    T, S, nt, nz, ny, nx, sT, sS, dt, squeeze = _pair(T, S, f32_mode)
+    pt, p_mode = _pressure(p, nt, nz, ny, nx, T.device, allow4d=True)
+    out = torch.empty((nt, nz, ny, nx), dtype=torch.float64, device=T.device)
+    rc = _lib.load().mlx_eos_map(
+        _ptr(T), _ptr(S), dt, _ptr(pt), p_mode, EOS_IDS[eos.lower()], FUNC_IDS[func],
+        nt, nz, ny * nx, sT, sS, _ptr(out), _stream(),
+    )
+    _lib.check(rc, "mlx_eos_map")
+    return out[0] if squeeze else out
+
+
+def steric_global_masso(T, S, vol0, p, eos="wright", f32_mode="faithful"):
+    """K1: masso[t] = sum_{z,y,x} rho(T,S,p) * vol0  (skipna) -> (nt,) float64."""
+    require_device()
+    T, S, nt, nz, ny, nx, sT, sS, dt, _ = _pair(T, S, f32_mode)
+    vol0 = _f64(vol0, T.device)
+    if tuple(vol0.shape) != (nz, ny, nx):
+        raise ValueError(f"vol0 has shape {tuple(vol0.shape)}, expected {(nz, ny, nx)}")
+    pt, p_mode = _pressure(p, nt, nz, ny, nx, T.device, allow4d=False)
+    lib = _lib.load()
+    nbytes = lib.mlx_steric_global_workspace_bytes(nt, nz, ny * nx)
+    ws = torch.empty(nbytes // 8, dtype=torch.float64, device=T.device)
+    out = torch.empty(nt, dtype=torch.float64, device=T.device)
+    rc = lib.mlx_steric_global(
+        _ptr(T), _ptr(S), dt, _ptr(vol0), _ptr(pt), p_mode, EOS_IDS[eos.lower()],
+        nt, nz, ny * nx, sT, sS, _ptr(out), _ptr(ws), nbytes, _stream(),
+    )
+    _lib.check(rc, "mlx_steric_global")
+    return out
+
+
+def fold_mask(rho0, vol0):
+    """rho0m = where(vol0 notnull, rho0, NaN) -- prepared once per reference state."""
+    require_device()
+    rho0 = _f64(rho0, rho0.device)
+    vol0 = _f64(vol0, rho0.device)
+    out = torch.empty_like(rho0)
+    rc = _lib.load().mlx_fold_mask(_ptr(rho0), _ptr(vol0), rho0.numel(), _ptr(out), _stream())
+    _lib.check(rc, "mlx_fold_mask")
+    return out
+
+
+def steric_local(T, S, rho0m, vol0_surface, p, neg_inv_rhozero, dz=None, z_i=None,
+                 deptho=None, eos="wright", f32_mode="faithful", want_delta_rho=True,
+                 delta_rho_out=None, eta_out=None):
+    """K2: (delta_rho (nt,nz,ny,nx) or None, eta (nt,ny,nx))."""
+    require_device()
+    T, S, nt, nz, ny, nx, sT, sS, dt, _ = _pair(T, S, f32_mode)
+    dev = T.device
+    rho0m = _f64(rho0m, dev)
+    vol0_surface = _f64(vol0_surface, dev)
+    if tuple(rho0m.shape) != (nz, ny, nx) or tuple(vol0_surface.shape) != (ny, nx):
+        raise ValueError("rho0m must be (nz,ny,nx) and vol0_surface (ny,nx)")
+    pt, p_mode = _pressure(p, nt, nz, ny, nx, dev, allow4d=False)
+    if dz is not None:
+        dz = _f64(dz, dev)
+        if tuple(dz.shape) != (nz, ny, nx):
+            raise ValueError("dz must be (nz,ny,nx)")
+    else:
+        z_i = _f64(z_i, dev)
+        deptho = _f64(deptho, dev)
+        if z_i.numel() != nz + 1 or tuple(deptho.shape) != (ny, nx):
+            raise ValueError("z_i must have nz+1 entries and deptho be (ny,nx)")
+    drho = None
+    if want_delta_rho:
+        drho = delta_rho_out
+        if drho is None:
+            drho = torch.empty((nt, nz, ny, nx), dtype=torch.float64, device=dev)
+    eta = eta_out if eta_out is not None else torch.empty(
+        (nt, ny, nx), dtype=torch.float64, device=dev
+    )
+    rc = _lib.load().mlx_steric_local(
+        _ptr(T), _ptr(S), dt, _ptr(rho0m), _ptr(vol0_surface), _ptr(dz), _ptr(z_i),
+        _ptr(deptho), _ptr(pt), p_mode, EOS_IDS[eos.lower()], float(neg_inv_rhozero),
+        nt, nz, ny * nx, sT, sS, _ptr(drho), _ptr(eta), _stream(),
+    )
+    _lib.check(rc, "mlx_steric_local")
+    return drho, eta
+
+
+def nansum(x):
+    """skipna sum of a float64 device tensor -> 0-d device tensor."""
+    require_device()
+    x = _f64(x, x.device).reshape(-1)
+    lib = _lib.load()
+    nbytes = lib.mlx_nansum_workspace_bytes(x.numel())
+    ws = torch.empty(max(nbytes // 8, 1), dtype=torch.float64, device=x.device)
+    out = torch.empty(1, dtype=torch.float64, device=x.device)
+    rc = lib.mlx_nansum(_ptr(x), x.numel(), _ptr(out), _ptr(ws), nbytes, _stream())
+    _lib.check(rc, "mlx_nansum")
+    return out[0]
+
+
+def masso(rho, vol):
+    """Standalone calc_masso: sum(rho*vol) [skipna] over every non-time dim."""
+    require_device()
+    rho = _f64(rho, rho.device)
+    vol = _f64(vol, rho.device)
+    squeeze = rho.dim() == 3
+    if squeeze:
+        rho = rho.unsqueeze(0)
+    nt = rho.shape[0]
+    n3 = rho[0].numel()
+    if tuple(vol.shape) == tuple(rho.shape[1:]):
+        vstride = 0
+    elif tuple(vol.shape) == tuple(rho.shape):
+        vstride = n3
+    else:
+        raise ValueError("volcello must be (z,y,x) or match rho")
+    lib = _lib.load()
+    nbytes = lib.mlx_steric_global_workspace_bytes(nt, 1, n3)
+    ws = torch.empty(nbytes // 8, dtype=torch.float64, device=rho.device)
+    out = torch.empty(nt, dtype=torch.float64, device=rho.device)
+    rc = lib.mlx_masso(_ptr(rho), _ptr(vol), nt, n3, vstride, _ptr(out), _ptr(ws), nbytes,
+                       _stream())
+    _lib.check(rc, "mlx_masso")
+    return out[0] if squeeze else out
+
+
+def calc_dz(z_i, depth, top=0.0, bottom=None, fraction=False):
+    """derived.calc_dz core on device -> (nz, ny, nx)."""
+    require_device()
+    depth = _f64(depth, depth.device if isinstance(depth, torch.Tensor) else "cuda")
+    z_i = _f64(z_i, depth.device)
+    nz = z_i.numel() - 1
+    ny, nx = depth.shape
+    out = torch.empty((nz, ny, nx), dtype=torch.float64, device=depth.device)
+    rc = _lib.load().mlx_calc_dz(
+        _ptr(z_i), _ptr(depth), nz, ny * nx, float(top),
+        float(bottom) if bottom is not None else 0.0, int(bottom is not None),
+        int(bool(fraction)), _ptr(out), _stream(),
+    )
+    _lib.check(rc, "mlx_calc_dz")
+    return out
+
+
+def synth_field(shape, dtype=torch.float64, *, seed, field_id, lo, scale, mask3d=None,
+                t0=0, global_hw=None, origin=(0, 0), device="cuda", out=None):
+    """Counter-based synthetic field (bench / full-size tests); see synthetic.py."""
+    require_device()
+    nt, nz, ny, nx = shape
+    NY, NX = global_hw if global_hw is not None else (ny, nx)
+    if out is None:
+        out = torch.empty(shape, dtype=dtype, device=device)
+    code = DTYPE_F64 if out.dtype == torch.float64 else DTYPE_F32
+    if mask3d is not None:
+        mask3d = _f64(mask3d, out.device)
+    rc = _lib.load().mlx_synth_field(
+        _ptr(out), code, nt, nz, ny, nx, t0, NY, NX, origin[0], origin[1], seed, field_id,
+        float(lo), float(scale), _ptr(mask3d), _stream(),
+    )
+    _lib.check(rc, "mlx_synth_field")
+    return out

@@ -1,0 +1,810 @@
+// momlevel_hip.hip -- HIP kernels (gfx950 / CDNA4) and the C ABI of libmomlevel_hip.so.
+//
+// Hot path: momlevel's steric sea level (src/momlevel/steric.py:17-184) =
+//   Wright EOS per cell (eos/wright.py:44-48)
+//   + global:  sum_{z,y,x} rho*vol0 per time step   (derived.py:435-438)
+//   + local:   delta_rho = rho - rho0, eta = -1/rhozero * sum_z dz*delta_rho (steric.py:151-166)
+//
+// Everything is pointwise + reduction: ~50 fp64 VALU ops against 16 B of HBM
+// traffic per cell.  The bound is HBM bandwidth, there is no contraction and
+// therefore no MFMA.  The design rules that matter (cdna_hip_programming.md G2, G7,
+// G11, G13; Appendix B element-wise/reduction):
+//   * 16 B per lane loads (global_load_dwordx4): double2 / float4, 64 lanes = 1 KiB
+//     contiguous per wave instruction;
+//   * time is the INNER loop of every thread, so that the time-invariant operands
+//     (vol0, rho0, dz, p) are read once and live in VGPRs while theta/S stream by;
+//   * next-time-step loads are issued before the current step's arithmetic
+//     (register double buffering) so each wave keeps 2x its working set in flight;
+//   * reductions are wave/LDS trees in a fixed order -- no float atomics -- so results
+//     are bit-reproducible run to run and independent of dispatch order;
+//   * >> 256 workgroups per launch (tens of thousands), each independent: no
+//     inter-workgroup hand-off inside a launch, so nothing depends on XCD placement.
+//
+// Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared  (csrc/build.py)
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/momlevel_hip.h"
+#include "eos_device.hpp"
+
+#pragma clang fp contract(off)
+
+namespace mlx {
+
+constexpr int kBlock = 256;  // 4 waves of 64
+constexpr int kNTC = 8;      // time steps whose per-thread partials are parked in LDS
+
+// ------------------------------------------------------------------------------------
+// vector load helpers: VEC elements of TIn = 16 bytes (double2 / float4), or scalar
+// ------------------------------------------------------------------------------------
+template <typename TIn, int VEC>
+struct Pack {
+  TIn v[VEC];
+};
+
+template <typename TIn, int VEC>
+__device__ __forceinline__ Pack<TIn, VEC> load_pack(const TIn* __restrict__ p) {
+  Pack<TIn, VEC> r;
+  if constexpr (VEC == 1) {
+    r.v[0] = p[0];
+  } else if constexpr (sizeof(TIn) * VEC == 16) {
+    // one global_load_dwordx4
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 raw = *reinterpret_cast<const f4*>(p);
+    __builtin_memcpy(&r, &raw, 16);
+  } else {
+    static_assert(sizeof(TIn) * VEC == 32, "pack must be 16 or 32 bytes");
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 raw0 = reinterpret_cast<const f4*>(p)[0];
+    f4 raw1 = reinterpret_cast<const f4*>(p)[1];
+    __builtin_memcpy(&r.v[0], &raw0, 16);
+    __builtin_memcpy(&r.v[VEC / 2], &raw1, 16);
+  }
+  return r;
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_pack(double* __restrict__ p, const Pack<double, VEC>& r) {
+  if constexpr (VEC == 1) {
+    p[0] = r.v[0];
+  } else {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int h = 0; h < VEC / 2; ++h) {
+      f4 raw;
+      __builtin_memcpy(&raw, &r.v[2 * h], 16);
+      reinterpret_cast<f4*>(p)[h] = raw;
+    }
+  }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+  // fixed-order butterfly-free tree: lane i += lane i+off, off = 32..1; lane 0 holds the sum
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------
+// K1: fused EOS + rho*vol0 + per-time-step sum over the block's cells.
+//
+// grid = (ceil(plane / (kBlock*VEC*U)), nz); each thread owns U packs of VEC adjacent
+// cells of ONE z level, keeps their vol0 (and p, if FULL3D) in registers and loops over
+// time.  Per time step it parks its partial in LDS row t%kNTC; every kNTC steps the block
+// reduces the parked rows (fixed order) and writes partials[t][block].  A second kernel
+// (k_reduce_rows) sums partials[t][:] in a fixed order -> masso[t].
+//
+// HOLD: 0 = both fields stream, 1 = T is time-invariant (halosteric), 2 = S is
+// (thermosteric); the held field is loaded once.  GENERIC (VEC==1 instantiation)
+// takes eos/p_mode at run time and honours any stride, incl. 0, by reloading.
+// ------------------------------------------------------------------------------------
+template <typename TIn, int VEC, int U, int HOLD, int MODE, bool GENERIC>
+__global__ __launch_bounds__(kBlock) void k_steric_global(
+    const TIn* __restrict__ T, const TIn* __restrict__ S, const double* __restrict__ vol0,
+    const double* __restrict__ p, int p_mode, int eos, int nt, int64_t plane,
+    int64_t t_stride_T, int64_t t_stride_S, double* __restrict__ partials, int64_t nblk_total) {
+  __shared__ double red[kNTC][kBlock];
+
+  const int tid = threadIdx.x;
+  const int z = blockIdx.y;
+  const int64_t blk = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+  const int64_t tile0 = (int64_t)blockIdx.x * (kBlock * VEC * U);
+  const int64_t zoff = (int64_t)z * plane;
+
+  int64_t off[U];  // offset of pack u inside a (z,y,x) slab; clamped when past the plane
+  double vol[U][VEC];
+  double pc[U][VEC];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    int64_t i = tile0 + ((int64_t)u * kBlock + tid) * VEC;
+    const bool valid = (i + VEC <= plane);  // plane % VEC == 0 is a host-side precondition
+    i = valid ? i : 0;
+    off[u] = zoff + i;
+    Pack<double, VEC> v = load_pack<double, VEC>(vol0 + off[u]);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) vol[u][k] = valid ? v.v[k] : canonical_nan();
+    if (GENERIC && p_mode == MLX_P_FULL3D) {
+      Pack<double, VEC> q = load_pack<double, VEC>(p + off[u]);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) pc[u][k] = q.v[k];
+    }
+  }
+  double pz = 0.0;
+  if (!GENERIC || p_mode == MLX_P_ZPROF) pz = p[z];
+  if (GENERIC && p_mode == MLX_P_SCALAR) pz = p[0];
+
+  Pack<TIn, VEC> curT[U], curS[U], nxtT[U], nxtS[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    nxtT[u] = load_pack<TIn, VEC>(T + off[u]);
+    nxtS[u] = load_pack<TIn, VEC>(S + off[u]);
+  }
+
+  for (int t = 0; t < nt; ++t) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (HOLD != 1 || t == 0) curT[u] = nxtT[u];
+      if (HOLD != 2 || t == 0) curS[u] = nxtS[u];
+    }
+    if (t + 1 < nt) {  // issue the next step's loads before this step's arithmetic
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (HOLD != 1) nxtT[u] = load_pack<TIn, VEC>(T + (int64_t)(t + 1) * t_stride_T + off[u]);
+        if (HOLD != 2) nxtS[u] = load_pack<TIn, VEC>(S + (int64_t)(t + 1) * t_stride_S + off[u]);
+      }
+    }
+    double c = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        double rho;
+        if constexpr (GENERIC) {
+          const double pp = (p_mode == MLX_P_FULL3D) ? pc[u][k] : pz;
+          rho = eos_eval<MODE, TIn>(eos, kDensity, curT[u].v[k], curS[u].v[k], pp);
+        } else {
+          rho = wright_density<MODE, TIn>(curT[u].v[k], curS[u].v[k], pz);
+        }
+        const double term = rho * vol[u][k];  // derived.py:435
+        c += is_nan(term) ? 0.0 : term;       // skipna
+      }
+    }
+    const int row = t % kNTC;
+    red[row][tid] = c;
+    if (row == kNTC - 1 || t == nt - 1) {
+      __syncthreads();
+      const int wave = tid >> 6, lane = tid & 63;
+      for (int r = wave; r <= row; r += kBlock / 64) {
+        double v = ((red[r][lane] + red[r][lane + 64]) + red[r][lane + 128]) + red[r][lane + 192];
+        v = wave_sum(v);
+        if (lane == 0) partials[(int64_t)(t - row + r) * nblk_total + blk] = v;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// partials[row][0..n) -> out[row]; one block per row, fixed order
+__global__ __launch_bounds__(kBlock) void k_reduce_rows(const double* __restrict__ partials,
+                                                        int64_t n, double* __restrict__ out) {
+  __shared__ double red[kBlock];
+  const double* row = partials + (int64_t)blockIdx.x * n;
+  double c = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += kBlock) c += row[i];
+  red[threadIdx.x] = c;
+  __syncthreads();
+#pragma unroll
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+// ------------------------------------------------------------------------------------
+// standalone calc_masso on a materialised rho (derived.py:435-438): per-block partial
+// of sum(rho*vol) [skipna] for one time step; grid = (nblk, nt)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_masso_partial(const double* __restrict__ rho,
+                                                          const double* __restrict__ vol,
+                                                          int64_t n3, int64_t vol_t_stride,
+                                                          double* __restrict__ partials) {
+  __shared__ double red[kBlock / 64];
+  const int64_t t = blockIdx.y;
+  const double* r = rho + t * n3;
+  const double* v = vol + t * vol_t_stride;
+  double c = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n3;
+       i += (int64_t)gridDim.x * kBlock) {
+    const double term = r[i] * v[i];
+    c += is_nan(term) ? 0.0 : term;
+  }
+  c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    partials[t * gridDim.x + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// skipna sum, stage 1: grid-stride, per-block partial
+__global__ __launch_bounds__(kBlock) void k_nansum_partial(const double* __restrict__ x, int64_t n,
+                                                           double* __restrict__ partials) {
+  __shared__ double red[kBlock / 64];
+  double c = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * kBlock) {
+    const double v = x[i];
+    c += is_nan(v) ? 0.0 : v;
+  }
+  c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// ------------------------------------------------------------------------------------
+// K0: pointwise EOS map.  grid = (ceil(plane/(kBlock*VEC*U)), nz, nt)
+// ------------------------------------------------------------------------------------
+template <typename TIn, int VEC, int U, int MODE, int FUNC, bool GENERIC>
+__global__ __launch_bounds__(kBlock) void k_eos_map(const TIn* __restrict__ T,
+                                                    const TIn* __restrict__ S,
+                                                    const double* __restrict__ p, int p_mode,
+                                                    int eos, int func, int64_t nz, int64_t plane,
+                                                    int64_t t_stride_T, int64_t t_stride_S,
+                                                    int64_t t_base, double* __restrict__ out) {
+  const int z = blockIdx.y;
+  const int64_t t = t_base + blockIdx.z;
+  const int64_t tile0 = (int64_t)blockIdx.x * (kBlock * VEC * U);
+  const int64_t zoff = (int64_t)z * plane;
+  double pz = 0.0;
+  if (!GENERIC || p_mode == MLX_P_ZPROF) pz = p[z];
+  if (GENERIC && p_mode == MLX_P_SCALAR) pz = p[0];
+  Pack<TIn, VEC> a[U], b[U];
+  int64_t off[U];
+  bool valid[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = tile0 + ((int64_t)u * kBlock + threadIdx.x) * VEC;
+    valid[u] = (i + VEC <= plane);
+    off[u] = zoff + (valid[u] ? i : 0);
+    a[u] = load_pack<TIn, VEC>(T + t * t_stride_T + off[u]);
+    b[u] = load_pack<TIn, VEC>(S + t * t_stride_S + off[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    Pack<double, VEC> r;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      if constexpr (GENERIC) {
+        double pp = pz;
+        if (p_mode == MLX_P_FULL3D) pp = p[off[u] + k];
+        if (p_mode == MLX_P_FULL4D) pp = p[t * nz * plane + off[u] + k];
+        r.v[k] = eos_eval<MODE, TIn>(eos, func, a[u].v[k], b[u].v[k], pp);
+      } else {
+        r.v[k] = eos_eval<MODE, TIn>(kWright, FUNC, a[u].v[k], b[u].v[k], pz);
+      }
+    }
+    if (valid[u]) store_pack<VEC>(out + t * nz * plane + off[u], r);
+  }
+}
+
+// rho0m = where(vol0 notnull, rho0, NaN)
+__global__ __launch_bounds__(kBlock) void k_fold_mask(const double* __restrict__ rho0,
+                                                      const double* __restrict__ vol0, int64_t n,
+                                                      double* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * kBlock)
+    out[i] = is_nan(vol0[i]) ? canonical_nan() : rho0[i];
+}
+
+// calc_dz's default-argument core, derived.py:295-318 with top=0, bottom=None
+__device__ __forceinline__ double dz_default(double depth, double ztop, double zbot) {
+  const double d = is_nan(depth) ? 0.0 : depth;  // fillna(0.0)
+  const double dz_field = zbot - ztop;
+  double part = d - ztop;
+  part = (part < 0.0) ? 0.0 : part;
+  double result = (part < dz_field) ? part : dz_field;  // np.minimum (no NaN possible here)
+  part = zbot - 0.0;
+  part = (part < 0.0) ? 0.0 : part;
+  result = (part < result) ? part : result;
+  return result;
+}
+
+// ------------------------------------------------------------------------------------
+// K2: fused EOS + delta_rho + dz-weighted column integral.
+//
+// grid = (ceil(plane/(kBlock*VEC)), ceil(nt/NTI)).  A thread owns VEC adjacent columns
+// and NTI consecutive time steps: z is the outer (sequential, as numpy's axis reduce)
+// loop, the NTI time steps are unrolled inside it with their column sums in registers,
+// so rho0m / dz are read once per z and reused NTI times.
+// ------------------------------------------------------------------------------------
+template <typename TIn, int VEC, int NTI, int HOLD, int MODE, bool GENERIC>
+__global__ __launch_bounds__(kBlock) void k_steric_local(
+    const TIn* __restrict__ T, const TIn* __restrict__ S, const double* __restrict__ rho0m,
+    const double* __restrict__ vol0_surface, const double* __restrict__ dz,
+    const double* __restrict__ z_i, const double* __restrict__ deptho,
+    const double* __restrict__ p, int p_mode, int eos, double neg_inv_rhozero, int nt, int nz,
+    int64_t plane, int64_t t_stride_T, int64_t t_stride_S, double* __restrict__ drho_out,
+    double* __restrict__ eta_out) {
+  const int64_t col = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
+  if (col + VEC > plane) return;  // whole packs only; no barrier below
+  const int t0 = blockIdx.y * NTI;
+  const int64_t n3 = (int64_t)nz * plane;
+
+  double acc[NTI][VEC];
+#pragma unroll
+  for (int j = 0; j < NTI; ++j)
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[j][k] = 0.0;
+
+  Pack<double, VEC> depth;
+  if (dz == nullptr) depth = load_pack<double, VEC>(deptho + col);
+  double pz = 0.0;
+  if (GENERIC && p_mode == MLX_P_SCALAR) pz = p[0];
+
+  for (int z = 0; z < nz; ++z) {
+    const int64_t off = (int64_t)z * plane + col;
+    const Pack<double, VEC> r0 = load_pack<double, VEC>(rho0m + off);
+    Pack<double, VEC> dzv;
+    if (dz != nullptr) {
+      dzv = load_pack<double, VEC>(dz + off);
+    } else {
+      const double ztop = z_i[z], zbot = z_i[z + 1];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) dzv.v[k] = dz_default(depth.v[k], ztop, zbot);
+    }
+    if (!GENERIC || p_mode == MLX_P_ZPROF) pz = p[z];
+    Pack<double, VEC> pfull;
+    if (GENERIC && p_mode == MLX_P_FULL3D) pfull = load_pack<double, VEC>(p + off);
+
+    Pack<TIn, VEC> hT, hS;
+    if (HOLD == 1) hT = load_pack<TIn, VEC>(T + off);
+    if (HOLD == 2) hS = load_pack<TIn, VEC>(S + off);
+
+    Pack<TIn, VEC> a[NTI], b[NTI];
+#pragma unroll
+    for (int j = 0; j < NTI; ++j) {
+      // clamp so the tail chunk's surplus loads stay in bounds (their results are unused)
+      const int64_t t = (t0 + j < nt) ? (t0 + j) : (nt - 1);
+      if (HOLD != 1) a[j] = load_pack<TIn, VEC>(T + t * t_stride_T + off);
+      if (HOLD != 2) b[j] = load_pack<TIn, VEC>(S + t * t_stride_S + off);
+    }
+#pragma unroll
+    for (int j = 0; j < NTI; ++j) {
+      if (t0 + j < nt) {
+        Pack<double, VEC> d;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          const TIn tv = (HOLD == 1) ? hT.v[k] : a[j].v[k];
+          const TIn sv = (HOLD == 2) ? hS.v[k] : b[j].v[k];
+          double rho;
+          if constexpr (GENERIC) {
+            const double pp = (p_mode == MLX_P_FULL3D) ? pfull.v[k] : pz;
+            rho = eos_eval<MODE, TIn>(eos, kDensity, tv, sv, pp);
+          } else {
+            rho = wright_density<MODE, TIn>(tv, sv, pz);
+          }
+          double dr = rho - r0.v[k];               // steric.py:152 (NaN where vol0 is NaN)
+          dr = is_nan(dr) ? canonical_nan() : dr;  // canonical payload
+          d.v[k] = dr;
+          const double term = dzv.v[k] * dr;       // steric.py:163
+          acc[j][k] += is_nan(term) ? 0.0 : term;  // skipna, z ascending like numpy
+        }
+        if (drho_out != nullptr) store_pack<VEC>(drho_out + (int64_t)(t0 + j) * n3 + off, d);
+      }
+    }
+  }
+  const Pack<double, VEC> surf = load_pack<double, VEC>(vol0_surface + col);
+#pragma unroll
+  for (int j = 0; j < NTI; ++j) {
+    if (t0 + j < nt) {
+      Pack<double, VEC> e;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k)
+        e.v[k] = is_nan(surf.v[k]) ? canonical_nan() : neg_inv_rhozero * acc[j][k];
+      store_pack<VEC>(eta_out + (int64_t)(t0 + j) * plane + col, e);
+    }
+  }
+}
+
+// derived.calc_dz, derived.py:295-323 with explicit top/bottom/fraction
+__global__ __launch_bounds__(kBlock) void k_calc_dz(const double* __restrict__ z_i,
+                                                    const double* __restrict__ depth, int64_t nz,
+                                                    int64_t plane, double top, double bottom,
+                                                    int has_bottom, int fraction,
+                                                    double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= plane) return;
+  double d = depth[i];
+  d = is_nan(d) ? 0.0 : d;
+  if (has_bottom) d = (is_nan(bottom) || bottom < d) ? bottom : d;  // np.minimum(depth, bottom)
+  for (int64_t z = 0; z < nz; ++z) {
+    const double ztop = z_i[z], zbot = z_i[z + 1];
+    const double dz_field = zbot - ztop;
+    double part = d - ztop;
+    part = (part < 0.0) ? 0.0 : part;
+    double result = (is_nan(part) || part < dz_field) ? part : dz_field;
+    part = zbot - top;
+    part = (part < 0.0) ? 0.0 : part;
+    result = (is_nan(part) || part < result) ? part : result;
+    if (fraction) {
+      const double f = (dz_field == 0.0) ? canonical_nan() : dz_field;
+      const double g = (result == 0.0) ? canonical_nan() : result;
+      result = g / f;
+    }
+    out[z * plane + i] = result;
+  }
+}
+
+// synthetic field: lo + scale*u(splitmix64(seed ^ field<<60 ^ global_index))
+template <typename TOut>
+__global__ __launch_bounds__(kBlock) void k_synth(TOut* __restrict__ out, int64_t nt, int64_t nz,
+                                                  int64_t ny, int64_t nx, int64_t t0, int64_t NY,
+                                                  int64_t NX, int64_t y0, int64_t x0,
+                                                  unsigned long long seed, int field_id, double lo,
+                                                  double scale, const double* __restrict__ mask3d) {
+  const int64_t n3 = nz * ny * nx;
+  const int64_t n = nt * n3;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * kBlock) {
+    const int64_t t = i / n3;
+    const int64_t r = i - t * n3;
+    const int64_t z = r / (ny * nx);
+    const int64_t r2 = r - z * ny * nx;
+    const int64_t y = r2 / nx;
+    const int64_t x = r2 - y * nx;
+    const unsigned long long g =
+        (unsigned long long)((((t0 + t) * nz + z) * NY + (y0 + y)) * NX + (x0 + x));
+    const unsigned long long h = splitmix64(seed ^ ((unsigned long long)field_id << 60) ^ g);
+    const double u = (double)(h >> 11) * 0x1.0p-53;
+    double v = lo + scale * u;
+    if (mask3d != nullptr && is_nan(mask3d[r])) v = canonical_nan();
+    out[i] = (TOut)v;
+  }
+}
+
+}  // namespace mlx
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+
+int hip_status(hipError_t e, const char* what) {
+  if (e == hipSuccess) return 0;
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  return (int)e;
+}
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// cells a K1 block covers within one z level
+constexpr int kU64 = 4, kVec64 = 2;  // 8 cells/thread, 2048 cells/block (fast f64)
+constexpr int kU32 = 2, kVec32 = 4;  // 8 cells/thread (fast f32)
+constexpr int kUGen = 4;             // generic: 4 scalar cells/thread, 1024 cells/block
+constexpr int kNTI = 8;              // time steps per K2 thread
+
+struct GlobalPlan {
+  bool fast;
+  int64_t grid_x;
+  int64_t nblk_total;
+};
+
+GlobalPlan plan_global(const void* T, const void* S, const double* vol0, int dtype, int p_mode,
+                       int eos, int64_t nz, int64_t plane, int64_t sT, int64_t sS) {
+  const int vec = (dtype == MLX_DTYPE_F64) ? kVec64 : kVec32;
+  const int u = (dtype == MLX_DTYPE_F64) ? kU64 : kU32;
+  GlobalPlan pl;
+  pl.fast = (eos == MLX_EOS_WRIGHT) && (p_mode == MLX_P_ZPROF) && (plane % vec == 0) &&
+            (sT % vec == 0) && (sS % vec == 0) && !(sT == 0 && sS == 0) && aligned(T, 16) &&
+            aligned(S, 16) && aligned(vol0, 16);
+  const int64_t cells = pl.fast ? (int64_t)mlx::kBlock * vec * u : (int64_t)mlx::kBlock * kUGen;
+  pl.grid_x = ceil_div(plane, cells);
+  pl.nblk_total = pl.grid_x * nz;
+  return pl;
+}
+
+int check_dtype(int dtype) {
+  if (dtype != MLX_DTYPE_F64 && dtype != MLX_DTYPE_F32 && dtype != MLX_DTYPE_F32_UPCAST)
+    return fail(MLX_E_ENUM, "dtype must be MLX_DTYPE_F64, _F32 or _F32_UPCAST");
+  return 0;
+}
+
+int check_common(const void* T, const void* S, int dtype, const double* p, int p_mode, int eos,
+                 int64_t nt, int64_t nz, int64_t plane, int64_t sT, int64_t sS, bool allow4d) {
+  if (!T || !S) return fail(MLX_E_NULL, "T and S must not be NULL");
+  if (int rc = check_dtype(dtype)) return rc;
+  if (eos != MLX_EOS_WRIGHT && eos != MLX_EOS_LINEAR) return fail(MLX_E_ENUM, "unknown eos");
+  if (p_mode < MLX_P_SCALAR || p_mode > (allow4d ? MLX_P_FULL4D : MLX_P_FULL3D))
+    return fail(MLX_E_ENUM, "p_mode not supported by this entry point");
+  if (!p && eos == MLX_EOS_WRIGHT) return fail(MLX_E_NULL, "p must not be NULL for the Wright EOS");
+  if (nt <= 0 || nz <= 0 || plane <= 0) return fail(MLX_E_SHAPE, "nt, nz, plane must be > 0");
+  if (nz > 65535) return fail(MLX_E_SHAPE, "nz must be <= 65535");
+  if (nt > 2147483647LL) return fail(MLX_E_SHAPE, "nt too large");
+  if (sT < 0 || sS < 0) return fail(MLX_E_SHAPE, "time strides must be >= 0");
+  const size_t es = (dtype == MLX_DTYPE_F64) ? 8 : 4;
+  if (!aligned(T, es) || !aligned(S, es)) return fail(MLX_E_ALIGN, "T/S not element-aligned");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mlx_version(void) { return MLX_ABI_VERSION; }
+
+int mlx_last_error(char* buf, size_t n) {
+  if (buf && n) {
+    strncpy(buf, g_err, n - 1);
+    buf[n - 1] = 0;
+  }
+  return (int)strlen(g_err);
+}
+
+// ---------------------------------------------------------------------------- K0
+int mlx_eos_map(const void* T, const void* S, int dtype, const double* p, int p_mode, int eos,
+                int func, int64_t nt, int64_t nz, int64_t plane, int64_t sT, int64_t sS,
+                double* out, void* stream) {
+  using namespace mlx;
+  if (int rc = check_common(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS, true)) return rc;
+  if (!out) return fail(MLX_E_NULL, "out must not be NULL");
+  if (func < MLX_FUNC_DENSITY || func > MLX_FUNC_BETA) return fail(MLX_E_ENUM, "unknown func");
+  if (eos == MLX_EOS_LINEAR && func != MLX_FUNC_DENSITY)
+    return fail(MLX_E_ENUM, "the linear EOS kernel provides density only");
+  hipStream_t st = (hipStream_t)stream;
+  const bool f64 = (dtype == MLX_DTYPE_F64);
+  const int vec = f64 ? kVec64 : kVec32;
+  const bool fast = (eos == MLX_EOS_WRIGHT) && (p_mode == MLX_P_ZPROF) && (plane % vec == 0) &&
+                    (sT % vec == 0) && (sS % vec == 0) && aligned(T, 16) && aligned(S, 16) &&
+                    aligned(out, 16) && (f64 || func == MLX_FUNC_DENSITY);
+  const double* pp = p ? p : out;  // never dereferenced for the linear EOS
+  for (int64_t tb = 0; tb < nt; tb += 32768) {
+    const int64_t ntc = (nt - tb < 32768) ? (nt - tb) : 32768;
+    if (fast) {
+      constexpr int U = 2;
+      dim3 grid((unsigned)ceil_div(plane, (int64_t)kBlock * vec * U), (unsigned)nz, (unsigned)ntc);
+#define MLX_LAUNCH_K0(TIN, VEC, MODE, FUNC)                                                     \
+  hipLaunchKernelGGL((k_eos_map<TIN, VEC, U, MODE, FUNC, false>), grid, dim3(kBlock), 0, st,     \
+                     (const TIN*)T, (const TIN*)S, pp, p_mode, eos, func, nz, plane, sT, sS, tb, \
+                     out)
+      if (f64) {
+        switch (func) {
+          case MLX_FUNC_DENSITY: MLX_LAUNCH_K0(double, 2, kF64, kDensity); break;
+          case MLX_FUNC_DRHO_DTEMP: MLX_LAUNCH_K0(double, 2, kF64, kDrhoDtemp); break;
+          case MLX_FUNC_DRHO_DSAL: MLX_LAUNCH_K0(double, 2, kF64, kDrhoDsal); break;
+          case MLX_FUNC_ALPHA: MLX_LAUNCH_K0(double, 2, kF64, kAlpha); break;
+          default: MLX_LAUNCH_K0(double, 2, kF64, kBeta); break;
+        }
+      } else if (dtype == MLX_DTYPE_F32) {
+        MLX_LAUNCH_K0(float, 4, kF32Faithful, kDensity);
+      } else {
+        MLX_LAUNCH_K0(float, 4, kF32Upcast, kDensity);
+      }
+#undef MLX_LAUNCH_K0
+    } else {
+      constexpr int U = 4;
+      dim3 grid((unsigned)ceil_div(plane, (int64_t)kBlock * U), (unsigned)nz, (unsigned)ntc);
+#define MLX_LAUNCH_K0G(TIN, MODE)                                                               \
+  hipLaunchKernelGGL((k_eos_map<TIN, 1, U, MODE, 0, true>), grid, dim3(kBlock), 0, st,           \
+                     (const TIN*)T, (const TIN*)S, pp, p_mode, eos, func, nz, plane, sT, sS, tb, \
+                     out)
+      if (f64) MLX_LAUNCH_K0G(double, kF64);
+      else if (dtype == MLX_DTYPE_F32) MLX_LAUNCH_K0G(float, kF32Faithful);
+      else MLX_LAUNCH_K0G(float, kF32Upcast);
+#undef MLX_LAUNCH_K0G
+    }
+  }
+  return hip_status(hipGetLastError(), "mlx_eos_map launch");
+}
+
+// ---------------------------------------------------------------------------- K1
+size_t mlx_steric_global_workspace_bytes(int64_t nt, int64_t nz, int64_t plane) {
+  if (nt <= 0 || nz <= 0 || plane <= 0) return 0;
+  // the generic path has the smaller tile, hence the larger block count: size for it
+  const int64_t nblk = ceil_div(plane, (int64_t)mlx::kBlock * kUGen) * nz;
+  return (size_t)(nt * nblk) * sizeof(double);
+}
+
+int mlx_steric_global(const void* T, const void* S, int dtype, const double* vol0, const double* p,
+                      int p_mode, int eos, int64_t nt, int64_t nz, int64_t plane, int64_t sT,
+                      int64_t sS, double* masso_out, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+  using namespace mlx;
+  if (int rc = check_common(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS, false)) return rc;
+  if (!vol0 || !masso_out) return fail(MLX_E_NULL, "vol0 and masso_out must not be NULL");
+  if (!workspace) return fail(MLX_E_NULL, "workspace must not be NULL");
+  if (!aligned(workspace, 8) || workspace_bytes < mlx_steric_global_workspace_bytes(nt, nz, plane))
+    return fail(MLX_E_WORKSPACE, "workspace smaller than mlx_steric_global_workspace_bytes()");
+  hipStream_t st = (hipStream_t)stream;
+  const GlobalPlan pl = plan_global(T, S, vol0, dtype, p_mode, eos, nz, plane, sT, sS);
+  double* partials = (double*)workspace;
+  dim3 grid((unsigned)pl.grid_x, (unsigned)nz);
+  const double* pp = p ? p : vol0;
+  const int hold = (sT == 0) ? 1 : ((sS == 0) ? 2 : 0);
+#define MLX_LAUNCH_K1(TIN, VEC, U, HOLD, MODE, GEN)                                              \
+  hipLaunchKernelGGL((k_steric_global<TIN, VEC, U, HOLD, MODE, GEN>), grid, dim3(kBlock), 0, st, \
+                     (const TIN*)T, (const TIN*)S, vol0, pp, p_mode, eos, (int)nt, plane, sT, sS, \
+                     partials, pl.nblk_total)
+  if (pl.fast) {
+    if (dtype == MLX_DTYPE_F64) {
+      if (hold == 0) MLX_LAUNCH_K1(double, kVec64, kU64, 0, kF64, false);
+      else if (hold == 1) MLX_LAUNCH_K1(double, kVec64, kU64, 1, kF64, false);
+      else MLX_LAUNCH_K1(double, kVec64, kU64, 2, kF64, false);
+    } else if (dtype == MLX_DTYPE_F32) {
+      if (hold == 0) MLX_LAUNCH_K1(float, kVec32, kU32, 0, kF32Faithful, false);
+      else if (hold == 1) MLX_LAUNCH_K1(float, kVec32, kU32, 1, kF32Faithful, false);
+      else MLX_LAUNCH_K1(float, kVec32, kU32, 2, kF32Faithful, false);
+    } else {
+      if (hold == 0) MLX_LAUNCH_K1(float, kVec32, kU32, 0, kF32Upcast, false);
+      else if (hold == 1) MLX_LAUNCH_K1(float, kVec32, kU32, 1, kF32Upcast, false);
+      else MLX_LAUNCH_K1(float, kVec32, kU32, 2, kF32Upcast, false);
+    }
+  } else {
+    if (dtype == MLX_DTYPE_F64) MLX_LAUNCH_K1(double, 1, kUGen, 0, kF64, true);
+    else if (dtype == MLX_DTYPE_F32) MLX_LAUNCH_K1(float, 1, kUGen, 0, kF32Faithful, true);
+    else MLX_LAUNCH_K1(float, 1, kUGen, 0, kF32Upcast, true);
+  }
+#undef MLX_LAUNCH_K1
+  if (int rc = hip_status(hipGetLastError(), "k_steric_global launch")) return rc;
+  hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)nt), dim3(kBlock), 0, st, partials,
+                     pl.nblk_total, masso_out);
+  return hip_status(hipGetLastError(), "k_reduce_rows launch");
+}
+
+// ---------------------------------------------------------------------------- K2
+int mlx_fold_mask(const double* rho0, const double* vol0, int64_t n, double* rho0m_out,
+                  void* stream) {
+  if (!rho0 || !vol0 || !rho0m_out) return fail(MLX_E_NULL, "rho0, vol0, rho0m_out must not be NULL");
+  if (n <= 0) return fail(MLX_E_SHAPE, "n must be > 0");
+  const int64_t blocks = ceil_div(n, mlx::kBlock);
+  hipLaunchKernelGGL(mlx::k_fold_mask, dim3((unsigned)(blocks < 8192 ? blocks : 8192)),
+                     dim3(mlx::kBlock), 0, (hipStream_t)stream, rho0, vol0, n, rho0m_out);
+  return hip_status(hipGetLastError(), "k_fold_mask launch");
+}
+
+int mlx_steric_local(const void* T, const void* S, int dtype, const double* rho0m,
+                     const double* vol0_surface, const double* dz, const double* z_i,
+                     const double* deptho, const double* p, int p_mode, int eos,
+                     double neg_inv_rhozero, int64_t nt, int64_t nz, int64_t plane, int64_t sT,
+                     int64_t sS, double* delta_rho_out, double* eta_out, void* stream) {
+  using namespace mlx;
+  if (int rc = check_common(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS, false)) return rc;
+  if (!rho0m || !vol0_surface || !eta_out)
+    return fail(MLX_E_NULL, "rho0m, vol0_surface and eta_out must not be NULL");
+  if (!dz && (!z_i || !deptho))
+    return fail(MLX_E_NULL, "either dz or both z_i and deptho must be given");
+  if (ceil_div(nt, kNTI) > 65535) return fail(MLX_E_SHAPE, "nt too large for one call: chunk it");
+  hipStream_t st = (hipStream_t)stream;
+  const bool f64 = (dtype == MLX_DTYPE_F64);
+  const int vec = f64 ? kVec64 : kVec32;
+  const bool fast = (eos == MLX_EOS_WRIGHT) && (p_mode == MLX_P_ZPROF) && (plane % vec == 0) &&
+                    (sT % vec == 0) && (sS % vec == 0) && !(sT == 0 && sS == 0) &&
+                    aligned(T, 16) && aligned(S, 16) && aligned(rho0m, 16) &&
+                    aligned(vol0_surface, 16) && aligned(eta_out, 16) &&
+                    (!dz || aligned(dz, 16)) && (dz || aligned(deptho, 16)) &&
+                    (!delta_rho_out || aligned(delta_rho_out, 16));
+  const double* pp = p ? p : rho0m;
+  const int hold = (sT == 0) ? 1 : ((sS == 0) ? 2 : 0);
+  const int v = fast ? vec : 1;
+  dim3 grid((unsigned)ceil_div(plane, (int64_t)kBlock * v), (unsigned)ceil_div(nt, kNTI));
+#define MLX_LAUNCH_K2(TIN, VEC, HOLD, MODE, GEN)                                                 \
+  hipLaunchKernelGGL((k_steric_local<TIN, VEC, kNTI, HOLD, MODE, GEN>), grid, dim3(kBlock), 0,   \
+                     st, (const TIN*)T, (const TIN*)S, rho0m, vol0_surface, dz, z_i, deptho, pp, \
+                     p_mode, eos, neg_inv_rhozero, (int)nt, (int)nz, plane, sT, sS,              \
+                     delta_rho_out, eta_out)
+  if (fast) {
+    if (f64) {
+      if (hold == 0) MLX_LAUNCH_K2(double, kVec64, 0, kF64, false);
+      else if (hold == 1) MLX_LAUNCH_K2(double, kVec64, 1, kF64, false);
+      else MLX_LAUNCH_K2(double, kVec64, 2, kF64, false);
+    } else if (dtype == MLX_DTYPE_F32) {
+      if (hold == 0) MLX_LAUNCH_K2(float, kVec32, 0, kF32Faithful, false);
+      else if (hold == 1) MLX_LAUNCH_K2(float, kVec32, 1, kF32Faithful, false);
+      else MLX_LAUNCH_K2(float, kVec32, 2, kF32Faithful, false);
+    } else {
+      if (hold == 0) MLX_LAUNCH_K2(float, kVec32, 0, kF32Upcast, false);
+      else if (hold == 1) MLX_LAUNCH_K2(float, kVec32, 1, kF32Upcast, false);
+      else MLX_LAUNCH_K2(float, kVec32, 2, kF32Upcast, false);
+    }
+  } else {
+    if (f64) MLX_LAUNCH_K2(double, 1, 0, kF64, true);
+    else if (dtype == MLX_DTYPE_F32) MLX_LAUNCH_K2(float, 1, 0, kF32Faithful, true);
+    else MLX_LAUNCH_K2(float, 1, 0, kF32Upcast, true);
+  }
+#undef MLX_LAUNCH_K2
+  return hip_status(hipGetLastError(), "k_steric_local launch");
+}
+
+// ---------------------------------------------------------------------------- sums
+static int64_t nansum_blocks(int64_t n) {
+  const int64_t b = ceil_div(n, (int64_t)mlx::kBlock * 8);
+  return b < 1 ? 1 : (b > 4096 ? 4096 : b);
+}
+
+size_t mlx_nansum_workspace_bytes(int64_t n) {
+  if (n <= 0) return 0;
+  return (size_t)nansum_blocks(n) * sizeof(double);
+}
+
+int mlx_nansum(const double* x, int64_t n, double* out, void* workspace, size_t workspace_bytes,
+               void* stream) {
+  if (!x || !out || !workspace) return fail(MLX_E_NULL, "x, out, workspace must not be NULL");
+  if (n <= 0) return fail(MLX_E_SHAPE, "n must be > 0");
+  if (workspace_bytes < mlx_nansum_workspace_bytes(n))
+    return fail(MLX_E_WORKSPACE, "workspace smaller than mlx_nansum_workspace_bytes()");
+  const int64_t nb = nansum_blocks(n);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(mlx::k_nansum_partial, dim3((unsigned)nb), dim3(mlx::kBlock), 0, st, x, n,
+                     (double*)workspace);
+  hipLaunchKernelGGL(mlx::k_reduce_rows, dim3(1), dim3(mlx::kBlock), 0, st,
+                     (const double*)workspace, nb, out);
+  return hip_status(hipGetLastError(), "mlx_nansum launch");
+}
+
+int mlx_masso(const double* rho, const double* vol, int64_t nt, int64_t n3, int64_t vol_t_stride,
+              double* masso_out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!rho || !vol || !masso_out || !workspace)
+    return fail(MLX_E_NULL, "rho, vol, masso_out, workspace must not be NULL");
+  if (nt <= 0 || n3 <= 0 || nt > 65535) return fail(MLX_E_SHAPE, "need 0 < nt <= 65535, n3 > 0");
+  if (vol_t_stride != 0 && vol_t_stride != n3)
+    return fail(MLX_E_SHAPE, "vol_t_stride must be 0 or n3");
+  const int64_t nb = nansum_blocks(n3);
+  if (workspace_bytes < (size_t)(nt * nb) * sizeof(double) ||
+      workspace_bytes < mlx_steric_global_workspace_bytes(nt, 1, n3))
+    return fail(MLX_E_WORKSPACE, "workspace smaller than mlx_steric_global_workspace_bytes(nt,1,n3)");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(mlx::k_masso_partial, dim3((unsigned)nb, (unsigned)nt), dim3(mlx::kBlock), 0,
+                     st, rho, vol, n3, vol_t_stride, (double*)workspace);
+  hipLaunchKernelGGL(mlx::k_reduce_rows, dim3((unsigned)nt), dim3(mlx::kBlock), 0, st,
+                     (const double*)workspace, nb, masso_out);
+  return hip_status(hipGetLastError(), "mlx_masso launch");
+}
+
+int mlx_calc_dz(const double* z_i, const double* depth, int64_t nz, int64_t plane, double top,
+                double bottom, int has_bottom, int fraction, double* dz_out, void* stream) {
+  if (!z_i || !depth || !dz_out) return fail(MLX_E_NULL, "z_i, depth, dz_out must not be NULL");
+  if (nz <= 0 || plane <= 0) return fail(MLX_E_SHAPE, "nz and plane must be > 0");
+  hipLaunchKernelGGL(mlx::k_calc_dz, dim3((unsigned)ceil_div(plane, mlx::kBlock)),
+                     dim3(mlx::kBlock), 0, (hipStream_t)stream, z_i, depth, nz, plane, top, bottom,
+                     has_bottom, fraction, dz_out);
+  return hip_status(hipGetLastError(), "k_calc_dz launch");
+}
+
+int mlx_synth_field(void* out, int dtype, int64_t nt, int64_t nz, int64_t ny, int64_t nx,
+                    int64_t t0, int64_t NY, int64_t NX, int64_t y0, int64_t x0, uint64_t seed,
+                    int field_id, double lo, double scale, const double* mask3d, void* stream) {
+  if (!out) return fail(MLX_E_NULL, "out must not be NULL");
+  if (nt <= 0 || nz <= 0 || ny <= 0 || nx <= 0) return fail(MLX_E_SHAPE, "dims must be > 0");
+  if (y0 < 0 || x0 < 0 || y0 + ny > NY || x0 + nx > NX)
+    return fail(MLX_E_SHAPE, "tile does not fit the global grid");
+  if (field_id < 0 || field_id > 15) return fail(MLX_E_ENUM, "field_id must be 0..15");
+  const int64_t n = nt * nz * ny * nx;
+  const int64_t want = ceil_div(n, mlx::kBlock);
+  dim3 grid((unsigned)(want < 16384 ? want : 16384));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MLX_DTYPE_F64)
+    hipLaunchKernelGGL(mlx::k_synth<double>, grid, dim3(mlx::kBlock), 0, st, (double*)out, nt, nz,
+                       ny, nx, t0, NY, NX, y0, x0, (unsigned long long)seed, field_id, lo, scale,
+                       mask3d);
+  else if (dtype == MLX_DTYPE_F32 || dtype == MLX_DTYPE_F32_UPCAST)
+    hipLaunchKernelGGL(mlx::k_synth<float>, grid, dim3(mlx::kBlock), 0, st, (float*)out, nt, nz,
+                       ny, nx, t0, NY, NX, y0, x0, (unsigned long long)seed, field_id, lo, scale,
+                       mask3d);
+  else
+    return fail(MLX_E_ENUM, "dtype must be MLX_DTYPE_F64 or MLX_DTYPE_F32");
+  return hip_status(hipGetLastError(), "k_synth launch");
+}
+
+}  // extern "C"

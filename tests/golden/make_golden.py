@@ -1,0 +1,130 @@
+"""Generate the committed golden vectors under tests/golden/.
+
+Run ONCE in the build container, where /root/reference exists:
+
+    python -B tests/golden/make_golden.py
+
+(-B: the process is root, a plain import would drop __pycache__ into the
+read-only reference tree.)
+
+Two files are written:
+
+* ``wright_vectors.npz`` -- inputs and the outputs of the REFERENCE'S OWN
+  ``src/momlevel/eos/wright.py`` (loaded standalone with importlib: the module
+  has no imports, the package itself is not importable here because xarray /
+  xgcm / cftime are absent).  These pin the oracle's EOS restatement -- and,
+  through it, the HIP kernels -- pointwise and bit for bit.
+* ``steric_cases.npz`` -- outputs of ``oracle.momlevel_numpy`` on the
+  reference's ``generate_test_data()`` datasets, for the quantities the
+  reference's own tests do not pin tightly (the ``domain="global"`` variants:
+  tests/test_steric.py:80-125 are atol-dominated).  Labelled "oracle-pinned".
+
+The text of no reference source file is stored: only numbers.
+"""
+
+import importlib.util
+import os
+import sys
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+REF_WRIGHT = "/root/reference/src/momlevel/eos/wright.py"
+
+
+def load_reference_wright():
+    spec = importlib.util.spec_from_file_location("ref_wright", REF_WRIGHT)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def main():
+    ref = load_reference_wright()
+    out = {}
+
+    # (1) the reference's own test inputs: tests/test_wright.py:4-8
+    rng = np.random.default_rng(123)
+    out["tw_T"] = rng.normal(15.0, 5.0, (5, 5))
+    out["tw_S"] = rng.normal(35.0, 1.5, (5, 5))
+    out["tw_p"] = rng.normal(2000.0, 500.0, (5, 5))
+
+    # (2) dense random, oceanographic range and beyond, incl. NaN / inf / zeros
+    rng = np.random.default_rng(20251114)
+    n = 4096
+    T = rng.uniform(-2.0, 32.0, n)
+    S = rng.uniform(30.0, 40.0, n)
+    p = rng.uniform(101325.0, 6.1e7, n)
+    T[:8] = [np.nan, 0.0, -0.0, 40.0, -5.0, np.inf, 15.0, 15.0]
+    S[:8] = [35.0, 0.0, 35.0, 45.0, 0.0, 35.0, np.nan, 35.0]
+    p[:8] = [2e5, 0.0, 101325.0, 1.1e8, 101325.0, 2e5, 2e5, np.nan]
+    out["rnd_T"], out["rnd_S"], out["rnd_p"] = T, S, p
+
+    # (3) a (nt,nz,ny,nx) block with a z-profile pressure, the shape calc_rho sees
+    out["blk_T"] = rng.uniform(-2.0, 32.0, (3, 7, 6, 10))
+    out["blk_S"] = rng.uniform(30.0, 40.0, (3, 7, 6, 10))
+    z_l = np.cumsum(2.0 * 1.075 ** np.arange(7)) * 40.0
+    out["blk_p"] = (z_l * 1.0e4 + 101325.0)[:, None, None]
+
+    for tag in ("tw", "rnd", "blk"):
+        T, S, p = out[f"{tag}_T"], out[f"{tag}_S"], out[f"{tag}_p"]
+        with np.errstate(all="ignore"):
+            out[f"{tag}_density"] = ref.density(T, S, p)
+            out[f"{tag}_drho_dtemp"] = ref.drho_dtemp(T, S, p)
+            out[f"{tag}_drho_dsal"] = ref.drho_dsal(T, S, p)
+            out[f"{tag}_alpha"] = ref.alpha(T, S, p)
+            out[f"{tag}_beta"] = ref.beta(T, S, p)
+
+    # (4) float32 theta/S with float64 pressure: numpy keeps al0,p0,lam in
+    # float32 (python-float constants are weak scalars) -- SURVEY 3.4 #7
+    T32 = out["blk_T"].astype(np.float32)
+    S32 = out["blk_S"].astype(np.float32)
+    out["f32_T"], out["f32_S"] = T32, S32
+    out["f32_density"] = ref.density(T32, S32, out["blk_p"])
+    assert out["f32_density"].dtype == np.float64
+
+    # scalars of tests/test_wright.py:11-12,30-31,50-51,70-71,120-121
+    out["scalar_args"] = np.array([18.0, 35.0, 200000.0])
+    out["scalar_out"] = np.array(
+        [
+            ref.density(18.0, 35.0, 200000.0),
+            ref.drho_dtemp(18.0, 35.0, 200000.0),
+            ref.drho_dsal(18.0, 35.0, 200000.0),
+            ref.alpha(18.0, 35.0, 200000.0),
+            ref.beta(18.0, 35.0, 200000.0),
+        ]
+    )
+    np.savez_compressed(os.path.join(HERE, "wright_vectors.npz"), **out)
+
+    # ---- oracle-pinned steric cases on the reference's test dataset ----------
+    from oracle import momlevel_numpy as o
+
+    d = o.generate_test_data()
+    cases = {}
+    for variant in ("steric", "thermosteric", "halosteric"):
+        res, refst = o.steric(
+            d["thetao"], d["so"], d["volcello"], d["areacello"], d["z_l"],
+            variant=variant, domain="global",
+        )
+        cases[f"global_{variant}"] = res[variant]
+        cases[f"global_{variant}_masso"] = res["masso"]
+        cases["global_reference_height"] = np.float64(res["reference_height"])
+        res, refst = o.steric(
+            d["thetao"], d["so"], d["volcello"], d["areacello"], d["z_l"],
+            d["z_i"], d["deptho"], variant=variant, domain="local",
+        )
+        cases[f"local_{variant}"] = res[variant]
+        cases[f"local_{variant}_delta_rho"] = res["delta_rho"]
+    cases["ref_rho"] = refst["rho"]
+    cases["ref_volo"] = np.float64(refst["volo"])
+    cases["ref_masso"] = np.float64(refst["masso"])
+    cases["ref_rhoga"] = np.float64(refst["rhoga"])
+    np.savez_compressed(os.path.join(HERE, "steric_cases.npz"), **cases)
+    print("wrote", sorted(os.listdir(HERE)))
+
+
+if __name__ == "__main__":
+    main()
