@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""bench.py -- Mcells/s of the fused Wright-EOS + steric pass on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (N=1): BASELINE.json configs[2], the roofline config -- OM4 0.25-degree synthetic
+grid 1440x1080x75, 120 time steps, fp64, global steric -- with theta/S (2 x 112 GB) resident
+in HBM before the timed region starts.  One *step* = one pass of the hot path over that
+batch: reference state (K0 rho0, volo, masso0) + K1 over all 120 time steps + the stage-2
+reduce + the area sum + [N>1: one RCCL all-reduce of nt+3 doubles] + the host epilogue
+(D2H of masso(t), log, scale).  A cell is one (t,z,y,x) grid point, wet or dry.
+
+N>1 (weak scaling): the (yh,xh) plane is tiled 1x2 / 2x2 / 2x4 over the ranks and every
+rank holds 120*N time steps of its tile, so the bytes per GPU stay those of N=1; value =
+all ranks' cells / max-over-ranks time.
+
+Besides the contract fields the JSON line carries
+  roofline     -- K1 (k_steric_global): 16 algorithmic bytes per cell x cells per launch /
+                  mean launch duration (HIP events on the launch stream, inside the timed
+                  region) against the 8 TB/s HBM3E peak;
+  cpu_baseline -- the numpy oracle (op-for-op restatement of the reference's CPU path) timed
+                  on this host, one thread, on a bounded sample of the same fields (rank 0,
+                  N=1 only) -- a reported baseline, not the target;
+  parity       -- max relative difference GPU vs oracle on that sample (masso per slab).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from momlevel_amd import core, engine, parallel, synthetic  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_CELL = 16    # theta 8 + S 8; vol0/p are amortised over the time loop
+GRID = (75, 1080, 1440)
+NT_PER_GPU = 120
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nt", type=int, default=NT_PER_GPU, help="time steps per GPU")
+    ap.add_argument("--grid", default=None, help="nz,ny,nx (default 75,1080,1440)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+                    help="target seconds of CPU-baseline work (0 disables it)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the local-variant timings")
+    return ap.parse_args()
+
+
+def fit_nt(nt, nz, ny, nx, device):
+    """Largest nt <= requested whose theta+S fit in free HBM with ~14 GB of headroom."""
+    free, _ = torch.cuda.mem_get_info(device)
+    n3 = nz * ny * nx
+    headroom = 14 * (1 << 30) + 6 * n3 * 8
+    cap = int((free - headroom) // (2 * n3 * 8))
+    return max(1, min(nt, cap))
+
+
+def cpu_baseline(T, S, g, pres, target_s, gpu_masso):
+    """Oracle timed on host cores over whole time slabs of the resident fields."""
+    from oracle import momlevel_numpy as o  # the checker / timed baseline, never the product
+
+    nz, ny, nx = T.shape[1:]
+    cells = nz * ny * nx
+    vol = g["volcello"]
+    spent, slabs, err = 0.0, 0, 0.0
+    for t in range(min(T.shape[0], 8)):
+        Tn = T[t].cpu().numpy()
+        Sn = S[t].cpu().numpy()
+        t0 = time.perf_counter()
+        rho = o.calc_rho(Tn, Sn, pres)
+        m = o.calc_masso(rho, vol)
+        spent += time.perf_counter() - t0
+        slabs += 1
+        err = max(err, abs(m - gpu_masso[t]) / abs(m))
+        del rho, Tn, Sn
+        if spent >= target_s:
+            break
+    return {
+        "value": round(slabs * cells / spent / 1e6, 3),
+        "unit": "Mcells/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": (f"{slabs} of {T.shape[0]} time slabs ({nx}x{ny}x{nz} cells each) of the same "
+                   "synthetic fields: unfused numpy wright density + nansum(rho*volcello_ref), "
+                   f"{spent:.1f} s on 1 thread"),
+    }, {"masso_max_rel_err_vs_oracle": float(err), "slabs_checked": slabs}
+
+
+def main():
+    a = parse()
+    rank, world, local_rank = parallel.init_from_env()
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        a.gpus = world
+    core.require_device()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    nz, ny, nx = (tuple(int(v) for v in a.grid.split(",")) if a.grid else GRID)
+    tile = synthetic.tile_bounds(ny, nx, rank, world)
+    th, tw = tile[1] - tile[0], tile[3] - tile[2]
+    g = synthetic.make_grid(ny, nx, nz, tile=tile)
+    nt_req = a.nt * world
+    nt = fit_nt(nt_req, nz, th, tw, dev)
+    if world > 1:  # every rank must run the same number of steps
+        t = torch.tensor([nt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        nt = int(t.item())
+
+    vol0 = torch.from_numpy(g["volcello"]).to(dev)
+    area = torch.from_numpy(g["areacello"]).to(dev)
+    pres = torch.from_numpy(np.asarray(g["z_l"]) * 1.0e4 + 101325.0).to(dev)
+    shape = (nt, nz, th, tw)
+    kw = dict(seed=synthetic.SEED, mask3d=vol0, global_hw=(ny, nx), origin=g["origin"], device=dev)
+    T = core.synth_field(shape, torch.float64, field_id=synthetic.FIELD_THETAO,
+                         lo=synthetic.THETA_LO, scale=synthetic.THETA_SCALE, **kw)
+    S = core.synth_field(shape, torch.float64, field_id=synthetic.FIELD_SO,
+                         lo=synthetic.SO_LO, scale=synthetic.SO_SCALE, **kw)
+    torch.cuda.synchronize(dev)
+
+    launch_ms = []
+
+    def step(timed):
+        """One pass of the hot path over the resident batch (what momlevel.steric(global) does)."""
+        _rho0, volo, masso0 = engine.reference_state(T[0], S[0], vol0, pres)
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        masso = engine.global_masso(T, S, vol0, pres, events=ev)
+        asum = core.nansum(area)
+        red = parallel.exchange_global(masso, volo, masso0, asum)
+        out = parallel.finalize(*red)  # D2H + host epilogue (synchronises)
+        if timed:
+            launch_ms.append(ev)
+        return out
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        out = step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    cells_rank = nt * nz * th * tw
+    cells_job = cells_rank * world
+    k1_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in launch_ms]))
+    achieved = BYTES_PER_CELL * cells_rank / (k1_ms * 1e-3) / 1e9
+
+    extras = {}
+    if not a.no_extras and rank == 0:
+        extras = local_variant_timings(T, S, vol0, pres, g, dev)
+
+    cpu, parity = None, None
+    if world == 1 and a.cpu_seconds > 0:
+        cpu, parity = cpu_baseline(T, S, g, pres.cpu().numpy(), a.cpu_seconds, out["masso"])
+
+    if rank == 0:
+        layout = {1: "1x1", 2: "1x2", 4: "2x2", 8: "2x4"}.get(world, f"1x{world}")
+        line = {
+            "metric": "Mcells/s for fused Wright-EOS+steric at 1440x1080x75; % HBM roofline",
+            "value": round(cells_job / elapsed / 1e6, 1),
+            "unit": "Mcells/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": (f"OM4 0.25deg synthetic grid {nx}x{ny}x{nz}, {nt_req // world} time "
+                             "steps per GPU, fp64, global steric (BASELINE.json configs[2])"),
+                "grid_xyz": [nx, ny, nz],
+                "nt_per_gpu_resident": nt,
+                "nt_total": nt,
+                "tile_layout_yx": layout,
+                "tile_xy": [tw, th],
+                "variant": "steric",
+                "domain": "global",
+                "collective": "none" if world == 1 else f"1 all_reduce of {nt + 3} f64 per step",
+                "hbm_resident_gb": round(2 * cells_rank * 8 / 1e9, 1),
+            },
+            "roofline": {
+                "kernel": "k_steric_global<double,2,4,0,0,false>",
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "launch_ms": round(k1_ms, 4),
+                "algorithmic_bytes_per_cell": BYTES_PER_CELL,
+                "cells_per_launch": cells_rank,
+            },
+            "cpu_baseline": cpu,
+            "parity": parity,
+            "eta_t0_is_zero": bool(out["eta"][0] == 0.0),
+        }
+        line.update(extras)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _time(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return best
+
+
+def local_variant_timings(T, S, vol0, pres, g, dev):
+    """Informative: the other variants on the same resident fields (outside the timed region)."""
+    nt, nz, ny, nx = T.shape
+    cells = nt * nz * ny * nx
+    out = {}
+    ms = _time(lambda: core.steric_global_masso(T, S[0], vol0, pres))
+    out["thermosteric_global"] = {"Mcells/s": round(cells / ms / 1e3, 1),
+                                  "GB/s_at_8B_per_cell": round(8 * cells / ms / 1e6, 1)}
+    rho0m = core.fold_mask(core.eos_map(T[0], S[0], pres), vol0)
+    zi = torch.from_numpy(g["z_i"]).to(dev)
+    dep = torch.from_numpy(g["deptho"]).to(dev)
+    eta = torch.empty((nt, ny, nx), dtype=torch.float64, device=dev)
+    ms = _time(lambda: core.steric_local(T, S, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=zi,
+                                         deptho=dep, want_delta_rho=False, eta_out=eta))
+    out["local_eta_only"] = {"Mcells/s": round(cells / ms / 1e3, 1),
+                             "GB/s_at_16B_per_cell": round(16 * cells / ms / 1e6, 1)}
+    chunk = min(nt, 8)
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free > chunk * nz * ny * nx * 8 + (2 << 30):
+        drho = torch.empty((chunk, nz, ny, nx), dtype=torch.float64, device=dev)
+
+        def run():
+            for t0 in range(0, nt - chunk + 1, chunk):
+                core.steric_local(T[t0:t0 + chunk], S[t0:t0 + chunk], rho0m, vol0[0], pres,
+                                  -1.0 / 1035.0, z_i=zi, deptho=dep, delta_rho_out=drho,
+                                  eta_out=eta[t0:t0 + chunk])
+
+        ms = _time(run, reps=2)
+        done = (nt // chunk) * chunk * nz * ny * nx
+        out["local_with_delta_rho"] = {"Mcells/s": round(done / ms / 1e3, 1),
+                                       "GB/s_at_24B_per_cell": round(24 * done / ms / 1e6, 1)}
+    return out
+
+
+if __name__ == "__main__":
+    main()

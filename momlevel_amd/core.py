@@ -131,8 +131,12 @@ def eos_map(T, S, p, eos="wright", func="density", f32_mode="faithful"):
     return out[0] if squeeze else out
 
 
-def steric_global_masso(T, S, vol0, p, eos="wright", f32_mode="faithful"):
-    """K1: masso[t] = sum_{z,y,x} rho(T,S,p) * vol0  (skipna) -> (nt,) float64."""
+def steric_global_masso(T, S, vol0, p, eos="wright", f32_mode="faithful", events=None):
+    """K1: masso[t] = sum_{z,y,x} rho(T,S,p) * vol0  (skipna) -> (nt,) float64.
+
+    ``events=(start, end)``: two ``torch.cuda.Event(enable_timing=True)`` recorded on the
+    launch stream immediately around the kernel launches (bench.py's per-launch timing).
+    """
     require_device()
     T, S, nt, nz, ny, nx, sT, sS, dt, _ = _pair(T, S, f32_mode)
     vol0 = _f64(vol0, T.device)
@@ -143,10 +147,14 @@ def steric_global_masso(T, S, vol0, p, eos="wright", f32_mode="faithful"):
     nbytes = lib.mlx_steric_global_workspace_bytes(nt, nz, ny * nx)
     ws = torch.empty(nbytes // 8, dtype=torch.float64, device=T.device)
     out = torch.empty(nt, dtype=torch.float64, device=T.device)
+    if events is not None:
+        events[0].record()
     rc = lib.mlx_steric_global(
         _ptr(T), _ptr(S), dt, _ptr(vol0), _ptr(pt), p_mode, EOS_IDS[eos.lower()],
         nt, nz, ny * nx, sT, sS, _ptr(out), _ptr(ws), nbytes, _stream(),
     )
+    if events is not None:
+        events[1].record()
     _lib.check(rc, "mlx_steric_global")
     return out
 
@@ -214,21 +222,19 @@ def nansum(x):
 
 
 def masso(rho, vol):
-    """Standalone calc_masso: sum(rho*vol) [skipna] over every non-time dim."""
+    """Standalone calc_masso: rho (nt, n3), vol (n3,) or (nt, n3) -> sum(rho*vol) [skipna], (nt,)."""
     require_device()
     rho = _f64(rho, rho.device)
     vol = _f64(vol, rho.device)
-    squeeze = rho.dim() == 3
-    if squeeze:
-        rho = rho.unsqueeze(0)
-    nt = rho.shape[0]
-    n3 = rho[0].numel()
-    if tuple(vol.shape) == tuple(rho.shape[1:]):
+    if rho.dim() != 2:
+        raise ValueError("rho must be (nt, n3)")
+    nt, n3 = rho.shape
+    if tuple(vol.shape) == (n3,):
         vstride = 0
-    elif tuple(vol.shape) == tuple(rho.shape):
+    elif tuple(vol.shape) == (nt, n3):
         vstride = n3
     else:
-        raise ValueError("volcello must be (z,y,x) or match rho")
+        raise ValueError("vol must be (n3,) or (nt, n3)")
     lib = _lib.load()
     nbytes = lib.mlx_steric_global_workspace_bytes(nt, 1, n3)
     ws = torch.empty(nbytes // 8, dtype=torch.float64, device=rho.device)
@@ -236,7 +242,7 @@ def masso(rho, vol):
     rc = lib.mlx_masso(_ptr(rho), _ptr(vol), nt, n3, vstride, _ptr(out), _ptr(ws), nbytes,
                        _stream())
     _lib.check(rc, "mlx_masso")
-    return out[0] if squeeze else out
+    return out
 
 
 def calc_dz(z_i, depth, top=0.0, bottom=None, fraction=False):

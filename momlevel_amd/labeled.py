@@ -1,0 +1,445 @@
+"""Minimal labelled-array containers with the slice of the xarray API the steric path uses.
+
+momlevel's boundary is xarray-in / xarray-out (src/momlevel/steric.py:17-31,184).
+xarray is an optional dependency here (it is absent from the build image): when
+it is importable, ``momlevel_amd`` accepts and returns real ``xarray`` objects
+(see ``adapters.py``); in every case the work is done on these two classes, which
+carry names, dims, coords, attrs and encoding but no arithmetic of their own
+beyond what input validation and the tests need.
+
+``DataArray.data`` is either a numpy array (host) or a torch tensor (device);
+``.values`` always gives numpy.  Nothing here is on the hot path: the 4-D fields
+are only ever *relabelled*; their numbers go through the HIP kernels.
+"""
+
+import copy as _copy
+
+import numpy as np
+
+try:  # torch is the device-array container; labelled arrays work without it
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _is_tensor(x):
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _to_numpy(x):
+    if _is_tensor(x):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+class DataArray:
+    """A named n-d array: data + dims + coords + attrs + encoding."""
+
+    __array_priority__ = 50
+
+    def __init__(self, data, dims=None, coords=None, attrs=None, name=None):
+        if isinstance(data, DataArray):
+            dims = data.dims if dims is None else dims
+            coords = data.coords if coords is None else coords
+            attrs = data.attrs if attrs is None else attrs
+            data = data.data
+        if not _is_tensor(data):
+            data = np.asarray(data)
+        ndim = data.dim() if _is_tensor(data) else data.ndim
+        if dims is None:
+            dims = tuple(f"dim_{i}" for i in range(ndim))
+        if isinstance(dims, str):
+            dims = (dims,)
+        dims = tuple(dims)
+        if len(dims) != ndim:
+            raise ValueError(f"{len(dims)} dims given for a {ndim}-d array")
+        self.data = data
+        self.dims = dims
+        self.coords = dict(coords) if coords else {}
+        self.attrs = dict(attrs) if attrs else {}
+        self.encoding = {}
+        self.name = name
+
+    # ---- basic properties ---------------------------------------------------------
+    @property
+    def values(self):
+        return _to_numpy(self.data)
+
+    @property
+    def shape(self):
+        return tuple(self.data.shape)
+
+    @property
+    def ndim(self):
+        return len(self.dims)
+
+    @property
+    def dtype(self):
+        return self.values.dtype if not _is_tensor(self.data) else np.dtype(
+            str(self.data.dtype).replace("torch.", "")
+        )
+
+    @property
+    def sizes(self):
+        return dict(zip(self.dims, self.shape))
+
+    @property
+    def is_device(self):
+        return _is_tensor(self.data) and self.data.is_cuda
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __array__(self, dtype=None, copy=None):
+        v = self.values
+        return v.astype(dtype) if dtype is not None else v
+
+    def __float__(self):
+        return float(self.values)
+
+    def __bool__(self):
+        return bool(self.values)
+
+    def __repr__(self):
+        return f"<momlevel_amd.DataArray {self.name!r} {dict(self.sizes)}>"
+
+    def item(self):
+        return self.values.item()
+
+    # ---- construction helpers -----------------------------------------------------
+    def _like(self, data, dims=None, keep_attrs=False):
+        dims = self.dims if dims is None else dims
+        coords = {k: v for k, v in self.coords.items() if set(v.dims) <= set(dims)}
+        out = DataArray(data, dims, coords, self.attrs if keep_attrs else None, self.name)
+        return out
+
+    def copy(self, deep=True):
+        data = self.data
+        if deep:
+            data = data.clone() if _is_tensor(data) else np.array(data)
+        out = DataArray(data, self.dims, self.coords, self.attrs, self.name)
+        out.encoding = dict(self.encoding)
+        return out
+
+    # ---- indexing -------------------------------------------------------------------
+    def __getitem__(self, key):
+        if isinstance(key, str):
+            return self.coords[key]
+        if not isinstance(key, tuple):
+            key = (key,)
+        key = key + (slice(None),) * (self.ndim - len(key))
+        dims = tuple(d for d, k in zip(self.dims, key) if not isinstance(k, (int, np.integer)))
+        data = self.data[key]
+        out = self._like(data, dims, keep_attrs=True)
+        for d, k in zip(self.dims, key):
+            if d in out.coords and not isinstance(k, (int, np.integer)):
+                c = self.coords[d]
+                out.coords[d] = DataArray(c.data[k], (d,), None, c.attrs, d)
+        return out
+
+    def __setitem__(self, key, value):
+        self.data[key] = value.data if isinstance(value, DataArray) else value
+
+    def isel(self, indexers=None, **kw):
+        indexers = dict(indexers or {}, **kw)
+        key = tuple(indexers.get(d, slice(None)) for d in self.dims)
+        return self[key]
+
+    def squeeze(self):
+        keep = [i for i, n in enumerate(self.shape) if n != 1]
+        data = self.data.reshape([self.shape[i] for i in keep])
+        return self._like(data, tuple(self.dims[i] for i in keep), keep_attrs=True)
+
+    def reset_coords(self, drop=True):
+        out = self.copy(deep=False)
+        out.coords = {k: v for k, v in self.coords.items() if k in self.dims}
+        return out
+
+    def transpose(self, *dims):
+        dims = list(dims)
+        if Ellipsis in dims:
+            i = dims.index(Ellipsis)
+            rest = [d for d in self.dims if d not in dims]
+            dims = dims[:i] + rest + dims[i + 1:]
+        if not dims:
+            dims = list(reversed(self.dims))
+        if tuple(dims) == self.dims:
+            return self
+        perm = [self.dims.index(d) for d in dims]
+        data = self.data.permute(*perm) if _is_tensor(self.data) else self.data.transpose(perm)
+        out = self._like(data, tuple(dims), keep_attrs=True)
+        out.encoding = dict(self.encoding)
+        return out
+
+    def rename(self, name):
+        out = self.copy(deep=False)
+        out.name = name
+        return out
+
+    # ---- reductions / element-wise (host side, validation-sized) -------------------
+    def sum(self, dim=None, skipna=True):
+        v = self.values
+        fn = np.nansum if skipna else np.sum
+        if dim is None:
+            return DataArray(fn(v), (), None, None, self.name)
+        dims = (dim,) if isinstance(dim, str) else tuple(dim)
+        axes = tuple(self.dims.index(d) for d in dims)
+        keep = tuple(d for d in self.dims if d not in dims)
+        return self._like(fn(v, axis=axes), keep)
+
+    def mean(self, dim=None):
+        v = self.values
+        if dim is None:
+            return DataArray(np.nanmean(v), ())
+        dims = (dim,) if isinstance(dim, str) else tuple(dim)
+        axes = tuple(self.dims.index(d) for d in dims)
+        return self._like(np.nanmean(v, axis=axes), tuple(d for d in self.dims if d not in dims))
+
+    def notnull(self):
+        return self._like(~np.isnan(self.values))
+
+    def isnull(self):
+        return self._like(np.isnan(self.values))
+
+    def fillna(self, value):
+        v = self.values
+        return self._like(np.where(np.isnan(v), value, v), keep_attrs=True)
+
+    def where(self, cond, other=np.nan):
+        a, c = _align(self, cond if isinstance(cond, DataArray) else DataArray(cond, self.dims))
+        return DataArray(np.where(c[0], a[0], other), a[1], self.coords, self.attrs, self.name)
+
+    def astype(self, dtype):
+        return self._like(self.values.astype(dtype), keep_attrs=True)
+
+    def _binary(self, other, op, reflexive=False):
+        if isinstance(other, DataArray):
+            (a, dims), (b, _) = _align(self, other)
+            coords = dict(other.coords)
+            coords.update(self.coords)
+        else:
+            a, b, dims, coords = self.values, _to_numpy(other), self.dims, self.coords
+        res = op(b, a) if reflexive else op(a, b)
+        return DataArray(res, dims, {k: v for k, v in coords.items() if set(v.dims) <= set(dims)})
+
+    def __add__(self, o):
+        return self._binary(o, np.add)
+
+    def __radd__(self, o):
+        return self._binary(o, np.add, True)
+
+    def __sub__(self, o):
+        return self._binary(o, np.subtract)
+
+    def __rsub__(self, o):
+        return self._binary(o, np.subtract, True)
+
+    def __mul__(self, o):
+        return self._binary(o, np.multiply)
+
+    def __rmul__(self, o):
+        return self._binary(o, np.multiply, True)
+
+    def __truediv__(self, o):
+        return self._binary(o, np.divide)
+
+    def __rtruediv__(self, o):
+        return self._binary(o, np.divide, True)
+
+    def __neg__(self):
+        return self._like(-self.values)
+
+    def __ge__(self, o):
+        return self._binary(o, np.greater_equal)
+
+    def __lt__(self, o):
+        return self._binary(o, np.less)
+
+
+def _align(a, b):
+    """Broadcast two DataArrays by dim NAME (first-appearance order, as xarray does)."""
+    dims = list(a.dims) + [d for d in b.dims if d not in a.dims]
+
+    def expand(x):
+        v = x.values
+        order = [d for d in dims if d in x.dims]
+        v = v.transpose([x.dims.index(d) for d in order])
+        shape = [x.sizes[d] if d in x.dims else 1 for d in dims]
+        return v.reshape(shape)
+
+    return (expand(a), tuple(dims)), (expand(b), tuple(dims))
+
+
+class Dataset:
+    """An ordered mapping name -> DataArray sharing coordinates."""
+
+    def __init__(self, data_vars=None, coords=None, attrs=None):
+        object.__setattr__(self, "_vars", {})
+        object.__setattr__(self, "_coord_names", set())
+        object.__setattr__(self, "attrs", dict(attrs) if attrs else {})
+        for k, v in (coords or {}).items():
+            self._set(k, v, is_coord=True)
+        for k, v in (data_vars or {}).items():
+            self[k] = v
+
+    # ---- mapping protocol -----------------------------------------------------------
+    def _set(self, key, value, is_coord=False):
+        if isinstance(value, tuple):
+            dims, data = value[0], value[1]
+            attrs = value[2] if len(value) > 2 else None
+            value = DataArray(data, dims, None, attrs)
+        elif not isinstance(value, DataArray):
+            value = DataArray(value, ())
+        da = DataArray(value.data, value.dims, None, value.attrs, key)
+        da.encoding = dict(value.encoding)
+        # adopt coordinates that ride along on the DataArray
+        for cname, c in value.coords.items():
+            if cname not in self._vars:
+                cc = DataArray(c.data, c.dims, None, c.attrs, cname)
+                self._vars[cname] = cc
+                self._coord_names.add(cname)
+        self._vars[key] = da
+        if is_coord or (da.dims == (key,)):
+            self._coord_names.add(key)
+
+    def __setitem__(self, key, value):
+        self._set(key, value)
+
+    def __getitem__(self, key):
+        if isinstance(key, (list, tuple)):
+            return Dataset({k: self[k] for k in key if k not in self._coord_names},
+                           {k: self._vars[k] for k in self._coord_names}, self.attrs)
+        da = self._vars[key]
+        out = DataArray(da.data, da.dims, self._coords_for(da.dims, exclude=key), da.attrs, key)
+        out.encoding = da.encoding  # shared on purpose: result["x"].encoding["dtype"] = ... sticks
+        out.attrs = da.attrs
+        return out
+
+    def _coords_for(self, dims, exclude=None):
+        return {
+            k: self._vars[k]
+            for k in self._coord_names
+            if k != exclude and set(self._vars[k].dims) <= set(dims)
+        }
+
+    def __getattr__(self, key):
+        try:
+            return self[key]
+        except KeyError as exc:
+            raise AttributeError(key) from exc
+
+    def __setattr__(self, key, value):
+        if key == "attrs":
+            object.__setattr__(self, key, value)
+        else:
+            raise AttributeError("assign variables with dset[name] = ...")
+
+    def __contains__(self, key):
+        return key in self._vars
+
+    def __iter__(self):
+        return iter(self.data_vars)
+
+    def __len__(self):
+        return len(self.data_vars)
+
+    def __repr__(self):
+        return f"<momlevel_amd.Dataset vars={list(self.data_vars)} coords={sorted(self._coord_names)}>"
+
+    def keys(self):
+        return self.data_vars.keys()
+
+    @property
+    def variables(self):
+        return dict(self._vars)
+
+    @property
+    def data_vars(self):
+        return {k: self[k] for k in self._vars if k not in self._coord_names}
+
+    @property
+    def coords(self):
+        return {k: self[k] for k in self._vars if k in self._coord_names}
+
+    @property
+    def dims(self):
+        out = {}
+        for da in self._vars.values():
+            for d, n in zip(da.dims, da.shape):
+                out.setdefault(d, n)
+        return out
+
+    sizes = dims
+
+    # ---- the few Dataset methods the steric path and its tests use -----------------
+    def copy(self, deep=False):
+        out = Dataset(attrs=self.attrs)
+        for k, v in self._vars.items():
+            vv = v.copy(deep=deep)
+            vv.encoding = dict(v.encoding)
+            out._vars[k] = vv
+        out._coord_names.update(self._coord_names)
+        return out
+
+    def rename(self, name_dict=None):
+        """Dataset.rename(varname_map); None is a no-op (steric.py:84)."""
+        if not name_dict:
+            return self
+        out = Dataset(attrs=self.attrs)
+        for k, v in self._vars.items():
+            nk = name_dict.get(k, k)
+            dims = tuple(name_dict.get(d, d) for d in v.dims)
+            da = DataArray(v.data, dims, None, v.attrs, nk)
+            da.encoding = dict(v.encoding)
+            out._vars[nk] = da
+            if k in self._coord_names:
+                out._coord_names.add(nk)
+        return out
+
+    def drop_vars(self, names):
+        names = [names] if isinstance(names, str) else list(names)
+        out = self.copy()
+        for n in names:
+            out._vars.pop(n)
+            out._coord_names.discard(n)
+        return out
+
+    def isel(self, indexers=None, **kw):
+        indexers = dict(indexers or {}, **kw)
+        out = Dataset(attrs=self.attrs)
+        for k, v in self._vars.items():
+            sub = v.isel({d: i for d, i in indexers.items() if d in v.dims})
+            sub.coords = {}
+            out._vars[k] = sub
+            if k in self._coord_names:
+                out._coord_names.add(k)
+        return out
+
+    def sum(self, dim=None):
+        out = Dataset(attrs=self.attrs)
+        for k, v in self.data_vars.items():
+            if v.values.dtype.kind in "fiub":
+                out[k] = v.sum(dim) if (dim is None or dim in v.dims) else v
+        return out
+
+    def assign_coords(self, coords):
+        out = self.copy()
+        for k, v in coords.items():
+            out._set(k, v if isinstance(v, DataArray) else DataArray(np.asarray(v), (k,)),
+                     is_coord=True)
+        return out
+
+
+def where(cond, x, y):
+    """xr.where for the labelled classes (host side)."""
+    cond = cond if isinstance(cond, DataArray) else DataArray(cond)
+    x = x if isinstance(x, DataArray) else DataArray(np.asarray(x, dtype=np.float64), ())
+    (c, dims), (xv, _) = _align(cond, x)
+    if isinstance(y, DataArray):
+        (_, dims2), (yv, _) = _align(DataArray(np.broadcast_to(c, np.broadcast(c, xv).shape), dims), y)
+        return DataArray(np.where(c, xv, yv), dims2)
+    return DataArray(np.where(c, xv, y), dims)
+
+
+def deepcopy(obj):
+    return _copy.deepcopy(obj)

@@ -1,0 +1,205 @@
+"""Host-side helpers of the steric path: the reference's ``momlevel.util`` hot subset.
+
+Same names, argument meaning and error behaviour as src/momlevel/util.py
+(default_coords :199-224, eos_func_from_str :227-249, validate_areacello
+:669-694, validate_dataset :697-814, annual_average :49-119).  No device work
+except the area sum of device-resident ``areacello`` (mlx_nansum).
+"""
+
+import warnings
+
+import numpy as np
+
+from . import eos
+from .labeled import DataArray, Dataset
+
+__all__ = [
+    "annual_average",
+    "default_coords",
+    "eos_func_from_str",
+    "validate_areacello",
+    "validate_dataset",
+]
+
+
+def default_coords(coord_names=None):
+    """Default coordinate names ``(tcoord, zcoord, zbounds)`` (util.py:199-224)."""
+    coord_names = {} if coord_names is None else coord_names
+    assert isinstance(coord_names, dict), "Coordinate mapping must be a dictionary."
+    zcoord = coord_names["z"] if "z" in coord_names.keys() else "z_l"
+    zbounds = coord_names["zbounds"] if "zbounds" in coord_names.keys() else "z_i"
+    tcoord = coord_names["t"] if "t" in coord_names.keys() else "time"
+    return (tcoord, zcoord, zbounds)
+
+
+def eos_func_from_str(eos_str, func_name="density"):
+    """Resolve ``"Wright"`` -> ``momlevel_amd.eos.wright.density`` (util.py:227-249)."""
+    assert isinstance(eos_str, str), "Expecting string for equation of state"
+    eos_str = eos_str.lower()
+    avail_eos = list(eos.__dict__.keys())
+    if eos_str not in avail_eos or eos_str.startswith("_"):
+        raise ValueError(f"Unknown equation of state: {eos_str}")
+    return eos.__dict__[eos_str].__dict__[func_name]
+
+
+def _area_sum(areacello):
+    """skipna sum of areacello; on the device (mlx_nansum) when the data lives there."""
+    if isinstance(areacello, DataArray) and areacello.is_device:
+        from . import core
+
+        return float(core.nansum(areacello.data).item())
+    return float(np.nansum(np.asarray(areacello)))
+
+
+def validate_areacello(areacello, reference=3.6111092e14, tolerance=0.02):
+    """True if sum(areacello) is within +/-tolerance of the real ocean area (util.py:669-694)."""
+    error = (_area_sum(areacello) - reference) / reference
+    result = bool(np.abs(error) < tolerance)
+    return result
+
+
+def validate_dataset(dset, reference=False, strict=True, additional_vars=None):
+    """Presence / rank checks of an input or reference dataset (util.py:697-814).
+
+    Errors are collected, printed, and one ``ValueError("Errors found in dataset.")``
+    is raised.  ``strict=False`` only downgrades the areacello range check to a
+    ``UserWarning`` (util.py:783-792).
+    """
+    dset_varlist = list(dset.variables)
+    exceptions = []
+
+    # (the reference's "no time coordinate" check compares against unbound methods and
+    #  can never fire -- util.py:728-733; reproduced as a no-op)
+
+    expected_varlist = ["thetao", "so", "volcello", "areacello"]
+    if additional_vars is not None:
+        additional_vars = (
+            [additional_vars] if not isinstance(additional_vars, list) else additional_vars
+        )
+    else:
+        additional_vars = []
+    expected_varlist = expected_varlist + additional_vars
+
+    reference_varlist = ["rho", "volo", "masso", "rhoga"]
+    expected_varlist = expected_varlist + reference_varlist if reference else expected_varlist
+
+    missing = list(set(expected_varlist) - set(dset_varlist))
+    try:
+        assert len(missing) == 0, f"Reference dataset is missing variables: {missing}"
+    except AssertionError as e:
+        exceptions.append(e)
+
+    ranks = (3, "(z,y,x)") if reference else (4, ("t,z,y,x"))
+    for var in ["thetao", "so", "volcello"]:
+        if var in dset.variables:
+            try:
+                assert (
+                    len(dset[var].dims) == ranks[0]
+                ), f"Variable {var} must have exactly {ranks[0]} dimensions {ranks[1]}"
+            except AssertionError as e:
+                exceptions.append(e)
+
+    for var in ["areacello", "deptho"]:
+        if var in dset.variables:
+            try:
+                assert (
+                    len(dset[var].dims) == 2
+                ), f"Variable {var} must have exactly 2 dimensions (y,x)"
+            except AssertionError as e:
+                exceptions.append(e)
+
+    if "areacello" in dset.variables:
+        try:
+            assert validate_areacello(
+                dset["areacello"]
+            ), "Variable `areacello` field is out of range. It may not be masked."
+        except AssertionError as e:
+            if not strict:
+                warnings.warn(str(e))
+            else:
+                exceptions.append(e)
+
+    if reference:
+        if "rho" not in missing:
+            try:
+                assert (
+                    len(dset["rho"].dims) == 3
+                ), "Variable areacello must have exactly 3 dimensions (z,y,x)"
+            except AssertionError as e:
+                exceptions.append(e)
+        for var in ["masso", "volo", "rhoga"]:
+            if var not in missing:
+                try:
+                    assert len(dset[var].dims) == 0, f"Variable {var} must be a scalar"
+                except AssertionError as e:
+                    exceptions.append(e)
+
+    if len(exceptions) > 0:
+        for e in exceptions:
+            print(e)
+        raise ValueError("Errors found in dataset.")
+
+
+# ---------------------------------------------------------------------------------------
+# annual_average (util.py:49-119).  The time coordinate must hold calendar-aware
+# objects exposing .year, .month, .calendar and .daysinmonth -- cftime.datetime does;
+# momlevel_amd.cftime_lite.DatetimeLite is the stand-in when cftime is not installed.
+# ---------------------------------------------------------------------------------------
+def _annual_weights(time_values):
+    years = np.array([t.year for t in time_values])
+    weights = np.array([float(t.daysinmonth) for t in time_values])
+    return years, weights
+
+
+def _annual_mean_array(values, years, weights):
+    """Per-year weighted mean over axis 0 (xarray ``weighted(w).mean``: NaNs carry no weight)."""
+    out = []
+    for yr in sorted(set(years.tolist())):
+        sel = np.nonzero(years == yr)[0]
+        assert len(sel) == 12
+        x = values[sel]
+        w = weights[sel].reshape((12,) + (1,) * (x.ndim - 1))
+        num = np.sum(np.where(np.isnan(x), 0.0, x) * w, axis=0)
+        den = np.sum(np.where(np.isnan(x), 0.0, 1.0) * w, axis=0)
+        out.append(num / np.where(den != 0, den, np.nan))
+    return np.stack(out, axis=0)
+
+
+def annual_average(xobj, tcoord="time"):
+    """Days-in-month weighted annual means (util.py:49-119).
+
+    Accepts a labelled Dataset or DataArray; asserts 12 steps per year; the new
+    time axis holds the mid-points of the years.
+    """
+    from .cftime_lite import year_midpoint
+
+    time_values = list(xobj[tcoord].values)
+    calendar = time_values[0].calendar
+    years, weights = _annual_weights(time_values)
+    new_time = [year_midpoint(int(y), calendar) for y in sorted(set(years.tolist()))]
+    tattrs = xobj[tcoord].attrs
+    time_da = DataArray(np.array(new_time, dtype=object), (tcoord,), None, tattrs, tcoord)
+
+    def avg(da):
+        if tcoord not in da.dims:
+            return da
+        moved = da.transpose(tcoord, ...)
+        res = _annual_mean_array(moved.values.astype(np.float64), years, weights)
+        coords = {k: v for k, v in moved.coords.items() if tcoord not in v.dims}
+        coords[tcoord] = time_da
+        out = DataArray(res, moved.dims, coords, da.attrs, da.name)
+        out.encoding = dict(da.encoding)
+        return out
+
+    if isinstance(xobj, Dataset):
+        result = Dataset(attrs=xobj.attrs)
+        for name, c in xobj.coords.items():
+            if tcoord not in c.dims:
+                result._set(name, c, is_coord=True)
+        result._set(tcoord, time_da, is_coord=True)
+        for name, var in xobj.data_vars.items():
+            if var.values.dtype.kind not in "fiu":
+                continue  # non-numeric variables are skipped (util.py:79-84)
+            result[name] = avg(var)
+        return result
+    return avg(xobj)

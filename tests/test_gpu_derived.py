@@ -1,0 +1,109 @@
+"""GPU: momlevel_amd.derived -- the reference's tests/test_derived.py hot subset
+(:26-51, :74-103), then oracle parity."""
+
+import numpy as np
+import pytest
+
+from momlevel_amd import derived
+from momlevel_amd.labeled import DataArray
+from momlevel_amd.test_data import generate_test_data, generate_test_data_dz
+from oracle import momlevel_numpy as o
+from conftest import assert_bit_equal, assert_rel
+
+pytestmark = pytest.mark.gpu
+
+dset1 = generate_test_data()
+dset2 = generate_test_data_dz()
+
+
+def test_calc_dz_1(goldens):
+    dz = derived.calc_dz(dset2.z_l, dset2.z_i, dset2.deptho)
+    assert np.allclose(dz.sum(), goldens["calc_dz"]["default"])
+    assert dz.dims == ("z_l", "yh", "xh")
+    assert_bit_equal(dz.values, o.calc_dz(dset2.z_l.values, dset2.z_i.values, dset2.deptho.values))
+
+
+def test_calc_dz_2(goldens):
+    dz = derived.calc_dz(dset2.z_l, dset2.z_i, dset2.deptho, fraction=True)
+    assert np.allclose(dz.sum(), goldens["calc_dz"]["fraction"])
+    assert_bit_equal(dz.values, o.calc_dz(dset2.z_l.values, dset2.z_i.values,
+                                          dset2.deptho.values, fraction=True))
+
+
+def test_calc_dz_3():
+    deptho = dset2.deptho.copy()
+    deptho[4, 4] = -200.0
+    with pytest.raises(Exception):
+        derived.calc_dz(dset2.z_l, dset2.z_i, deptho)
+
+
+def test_calc_dz_4(goldens):
+    dz = derived.calc_dz(dset2.z_l, dset2.z_i, dset2.deptho, top=12.0, bottom=33.0)
+    assert np.allclose(dz.sum(), goldens["calc_dz"]["top12_bottom33"])
+    assert_bit_equal(dz.values, o.calc_dz(dset2.z_l.values, dset2.z_i.values,
+                                          dset2.deptho.values, top=12.0, bottom=33.0))
+
+
+def test_calc_rho(goldens):
+    rho = derived.calc_rho(dset1.thetao, dset1.so, dset1.z_l * 1.0e4, eos="Wright")
+    pytest.rho = rho
+    assert np.allclose(rho.sum(), goldens["derived"]["calc_rho_loose"])  # the reference's bar
+    assert rho.dims == ("time", "z_l", "yh", "xh")
+    assert rho.attrs["comment"] == "calculated with the Wright equation of state"
+    assert_bit_equal(rho.values, o.calc_rho(dset1.thetao.values, dset1.so.values,
+                                            dset1.z_l.values * 1.0e4))
+
+
+def test_calc_rho_held_field_broadcast_order():
+    """halosteric's call: thetao (z,y,x), so (t,z,y,x) -> dims in first-appearance order."""
+    rho = derived.calc_rho(dset1.thetao.isel(time=0), dset1.so, dset1.z_l * 1.0e4)
+    assert rho.dims == ("z_l", "yh", "xh", "time")
+    ref = o.calc_rho(dset1.thetao.values[0], dset1.so.values, dset1.z_l.values * 1.0e4)
+    assert_bit_equal(rho.transpose("time", ...).values, ref)
+
+
+def test_calc_alpha_beta(goldens):
+    a = derived.calc_alpha(dset1.thetao, dset1.so, dset1.z_l * 1.0e4, eos="Wright")
+    b = derived.calc_beta(dset1.thetao, dset1.so, dset1.z_l * 1.0e4, eos="Wright")
+    assert np.allclose(a.sum(), goldens["derived"]["calc_alpha"])
+    assert np.allclose(b.sum(), goldens["derived"]["calc_beta"])
+    p3 = (dset1.z_l.values * 1.0e4)[:, None, None]
+    assert_bit_equal(a.values, o.wright_alpha(dset1.thetao.values, dset1.so.values, p3))
+    assert_bit_equal(b.values, o.wright_beta(dset1.thetao.values, dset1.so.values, p3))
+
+
+def test_calc_masso(goldens):
+    rho = derived.calc_rho(dset1.thetao, dset1.so, dset1.z_l * 1.0e4, eos="Wright")
+    masso = derived.calc_masso(rho, dset1.volcello)
+    pytest.masso = masso
+    assert masso.dims == ("time",)
+    assert np.allclose(masso.sum(), goldens["derived"]["calc_masso"])
+    assert_rel(masso.values, o.calc_masso(rho.values, dset1.volcello.values), 1e-10)
+    m3 = derived.calc_masso(rho.isel(time=0), dset1.volcello.isel(time=0))
+    assert m3.dims == ()
+    assert_rel(m3.values, o.calc_masso(rho.values[0], dset1.volcello.values[0]), 1e-10)
+    mb = derived.calc_masso(rho, dset1.volcello.isel(time=0))  # 3-D volcello broadcast over time
+    assert_rel(mb.values, o.calc_masso(rho.values, dset1.volcello.values[0]), 1e-10)
+
+
+def test_calc_volo_1():
+    with pytest.raises(Exception):
+        _ = derived.calc_volo(dset1.volcello)
+
+
+def test_calc_volo_2(goldens):
+    volo = derived.calc_volo(dset1.volcello.isel(time=0))
+    pytest.volo = volo
+    assert np.allclose(volo, goldens["derived"]["calc_volo"])
+    v = dset1.volcello.isel(time=0).values.copy()
+    v[0, 0, :3] = np.nan
+    assert_rel(derived.calc_volo(DataArray(v, ("z_l", "yh", "xh"))).values, np.nansum(v), 1e-13)
+
+
+def test_rhoga(goldens):
+    rho = derived.calc_rho(dset1.thetao, dset1.so, dset1.z_l * 1.0e4, eos="Wright")
+    masso = derived.calc_masso(rho, dset1.volcello)
+    volo = derived.calc_volo(dset1.volcello.isel(time=0))
+    rhoga = derived.calc_rhoga(masso, volo)
+    assert np.allclose(rhoga.sum(), goldens["derived"]["rhoga_sum"])
+    assert rhoga.attrs["units"] == "kg m-3"

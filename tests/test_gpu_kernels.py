@@ -1,0 +1,224 @@
+"""GPU: the kernels through the C ABI (momlevel_amd.core -> ctypes -> libmomlevel_hip.so):
+edge cases, error behaviour, determinism, and parity at BASELINE.json's sizes.
+
+config 2 (360x576x75, nt=12): element-wise parity with the oracle.
+config 3 (1440x1080x75): size-independent properties at the full grid (a reduced number of
+time steps keeps the test inside the time budget; bench.py runs all 120).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from momlevel_amd import _lib, core, engine, parallel, synthetic
+from oracle import momlevel_numpy as o
+from conftest import assert_bit_equal, assert_rel
+
+pytestmark = pytest.mark.gpu
+
+SEED = synthetic.SEED
+
+
+def make_case(nt, nz, ny, nx, dtype=torch.float64):
+    g = synthetic.make_grid(ny, nx, nz)
+    vol0 = torch.from_numpy(g["volcello"]).cuda()
+    shape = (nt, nz, ny, nx)
+    T = core.synth_field(shape, dtype, seed=SEED, field_id=1, lo=-2.0, scale=34.0, mask3d=vol0)
+    S = core.synth_field(shape, dtype, seed=SEED, field_id=2, lo=30.0, scale=10.0, mask3d=vol0)
+    pres = o.pressure_from_depth(g["z_l"])
+    return g, vol0, T, S, pres
+
+
+def host_fields(g, shape, t0=0, dtype=np.float64):
+    kw = dict(seed=SEED, mask3d=g["volcello"], t0=t0, dtype=dtype)
+    return (synthetic.field_numpy(shape, field_id=1, lo=-2.0, scale=34.0, **kw),
+            synthetic.field_numpy(shape, field_id=2, lo=30.0, scale=10.0, **kw))
+
+
+# ---------------------------------------------------------------------------------------------
+def test_synth_generator_replays_in_numpy():
+    g, vol0, T, S, _ = make_case(3, 5, 12, 20)
+    Tn, Sn = host_fields(g, (3, 5, 12, 20))
+    assert_bit_equal(T.cpu().numpy(), Tn)
+    assert_bit_equal(S.cpu().numpy(), Sn)
+    T32 = core.synth_field((3, 5, 12, 20), torch.float32, seed=SEED, field_id=1, lo=-2.0,
+                           scale=34.0, mask3d=vol0)
+    assert_bit_equal(T32.cpu().numpy(), host_fields(g, (3, 5, 12, 20), dtype=np.float32)[0])
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (2, 3, 1, 7), (5, 2, 3, 3), (3, 4, 2, 1024),
+                                   (2, 2, 17, 130), (9, 3, 64, 64), (16, 1, 1, 4098)])
+def test_k1_ragged_shapes(shape):
+    """empty-ish, odd and tile-straddling planes; nt around the LDS flush period (8)."""
+    nt, nz, ny, nx = shape
+    r = np.random.default_rng(nx)
+    T = r.uniform(-2, 32, shape)
+    S = r.uniform(30, 40, shape)
+    vol = r.uniform(1e9, 1e12, shape[1:])
+    vol[r.uniform(size=vol.shape) < 0.2] = np.nan
+    pres = o.pressure_from_depth(np.linspace(1.0, 5000.0, nz))
+    got = core.steric_global_masso(torch.from_numpy(T).cuda(), torch.from_numpy(S).cuda(),
+                                   torch.from_numpy(vol).cuda(), pres)
+    ref = o.calc_masso(o.calc_rho(T, S, pres), vol)
+    assert_rel(got.cpu().numpy(), ref, 1e-12, f"masso {shape}")
+
+
+def test_all_nan_reductions_are_zero():
+    shape = (3, 2, 4, 6)
+    T = torch.full(shape, float("nan"), dtype=torch.float64, device="cuda")
+    vol = torch.full(shape[1:], float("nan"), dtype=torch.float64, device="cuda")
+    got = core.steric_global_masso(T, T, vol, np.array([1e5, 2e5]))
+    assert (got.cpu().numpy() == 0.0).all()
+    assert core.nansum(vol).item() == 0.0
+
+
+def test_fast_and_generic_paths_agree():
+    """a 16-byte-misaligned view must take the scalar kernels and give the same numbers."""
+    g, vol0, T, S, pres = make_case(5, 6, 16, 24)
+    n = T.numel()
+    buf = torch.empty(n + 1, dtype=torch.float64, device="cuda")
+    T_mis = buf[1:].view(T.shape)
+    T_mis.copy_(T)
+    assert T_mis.data_ptr() % 16 == 8
+    a = core.steric_global_masso(T, S, vol0, pres).cpu().numpy()
+    b = core.steric_global_masso(T_mis, S, vol0, pres).cpu().numpy()
+    assert_rel(b, a, 1e-13, "generic vs fast masso")
+    ra = core.eos_map(T, S, pres).cpu().numpy()
+    rb = core.eos_map(T_mis, S, pres).cpu().numpy()
+    assert_bit_equal(rb, ra, "generic vs fast rho")
+
+
+def test_strided_time_axis_needs_no_copy():
+    g, vol0, T, S, pres = make_case(8, 4, 8, 16)
+    a = core.steric_global_masso(T[::2], S[::2], vol0, pres).cpu().numpy()
+    b = core.steric_global_masso(T[::2].contiguous(), S[::2].contiguous(), vol0, pres).cpu().numpy()
+    assert_bit_equal(a, b)
+
+
+def test_run_to_run_bit_identical():
+    g, vol0, T, S, pres = make_case(9, 10, 48, 64)
+    runs = [core.steric_global_masso(T, S, vol0, pres).cpu().numpy() for _ in range(3)]
+    assert_bit_equal(runs[1], runs[0])
+    assert_bit_equal(runs[2], runs[0])
+
+
+def test_abi_error_codes():
+    g, vol0, T, S, pres = make_case(2, 3, 4, 8)
+    with pytest.raises(_lib.MomlevelHipError, match="argument error -3"):
+        lib = _lib.load()
+        rc = lib.mlx_eos_map(T.data_ptr(), S.data_ptr(), 0, vol0.data_ptr(), 1, 7, 0,
+                             2, 3, 32, 96, 96, T.data_ptr(), None)
+        _lib.check(rc, "mlx_eos_map")
+    lib = _lib.load()
+    ws = torch.empty(1, dtype=torch.float64, device="cuda")
+    rc = lib.mlx_steric_global(T.data_ptr(), S.data_ptr(), 0, vol0.data_ptr(), vol0.data_ptr(), 1,
+                               0, 2, 3, 32, 96, 96, ws.data_ptr(), ws.data_ptr(), 8, None)
+    assert rc == -4 and "workspace" in _lib.last_error()
+    with pytest.raises(TypeError):
+        core.steric_global_masso(T.cpu(), S, vol0, pres)
+    with pytest.raises(ValueError):
+        core.steric_global_masso(T, S, vol0[:, :2], pres)
+
+
+# ---------------------------------------------------------------------------------------------
+# config 2: OM4 1-degree-like grid 360x576x75, 12 steps -- element-wise parity with the oracle
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.timeout(900)
+def test_config2_full_parity():
+    nt, nz, ny, nx = 12, 75, 576, 360
+    g, vol0, T, S, pres = make_case(nt, nz, ny, nx)
+    masso = core.steric_global_masso(T, S, vol0, pres).cpu().numpy()
+    rho0 = core.eos_map(T[0], S[0], pres)
+    rho0m = core.fold_mask(rho0, vol0)
+    drho, eta = core.steric_local(T, S, rho0m, vol0[0], pres, -1.0 / 1035.0,
+                                  z_i=g["z_i"], deptho=g["deptho"])
+    ref_masso = np.empty(nt)
+    dz = o.calc_dz(g["z_l"], g["z_i"], g["deptho"])
+    wet3 = ~np.isnan(g["volcello"])
+    rho0_ref = None
+    for t in range(nt):  # slab by slab: keeps the oracle's temporaries at 124 MB each
+        Tn, Sn = host_fields(g, (1, nz, ny, nx), t0=t)
+        rho = o.calc_rho(Tn[0], Sn[0], pres)
+        if t == 0:
+            rho0_ref = rho
+            assert_bit_equal(rho0.cpu().numpy(), rho, "rho0")
+        ref_masso[t] = o.calc_masso(rho, g["volcello"])
+        d = np.where(wet3, rho - rho0_ref, np.nan)
+        assert_bit_equal(drho[t].cpu().numpy(), d, f"delta_rho t={t}")
+        e = np.where(wet3[0], (-1.0 / 1035.0) * np.nansum(dz * d, axis=0), np.nan)
+        assert_bit_equal(eta[t].cpu().numpy(), e, f"eta t={t}")
+    assert_rel(masso, ref_masso, 1e-10, "masso")
+    assert np.max(np.abs(masso - ref_masso) / ref_masso) < 1e-13  # what is actually achieved
+
+
+# ---------------------------------------------------------------------------------------------
+# config 3 grid (1440x1080x75) at full horizontal/vertical size: size-independent properties
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.timeout(900)
+def test_config3_grid_properties():
+    nt, nz, ny, nx = 4, 75, 1080, 1440
+    g, vol0, T, S, pres = make_case(nt, nz, ny, nx)
+    m = core.steric_global_masso(T, S, vol0, pres)
+    # determinism
+    assert torch.equal(m, core.steric_global_masso(T, S, vol0, pres))
+    # linearity in vol0: a power-of-two scale is exact in floating point
+    m2 = core.steric_global_masso(T, S, vol0 * 2.0, pres)
+    assert torch.equal(m2, m * 2.0)
+    # reference-state identity: masso0 == masso(t=0), held-field variants agree at t=0
+    _rho0, volo, masso0 = engine.reference_state(T[0], S[0], vol0, pres)
+    assert masso0.item() == m[0].item()
+    assert core.steric_global_masso(T, S[0], vol0, pres)[0].item() == masso0.item()
+    assert core.steric_global_masso(T[0], S, vol0, pres)[0].item() == masso0.item()
+    # horizontal tiling (the 2x4 multi-GPU decomposition) sums to the whole
+    tot = torch.zeros(nt, dtype=torch.float64, device="cuda")
+    vtot = 0.0
+    for rank in range(8):
+        y0, y1, x0, x1 = synthetic.tile_bounds(ny, nx, rank, 8)
+        Tt = T[:, :, y0:y1, x0:x1].contiguous()
+        St = S[:, :, y0:y1, x0:x1].contiguous()
+        vt = vol0[:, y0:y1, x0:x1].contiguous()
+        tot += core.steric_global_masso(Tt, St, vt, pres)
+        vtot += core.nansum(vt).item()
+        del Tt, St, vt
+    assert_rel(tot.cpu().numpy(), m.cpu().numpy(), 1e-12, "tiles vs whole")
+    assert_rel(vtot, volo.item(), 1e-12, "volo tiles vs whole")
+    # oracle spot check on one time slab of a 135x1440 band (all z): masso band + local columns
+    y0, y1 = 400, 535
+    Tb = T[2:3, :, y0:y1].contiguous()
+    Sb = S[2:3, :, y0:y1].contiguous()
+    vb = vol0[:, y0:y1].contiguous()
+    Tn, Sn, vn = Tb.cpu().numpy(), Sb.cpu().numpy(), vb.cpu().numpy()
+    rho = o.calc_rho(Tn, Sn, pres)
+    assert_rel(core.steric_global_masso(Tb, Sb, vb, pres).cpu().numpy(), o.calc_masso(rho, vn),
+               1e-12, "band masso")
+    rho0m = core.fold_mask(core.eos_map(T[0], S[0], pres), vol0)
+    drho, eta = core.steric_local(T[2:3], S[2:3], rho0m, vol0[0], pres, -1.0 / 1035.0,
+                                  z_i=g["z_i"], deptho=g["deptho"])
+    rho0n = o.calc_rho(T[0, :, y0:y1].cpu().numpy(), S[0, :, y0:y1].cpu().numpy(), pres)
+    d = np.where(~np.isnan(vn), rho[0] - rho0n, np.nan)
+    assert_bit_equal(drho[0, :, y0:y1].cpu().numpy(), d, "band delta_rho")
+    dz = o.calc_dz(g["z_l"], g["z_i"], g["deptho"][y0:y1])
+    e = np.where(~np.isnan(vn[0]), (-1.0 / 1035.0) * np.nansum(dz * d, axis=0), np.nan)
+    assert_bit_equal(eta[0, y0:y1].cpu().numpy(), e, "band eta")
+    # eta-only mode (delta_rho store skipped) gives the same eta
+    _, eta2 = core.steric_local(T[2:3], S[2:3], rho0m, vol0[0], pres, -1.0 / 1035.0,
+                                z_i=g["z_i"], deptho=g["deptho"], want_delta_rho=False)
+    assert torch.equal(torch.nan_to_num(eta2), torch.nan_to_num(eta))
+    # an explicit dz array instead of the on-the-fly calc_dz
+    dzd = core.calc_dz(torch.from_numpy(g["z_i"]).cuda(), torch.from_numpy(g["deptho"]).cuda())
+    _, eta3 = core.steric_local(T[2:3], S[2:3], rho0m, vol0[0], pres, -1.0 / 1035.0, dz=dzd,
+                                want_delta_rho=False)
+    assert torch.equal(torch.nan_to_num(eta3), torch.nan_to_num(eta))
+
+
+def test_single_process_tile_pipeline_matches_labelled_api():
+    """parallel.steric_global_tile with world_size 1 == the public steric(domain='global')."""
+    g, vol0, T, S, pres = make_case(5, 8, 16, 24)
+    out = parallel.steric_global_tile(T, S, vol0, g["areacello"], pres)
+    vol4 = np.broadcast_to(g["volcello"], T.shape).copy()
+    ref, refst = o.steric(T.cpu().numpy(), S.cpu().numpy(), vol4, g["areacello"], g["z_l"],
+                          domain="global")
+    assert out["eta"][0] == 0.0
+    assert_rel(out["masso"], ref["masso"], 1e-10)
+    assert_rel(out["reference_height"], ref["reference_height"], 1e-10)
+    assert np.allclose(out["expansion_coeff"], ref["expansion_coeff"], rtol=0, atol=1e-12)

@@ -1,0 +1,105 @@
+"""GPU: the EOS kernel (K0) behind momlevel_amd.eos.wright -- mirrors the reference's
+tests/test_wright.py, then tightens it to bit-exactness against the reference module's own
+outputs (tests/golden/wright_vectors.npz) and the oracle."""
+
+import numpy as np
+import pytest
+import torch
+
+from momlevel_amd.eos.wright import alpha, beta, density, drho_dsal, drho_dtemp
+from momlevel_amd.eos import linear
+from oracle import momlevel_numpy as o
+from conftest import assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+
+rng = np.random.default_rng(123)
+thetao = rng.normal(15.0, 5.0, (5, 5))
+so = rng.normal(35.0, 1.5, (5, 5))
+pressure = rng.normal(2000.0, 500.0, (5, 5))
+
+FUNCS = {"density": density, "drho_dtemp": drho_dtemp, "drho_dsal": drho_dsal,
+         "alpha": alpha, "beta": beta}
+
+
+# ---- the reference's own tests (tests/test_wright.py:11-137), np.allclose defaults ---------
+def test_wright_density_scalar():
+    assert np.allclose(density(18.0, 35.0, 200000.0), 1025.359957453976)
+
+
+def test_wright_density_3D(goldens):
+    assert np.allclose(density(thetao, so, pressure), np.array(goldens["wright_5x5"]["density"]))
+
+
+def test_wright_drho_dtemp(goldens):
+    assert np.allclose(drho_dtemp(18.0, 35.0, 200000.0), -0.24680005918175105)
+    assert np.allclose(drho_dtemp(thetao, so, pressure), np.array(goldens["wright_5x5"]["drho_dtemp"]))
+
+
+def test_wright_drho_dsal(goldens):
+    assert np.allclose(drho_dsal(18.0, 35.0, 200000.0), 0.7652676800174607)
+    assert np.allclose(drho_dsal(thetao, so, pressure), np.array(goldens["wright_5x5"]["drho_dsal"]))
+
+
+def test_wright_alpha_beta(goldens):
+    assert np.allclose(alpha(18.0, 35.0, 200000.0), 0.0002406960183958898)
+    assert np.allclose(beta(18.0, 35.0, 200000.0), 0.0007463405162784603)
+    assert np.allclose(beta(thetao, so, pressure), np.array(goldens["wright_5x5"]["beta"]))
+
+
+# ---- bit-exact against the reference module's outputs ------------------------------------
+def test_scalars_bit_exact(wright_vectors):
+    T, S, p = wright_vectors["scalar_args"]
+    got = np.array([f(T, S, p) for f in (density, drho_dtemp, drho_dsal, alpha, beta)])
+    assert_bit_equal(got, wright_vectors["scalar_out"], "scalars")
+    assert isinstance(density(T, S, p), np.float64)
+
+
+@pytest.mark.parametrize("tag", ["tw", "rnd", "blk"])
+@pytest.mark.parametrize("func", list(FUNCS))
+def test_vectors_bit_exact(wright_vectors, tag, func):
+    v = wright_vectors
+    got = FUNCS[func](v[f"{tag}_T"], v[f"{tag}_S"], v[f"{tag}_p"])
+    # 'rnd' holds NaN/inf/zero edge cases; 'blk' is the calc_rho shape (nt,nz,ny,nx) x (nz,1,1)
+    assert_bit_equal(got, v[f"{tag}_{func}"], f"{tag}/{func}")
+
+
+def test_float32_inputs_follow_numpy_mixed_precision(wright_vectors):
+    v = wright_vectors
+    got = density(v["f32_T"], v["f32_S"], v["blk_p"])
+    assert got.dtype == np.float64
+    assert_bit_equal(got, v["f32_density"], "float32 theta/S, float64 p")
+
+
+def test_float32_upcast_mode_is_plain_float64(wright_vectors):
+    from momlevel_amd import core
+
+    v = wright_vectors
+    T = torch.from_numpy(v["f32_T"]).cuda()
+    S = torch.from_numpy(v["f32_S"]).cuda()
+    got = core.eos_map(T, S, v["blk_p"].reshape(-1), f32_mode="upcast").cpu().numpy()
+    ref = o.wright_density(v["f32_T"].astype(np.float64), v["f32_S"].astype(np.float64), v["blk_p"])
+    assert_bit_equal(got, ref, "upcast")
+
+
+@pytest.mark.parametrize("shape", [(1,), (7,), (63,), (64,), (65,), (1023,), (3, 5, 7), (2, 3, 5, 8)])
+def test_ragged_shapes_and_broadcasting(shape):
+    r = np.random.default_rng(sum(shape))
+    T = r.uniform(-2, 32, shape)
+    S = r.uniform(30, 40, shape)
+    p = r.uniform(1e5, 6e7, shape)
+    assert_bit_equal(density(T, S, p), o.wright_density(T, S, p))
+    assert_bit_equal(density(T, 35.0, 2.0e5), o.wright_density(T, 35.0, 2.0e5))
+    assert_bit_equal(density(T, S[..., :1], p), o.wright_density(T, S[..., :1], p))
+
+
+def test_device_tensors_stay_on_device():
+    T = torch.from_numpy(thetao).cuda()
+    out = density(T, torch.from_numpy(so).cuda(), torch.from_numpy(pressure).cuda())
+    assert isinstance(out, torch.Tensor) and out.is_cuda
+    assert_bit_equal(out.cpu().numpy(), o.wright_density(thetao, so, pressure))
+
+
+def test_linear_eos():
+    got = linear.density(thetao, so)
+    assert_bit_equal(got, o.linear_density(thetao, so))

@@ -1,0 +1,211 @@
+"""CPU: host-side mirror of the reference interface (no kernels are launched)."""
+
+import numpy as np
+import pytest
+
+import momlevel_amd as m
+from momlevel_amd import synthetic, util
+from momlevel_amd.labeled import DataArray, Dataset
+from momlevel_amd.test_data import (
+    generate_test_data,
+    generate_test_data_dz,
+    generate_test_data_time,
+)
+from oracle import momlevel_numpy as o
+
+dset = generate_test_data()
+
+
+# ---- reference tests/test_util.py:47-121 ------------------------------------------------
+def test_default_coords_1():
+    assert util.default_coords() == ("time", "z_l", "z_i")
+
+
+def test_default_coords_2():
+    assert util.default_coords(coord_names={"z": "lev", "t": "TIME"}) == ("TIME", "lev", "z_i")
+
+
+def test_validate_areacello_1():
+    assert util.validate_areacello(dset.areacello)
+
+
+def test_validate_areacello_2():
+    assert not util.validate_areacello(dset.areacello * 1.3)
+
+
+def test_validate_dataset_1():
+    util.validate_dataset(dset)
+
+
+def test_validate_dataset_2():
+    with pytest.raises(ValueError):
+        util.validate_dataset(dset.copy().drop_vars(["thetao"]))
+
+
+def test_validate_dataset_3():
+    t = dset.copy()
+    t["areacello"] = t["areacello"] * 1.3
+    with pytest.raises(ValueError):
+        util.validate_dataset(t)
+
+
+def test_validate_dataset_4():
+    t = dset.copy()
+    t["areacello"] = t["areacello"] * 1.3
+    with pytest.warns(UserWarning):
+        util.validate_dataset(t, strict=False)
+
+
+def test_validate_dataset_5():
+    with pytest.raises(ValueError):
+        util.validate_dataset(dset.copy(), reference=True)
+
+
+def test_validate_dataset_8():
+    with pytest.raises(ValueError):
+        util.validate_dataset(dset.copy(), additional_vars=["foo", "bar"])
+
+
+def test_eos_func_from_str():
+    assert util.eos_func_from_str("Wright") is m.eos.wright.density
+    assert util.eos_func_from_str("wright", func_name="alpha") is m.eos.wright.alpha
+    assert util.eos_func_from_str("LINEAR") is m.eos.linear.density
+    with pytest.raises(ValueError):
+        util.eos_func_from_str("teos10")
+    with pytest.raises(AssertionError):
+        util.eos_func_from_str(10)
+
+
+# ---- generators reproduce the reference's datasets (via the oracle's restatement) -------
+@pytest.mark.parametrize("seed", [123, 999])
+def test_generate_test_data_matches_oracle(seed):
+    a, b = generate_test_data(seed=seed), o.generate_test_data(seed=seed)
+    for k in ("thetao", "so", "volcello", "areacello", "deptho", "z_i", "z_l"):
+        assert np.array_equal(a[k].values, b[k]), k
+    assert a["thetao"].dims == ("time", "z_l", "yh", "xh")
+    assert np.isclose(a["areacello"].values.sum(), 3.6111092e14)
+
+
+def test_generate_test_data_monthly_axis():
+    a = generate_test_data(start_year=1983, nyears=2, calendar="julian")
+    b = o.generate_test_data(start_year=1983, nyears=2, calendar="julian")
+    assert len(a["time"]) == 24
+    t = a["time"].values
+    assert [x.daysinmonth for x in t] == list(b["time_days_in_month"])
+    assert t[13].year == 1984 and t[13].month == 2 and t[13].daysinmonth == 29
+    assert np.array_equal(a["thetao"].values, b["thetao"])
+
+
+def test_generate_test_data_dz_matches_oracle():
+    a, b = generate_test_data_dz(), o.generate_test_data_dz()
+    assert np.array_equal(np.isnan(a["deptho"].values), np.isnan(b["deptho"]))
+    assert np.allclose(np.nan_to_num(a["deptho"].values), np.nan_to_num(b["deptho"]))
+
+
+# ---- annual_average: reference tests/test_util.py:125-148 ------------------------------
+def test_annual_average(goldens):
+    g = goldens["annual_average"]
+    for cal in ("noleap", "julian"):
+        d = generate_test_data_time(calendar=cal)
+        res = util.annual_average(d)
+        assert len(res["time"]) == 5
+        s = res.sum()
+        assert np.allclose(s["var_a"], g[f"{cal}_var_a"])
+        assert np.allclose(s["var_b"], g[f"{cal}_var_b"])
+        assert np.allclose(util.annual_average(d["var_a"]).sum(), g[f"{cal}_var_a"])
+        assert res["var_a"].attrs == {"first_attribute": "foo", "second_attribute": "bar"}
+
+
+def test_annual_average_requires_12_steps():
+    d = generate_test_data_time(nyears=1)
+    short = Dataset({"var_a": d["var_a"][0:11]}, {"time": d["time"][0:11]})
+    with pytest.raises(AssertionError):
+        util.annual_average(short)
+
+
+# ---- labelled containers ------------------------------------------------------------------
+def test_labelled_basics():
+    da = dset["thetao"]
+    assert da.dims == ("time", "z_l", "yh", "xh") and da.shape == (5, 5, 5, 5)
+    assert float(da[0, 1, 2, 3]) == da.values[0, 1, 2, 3]
+    sub = da.isel(time=0)
+    assert sub.dims == ("z_l", "yh", "xh") and "time" not in sub.coords
+    tr = da.transpose("xh", ...)
+    assert tr.dims == ("xh", "time", "z_l", "yh")
+    assert np.array_equal(tr.values, np.moveaxis(da.values, 3, 0))
+    pres = dset["z_l"] * 1.0e4 + 101325.0
+    assert pres.dims == ("z_l",) and np.allclose(pres.values, o.pressure_from_depth(dset["z_l"].values))
+    prod = dset["z_l"] * dset["areacello"]  # broadcast by NAME
+    assert prod.dims == ("z_l", "yh", "xh")
+    ren = dset.rename({"thetao": "temp", "z_l": "lev"})
+    assert ren["temp"].dims == ("time", "lev", "yh", "xh") and "thetao" not in ren
+    assert dset.rename(None) is dset
+    res = Dataset()
+    res["x"] = DataArray(np.arange(3.0), ("time",))
+    res["x"].encoding["dtype"] = "float32"
+    assert res["x"].encoding["dtype"] == "float32"
+    assert float(dset.sum()["thetao"]) == pytest.approx(np.sum(dset["thetao"].values))
+
+
+# ---- synthetic grids -------------------------------------------------------------------------
+def test_synthetic_grid_is_a_valid_momlevel_input():
+    g = synthetic.make_grid(48, 64, 15)
+    assert util.validate_areacello(DataArray(g["areacello"], ("yh", "xh")))
+    land = np.isnan(g["deptho"])
+    assert 0.1 < land.mean() < 0.5
+    assert np.isnan(g["volcello"][:, land]).all()
+    assert not np.isnan(g["volcello"][0, ~land]).any()  # every ocean column has a wet top cell
+    # volcello = areacello * calc_dz, NaN below the bottom
+    dz = o.calc_dz(g["z_l"], g["z_i"], g["deptho"])
+    wet = ~np.isnan(g["volcello"])
+    assert np.allclose(g["volcello"][wet], (g["areacello"][None] * dz)[wet])
+    assert (dz[~wet & ~land[None]] == 0).all()
+
+
+def test_synthetic_field_tiles_reproduce_global_field():
+    shape = (3, 4, 8, 12)
+    kw = dict(seed=synthetic.SEED, field_id=1, lo=-2.0, scale=34.0)
+    full = synthetic.field_numpy(shape, **kw)
+    assert full.min() >= -2.0 and full.max() < 32.0
+    for rank in range(4):
+        y0, y1, x0, x1 = synthetic.tile_bounds(8, 12, rank, 4)
+        tile = synthetic.field_numpy((3, 4, y1 - y0, x1 - x0), global_hw=(8, 12),
+                                     origin=(y0, x0), **kw)
+        assert np.array_equal(tile, full[:, :, y0:y1, x0:x1])
+    later = synthetic.field_numpy((1, 4, 8, 12), t0=2, **kw)
+    assert np.array_equal(later[0], full[2])
+
+
+def test_tile_bounds_cover_the_grid():
+    for world in (1, 2, 4, 8):
+        seen = np.zeros((1080, 1440), dtype=int)
+        for r in range(world):
+            y0, y1, x0, x1 = synthetic.tile_bounds(1080, 1440, r, world)
+            seen[y0:y1, x0:x1] += 1
+        assert (seen == 1).all()
+
+
+# ---- no CPU fallback ---------------------------------------------------------------------------
+def test_product_fails_loudly_without_a_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(m.MomlevelHipError):
+        m.steric(dset)
+    with pytest.raises(m.MomlevelHipError):
+        m.eos.wright.density(18.0, 35.0, 2.0e5)
+    with pytest.raises(m.MomlevelHipError):
+        m.derived.calc_volo(dset["volcello"].isel(time=0))
+
+
+def test_product_never_imports_the_oracle():
+    import os
+    import re
+
+    root = os.path.dirname(os.path.abspath(m.__file__))
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
