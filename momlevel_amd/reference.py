@@ -11,7 +11,7 @@ import numpy as np
 from . import engine
 from .adapters import accepts_xarray
 from .labeled import DataArray, Dataset
-from .util import default_coords
+from .util import default_coords, eos_func_from_str
 
 __all__ = ["setup_reference_state"]
 
@@ -62,6 +62,8 @@ def setup_reference_state(
     coords = default_coords(coord_names)
     tcoord = coords[0]
     zcoord = coords[1]
+
+    eos_func_from_str(eos)  # unknown EOS -> ValueError, as calc_rho raises it (util.py:247)
 
     pres = pressure_field(dset, zcoord, patm)
 

@@ -27,7 +27,7 @@ from .reference import (
     pressure_operand,
     setup_reference_state,
 )
-from .util import annual_average, default_coords, validate_dataset
+from .util import annual_average, default_coords, eos_func_from_str, validate_dataset
 
 __all__ = ["halosteric", "steric", "thermosteric"]
 
@@ -116,10 +116,8 @@ def steric(
     T, S = field(thetao), field(so)
     vol0 = _canonical(reference["volcello"], cdims3)
     p = pressure_operand(pres, tcoord, cdims3)
-    eos = equation_of_state.lower()
-    from .util import eos_func_from_str
-
     eos_func_from_str(equation_of_state)  # unknown EOS -> ValueError (util.py:247)
+    eos = equation_of_state.lower()
 
     def coords_for(dims):
         return {d: dset[d] for d in dims if d in dset.variables}
