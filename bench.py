@@ -182,7 +182,7 @@ def main():
         layout = {1: "1x1", 2: "1x2", 4: "2x2", 8: "2x4"}.get(world, f"1x{world}")
         line = {
             "metric": "Mcells/s for fused Wright-EOS+steric at 1440x1080x75; % HBM roofline",
-            "value": round(cells_job / elapsed / 1e6, 1),
+            "value": round(cells_job * a.steps / elapsed / 1e6, 1),
             "unit": "Mcells/s",
             "n_gpus": world,
             "steps": a.steps,
