@@ -58,6 +58,20 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(cells_per_launch):
+    """HBM bytes per K1 launch from the committed rocprofv3 --pmc passes (profiles/), if they
+    were taken on this workload; bench.py itself cannot read hardware counters."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_summary.json")
+    try:
+        with open(path) as f:
+            s = json.load(f)
+        if s.get("cells_per_launch") == cells_per_launch:
+            return round(s["hbm_traffic_bytes_per_launch"] / 1e9, 2), "profiles/r01_summary.json"
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
+
+
 def fit_nt(nt, nz, ny, nx, device):
     """Largest nt <= requested whose theta+S fit in free HBM with ~14 GB of headroom."""
     free, _ = torch.cuda.mem_get_info(device)
@@ -170,6 +184,8 @@ def main():
     k1_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in launch_ms]))
     achieved = BYTES_PER_CELL * cells_rank / (k1_ms * 1e-3) / 1e9
 
+    traffic, traffic_src = measured_traffic(cells_rank)
+
     extras = {}
     if not a.no_extras and rank == 0:
         extras = local_variant_timings(T, S, vol0, pres, g, dev)
@@ -213,10 +229,14 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "GB per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc)",
+                "traffic_source": traffic_src,
                 "launch_ms": round(k1_ms, 4),
                 "algorithmic_bytes_per_cell": BYTES_PER_CELL,
+                "algorithmic_gb_per_launch": round(BYTES_PER_CELL * cells_rank / 1e9, 2),
                 "cells_per_launch": cells_rank,
+                "time_loop_steps_per_block": 32,
             },
             "cpu_baseline": cpu,
             "parity": parity,

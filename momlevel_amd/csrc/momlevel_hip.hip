@@ -45,38 +45,56 @@ struct Pack {
   TIn v[VEC];
 };
 
-template <typename TIn, int VEC>
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+// STREAM: once-read data (theta/S, delta_rho) moves with the `nt` cache policy
+// (global_load_dwordx4 ... nt).  Measured on MI355X (scripts/tune_k1.hip): the K1 loop
+// streams at ~6.0 TB/s with default-policy loads and ~6.6 TB/s with nt loads.
+template <bool STREAM>
+__device__ __forceinline__ f4_t load16(const void* p) {
+  if constexpr (STREAM) return __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(p));
+  else return *reinterpret_cast<const f4_t*>(p);
+}
+
+template <typename TIn, int VEC, bool STREAM = false>
 __device__ __forceinline__ Pack<TIn, VEC> load_pack(const TIn* __restrict__ p) {
   Pack<TIn, VEC> r;
   if constexpr (VEC == 1) {
-    r.v[0] = p[0];
+    if constexpr (STREAM) r.v[0] = __builtin_nontemporal_load(p);
+    else r.v[0] = p[0];
   } else if constexpr (sizeof(TIn) * VEC == 16) {
-    // one global_load_dwordx4
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    f4 raw = *reinterpret_cast<const f4*>(p);
+    f4_t raw = load16<STREAM>(p);  // one global_load_dwordx4
     __builtin_memcpy(&r, &raw, 16);
   } else {
     static_assert(sizeof(TIn) * VEC == 32, "pack must be 16 or 32 bytes");
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    f4 raw0 = reinterpret_cast<const f4*>(p)[0];
-    f4 raw1 = reinterpret_cast<const f4*>(p)[1];
+    f4_t raw0 = load16<STREAM>(p);
+    f4_t raw1 = load16<STREAM>(reinterpret_cast<const char*>(p) + 16);
     __builtin_memcpy(&r.v[0], &raw0, 16);
     __builtin_memcpy(&r.v[VEC / 2], &raw1, 16);
   }
   return r;
 }
 
-template <int VEC>
+// XCD-aware tile index: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share
+// one), so give the blocks that share an XCD one contiguous eighth of the row of tiles.
+// Bijective for any n (cdna_hip_programming.md T1); speed only, never correctness.
+__device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t n) {
+  const int64_t q = n / 8, r = n % 8, xcd = b % 8, k = b / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+template <int VEC, bool STREAM = false>
 __device__ __forceinline__ void store_pack(double* __restrict__ p, const Pack<double, VEC>& r) {
   if constexpr (VEC == 1) {
-    p[0] = r.v[0];
+    if constexpr (STREAM) __builtin_nontemporal_store(r.v[0], p);
+    else p[0] = r.v[0];
   } else {
-    typedef float f4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int h = 0; h < VEC / 2; ++h) {
-      f4 raw;
+      f4_t raw;
       __builtin_memcpy(&raw, &r.v[2 * h], 16);
-      reinterpret_cast<f4*>(p)[h] = raw;
+      if constexpr (STREAM) __builtin_nontemporal_store(raw, reinterpret_cast<f4_t*>(p) + h);
+      else reinterpret_cast<f4_t*>(p)[h] = raw;
     }
   }
 }
@@ -91,9 +109,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 // ------------------------------------------------------------------------------------
 // K1: fused EOS + rho*vol0 + per-time-step sum over the block's cells.
 //
-// grid = (ceil(plane / (kBlock*VEC*U)), nz); each thread owns U packs of VEC adjacent
-// cells of ONE z level, keeps their vol0 (and p, if FULL3D) in registers and loops over
-// time.  Per time step it parks its partial in LDS row t%kNTC; every kNTC steps the block
+// grid = (ceil(plane / (kBlock*VEC*U)), nz, ceil(nt/t_chunk)); each thread owns U packs of
+// VEC adjacent cells of ONE z level, keeps their vol0 (and p, if FULL3D) in registers and
+// loops over the time steps of its chunk.  Per time step it parks its partial in LDS row t%kNTC; every kNTC steps the block
 // reduces the parked rows (fixed order) and writes partials[t][block].  A second kernel
 // (k_reduce_rows) sums partials[t][:] in a fixed order -> masso[t].
 //
@@ -104,14 +122,20 @@ __device__ __forceinline__ double wave_sum(double v) {
 template <typename TIn, int VEC, int U, int HOLD, int MODE, bool GENERIC>
 __global__ __launch_bounds__(kBlock) void k_steric_global(
     const TIn* __restrict__ T, const TIn* __restrict__ S, const double* __restrict__ vol0,
-    const double* __restrict__ p, int p_mode, int eos, int nt, int64_t plane,
+    const double* __restrict__ p, int p_mode, int eos, int nt, int t_chunk, int64_t plane,
     int64_t t_stride_T, int64_t t_stride_S, double* __restrict__ partials, int64_t nblk_total) {
   __shared__ double red[kNTC][kBlock];
 
   const int tid = threadIdx.x;
   const int z = blockIdx.y;
-  const int64_t blk = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-  const int64_t tile0 = (int64_t)blockIdx.x * (kBlock * VEC * U);
+  // blockIdx.z = time chunk (slowest grid dimension): the resident blocks all work inside one
+  // window of t_chunk time steps instead of drifting over the whole record (+3.7 % measured
+  // at nt=120, scripts/tune_k1.hip), at the price of re-reading vol0 once per chunk.
+  const int tb = blockIdx.z * t_chunk;
+  const int te = (tb + t_chunk < nt) ? (tb + t_chunk) : nt;
+  const int64_t bx = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t blk = (int64_t)blockIdx.y * gridDim.x + bx;  // partial slot = tile position
+  const int64_t tile0 = bx * (kBlock * VEC * U);
   const int64_t zoff = (int64_t)z * plane;
 
   int64_t off[U];  // offset of pack u inside a (z,y,x) slab; clamped when past the plane
@@ -139,21 +163,23 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
   Pack<TIn, VEC> curT[U], curS[U], nxtT[U], nxtS[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    nxtT[u] = load_pack<TIn, VEC>(T + off[u]);
-    nxtS[u] = load_pack<TIn, VEC>(S + off[u]);
+    nxtT[u] = load_pack<TIn, VEC, true>(T + (int64_t)tb * t_stride_T + off[u]);
+    nxtS[u] = load_pack<TIn, VEC, true>(S + (int64_t)tb * t_stride_S + off[u]);
   }
 
-  for (int t = 0; t < nt; ++t) {
+  for (int t = tb; t < te; ++t) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (HOLD != 1 || t == 0) curT[u] = nxtT[u];
-      if (HOLD != 2 || t == 0) curS[u] = nxtS[u];
+      if (HOLD != 1 || t == tb) curT[u] = nxtT[u];
+      if (HOLD != 2 || t == tb) curS[u] = nxtS[u];
     }
-    if (t + 1 < nt) {  // issue the next step's loads before this step's arithmetic
+    if (t + 1 < te) {  // issue the next step's loads before this step's arithmetic
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (HOLD != 1) nxtT[u] = load_pack<TIn, VEC>(T + (int64_t)(t + 1) * t_stride_T + off[u]);
-        if (HOLD != 2) nxtS[u] = load_pack<TIn, VEC>(S + (int64_t)(t + 1) * t_stride_S + off[u]);
+        if (HOLD != 1)
+          nxtT[u] = load_pack<TIn, VEC, true>(T + (int64_t)(t + 1) * t_stride_T + off[u]);
+        if (HOLD != 2)
+          nxtS[u] = load_pack<TIn, VEC, true>(S + (int64_t)(t + 1) * t_stride_S + off[u]);
       }
     }
     double c = 0.0;
@@ -172,9 +198,9 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
         c += is_nan(term) ? 0.0 : term;       // skipna
       }
     }
-    const int row = t % kNTC;
+    const int row = (t - tb) % kNTC;
     red[row][tid] = c;
-    if (row == kNTC - 1 || t == nt - 1) {
+    if (row == kNTC - 1 || t == te - 1) {
       __syncthreads();
       const int wave = tid >> 6, lane = tid & 63;
       for (int r = wave; r <= row; r += kBlock / 64) {
@@ -270,8 +296,8 @@ __global__ __launch_bounds__(kBlock) void k_eos_map(const TIn* __restrict__ T,
     const int64_t i = tile0 + ((int64_t)u * kBlock + threadIdx.x) * VEC;
     valid[u] = (i + VEC <= plane);
     off[u] = zoff + (valid[u] ? i : 0);
-    a[u] = load_pack<TIn, VEC>(T + t * t_stride_T + off[u]);
-    b[u] = load_pack<TIn, VEC>(S + t * t_stride_S + off[u]);
+    a[u] = load_pack<TIn, VEC, true>(T + t * t_stride_T + off[u]);
+    b[u] = load_pack<TIn, VEC, true>(S + t * t_stride_S + off[u]);
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -287,7 +313,7 @@ __global__ __launch_bounds__(kBlock) void k_eos_map(const TIn* __restrict__ T,
         r.v[k] = eos_eval<MODE, TIn>(kWright, FUNC, a[u].v[k], b[u].v[k], pz);
       }
     }
-    if (valid[u]) store_pack<VEC>(out + t * nz * plane + off[u], r);
+    if (valid[u]) store_pack<VEC, true>(out + t * nz * plane + off[u], r);
   }
 }
 
@@ -319,7 +345,10 @@ __device__ __forceinline__ double dz_default(double depth, double ztop, double z
 // grid = (ceil(plane/(kBlock*VEC)), ceil(nt/NTI)).  A thread owns VEC adjacent columns
 // and NTI consecutive time steps: z is the outer (sequential, as numpy's axis reduce)
 // loop, the NTI time steps are unrolled inside it with their column sums in registers,
-// so rho0m / dz are read once per z and reused NTI times.
+// so rho0m / dz are read once per z and reused NTI times.  NTI*VEC = 32 column sums per
+// thread (64 VGPRs) + 2*NTI loads in flight: ~240 VGPRs, 2 waves/SIMD -- measured faster
+// (scripts/tune_k2.hip) than NTI=8 at 4 waves/SIMD: half the rho0m re-reads and twice the
+// bytes in flight per wave.  theta/S loads and the delta_rho stores use the nt policy.
 // ------------------------------------------------------------------------------------
 template <typename TIn, int VEC, int NTI, int HOLD, int MODE, bool GENERIC>
 __global__ __launch_bounds__(kBlock) void k_steric_local(
@@ -329,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
     const double* __restrict__ p, int p_mode, int eos, double neg_inv_rhozero, int nt, int nz,
     int64_t plane, int64_t t_stride_T, int64_t t_stride_S, double* __restrict__ drho_out,
     double* __restrict__ eta_out) {
-  const int64_t col = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
+  const int64_t col = (xcd_remap(blockIdx.x, gridDim.x) * kBlock + threadIdx.x) * VEC;
   if (col + VEC > plane) return;  // whole packs only; no barrier below
   const int t0 = blockIdx.y * NTI;
   const int64_t n3 = (int64_t)nz * plane;
@@ -367,10 +396,11 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
     Pack<TIn, VEC> a[NTI], b[NTI];
 #pragma unroll
     for (int j = 0; j < NTI; ++j) {
-      // clamp so the tail chunk's surplus loads stay in bounds (their results are unused)
-      const int64_t t = (t0 + j < nt) ? (t0 + j) : (nt - 1);
-      if (HOLD != 1) a[j] = load_pack<TIn, VEC>(T + t * t_stride_T + off);
-      if (HOLD != 2) b[j] = load_pack<TIn, VEC>(S + t * t_stride_S + off);
+      if (t0 + j < nt) {  // block-uniform: the ragged last chunk issues no surplus loads
+        const int64_t t = t0 + j;
+        if (HOLD != 1) a[j] = load_pack<TIn, VEC, true>(T + t * t_stride_T + off);
+        if (HOLD != 2) b[j] = load_pack<TIn, VEC, true>(S + t * t_stride_S + off);
+      }
     }
 #pragma unroll
     for (int j = 0; j < NTI; ++j) {
@@ -393,7 +423,8 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
           const double term = dzv.v[k] * dr;       // steric.py:163
           acc[j][k] += is_nan(term) ? 0.0 : term;  // skipna, z ascending like numpy
         }
-        if (drho_out != nullptr) store_pack<VEC>(drho_out + (int64_t)(t0 + j) * n3 + off, d);
+        if (drho_out != nullptr)
+          store_pack<VEC, true>(drho_out + (int64_t)(t0 + j) * n3 + off, d);
       }
     }
   }
@@ -494,7 +525,10 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 constexpr int kU64 = 4, kVec64 = 2;  // 8 cells/thread, 2048 cells/block (fast f64)
 constexpr int kU32 = 2, kVec32 = 4;  // 8 cells/thread (fast f32)
 constexpr int kUGen = 4;             // generic: 4 scalar cells/thread, 1024 cells/block
-constexpr int kNTI = 8;              // time steps per K2 thread
+constexpr int kTChunk = 32;          // K1 time steps per block (grid.z = ceil(nt / kTChunk))
+constexpr int kNTI64 = 16;           // time steps per K2 thread, f64 (2 columns/thread)
+constexpr int kNTI32 = 8;            // f32 (4 columns/thread)
+constexpr int kNTIGen = 8;           // generic scalar path
 
 struct GlobalPlan {
   bool fast;
@@ -630,13 +664,14 @@ int mlx_steric_global(const void* T, const void* S, int dtype, const double* vol
   hipStream_t st = (hipStream_t)stream;
   const GlobalPlan pl = plan_global(T, S, vol0, dtype, p_mode, eos, nz, plane, sT, sS);
   double* partials = (double*)workspace;
-  dim3 grid((unsigned)pl.grid_x, (unsigned)nz);
+  if (ceil_div(nt, kTChunk) > 65535) return fail(MLX_E_SHAPE, "nt too large for one call: chunk it");
+  dim3 grid((unsigned)pl.grid_x, (unsigned)nz, (unsigned)ceil_div(nt, kTChunk));
   const double* pp = p ? p : vol0;
   const int hold = (sT == 0) ? 1 : ((sS == 0) ? 2 : 0);
 #define MLX_LAUNCH_K1(TIN, VEC, U, HOLD, MODE, GEN)                                              \
   hipLaunchKernelGGL((k_steric_global<TIN, VEC, U, HOLD, MODE, GEN>), grid, dim3(kBlock), 0, st, \
-                     (const TIN*)T, (const TIN*)S, vol0, pp, p_mode, eos, (int)nt, plane, sT, sS, \
-                     partials, pl.nblk_total)
+                     (const TIN*)T, (const TIN*)S, vol0, pp, p_mode, eos, (int)nt, kTChunk, plane, \
+                     sT, sS, partials, pl.nblk_total)
   if (pl.fast) {
     if (dtype == MLX_DTYPE_F64) {
       if (hold == 0) MLX_LAUNCH_K1(double, kVec64, kU64, 0, kF64, false);
@@ -685,7 +720,7 @@ int mlx_steric_local(const void* T, const void* S, int dtype, const double* rho0
     return fail(MLX_E_NULL, "rho0m, vol0_surface and eta_out must not be NULL");
   if (!dz && (!z_i || !deptho))
     return fail(MLX_E_NULL, "either dz or both z_i and deptho must be given");
-  if (ceil_div(nt, kNTI) > 65535) return fail(MLX_E_SHAPE, "nt too large for one call: chunk it");
+  if (ceil_div(nt, kNTIGen) > 65535) return fail(MLX_E_SHAPE, "nt too large for one call: chunk it");
   hipStream_t st = (hipStream_t)stream;
   const bool f64 = (dtype == MLX_DTYPE_F64);
   const int vec = f64 ? kVec64 : kVec32;
@@ -698,30 +733,31 @@ int mlx_steric_local(const void* T, const void* S, int dtype, const double* rho0
   const double* pp = p ? p : rho0m;
   const int hold = (sT == 0) ? 1 : ((sS == 0) ? 2 : 0);
   const int v = fast ? vec : 1;
-  dim3 grid((unsigned)ceil_div(plane, (int64_t)kBlock * v), (unsigned)ceil_div(nt, kNTI));
-#define MLX_LAUNCH_K2(TIN, VEC, HOLD, MODE, GEN)                                                 \
-  hipLaunchKernelGGL((k_steric_local<TIN, VEC, kNTI, HOLD, MODE, GEN>), grid, dim3(kBlock), 0,   \
+  const int nti = fast ? (f64 ? kNTI64 : kNTI32) : kNTIGen;
+  dim3 grid((unsigned)ceil_div(plane, (int64_t)kBlock * v), (unsigned)ceil_div(nt, nti));
+#define MLX_LAUNCH_K2(TIN, VEC, NTI, HOLD, MODE, GEN)                                            \
+  hipLaunchKernelGGL((k_steric_local<TIN, VEC, NTI, HOLD, MODE, GEN>), grid, dim3(kBlock), 0,    \
                      st, (const TIN*)T, (const TIN*)S, rho0m, vol0_surface, dz, z_i, deptho, pp, \
                      p_mode, eos, neg_inv_rhozero, (int)nt, (int)nz, plane, sT, sS,              \
                      delta_rho_out, eta_out)
   if (fast) {
     if (f64) {
-      if (hold == 0) MLX_LAUNCH_K2(double, kVec64, 0, kF64, false);
-      else if (hold == 1) MLX_LAUNCH_K2(double, kVec64, 1, kF64, false);
-      else MLX_LAUNCH_K2(double, kVec64, 2, kF64, false);
+      if (hold == 0) MLX_LAUNCH_K2(double, kVec64, kNTI64, 0, kF64, false);
+      else if (hold == 1) MLX_LAUNCH_K2(double, kVec64, kNTI64, 1, kF64, false);
+      else MLX_LAUNCH_K2(double, kVec64, kNTI64, 2, kF64, false);
     } else if (dtype == MLX_DTYPE_F32) {
-      if (hold == 0) MLX_LAUNCH_K2(float, kVec32, 0, kF32Faithful, false);
-      else if (hold == 1) MLX_LAUNCH_K2(float, kVec32, 1, kF32Faithful, false);
-      else MLX_LAUNCH_K2(float, kVec32, 2, kF32Faithful, false);
+      if (hold == 0) MLX_LAUNCH_K2(float, kVec32, kNTI32, 0, kF32Faithful, false);
+      else if (hold == 1) MLX_LAUNCH_K2(float, kVec32, kNTI32, 1, kF32Faithful, false);
+      else MLX_LAUNCH_K2(float, kVec32, kNTI32, 2, kF32Faithful, false);
     } else {
-      if (hold == 0) MLX_LAUNCH_K2(float, kVec32, 0, kF32Upcast, false);
-      else if (hold == 1) MLX_LAUNCH_K2(float, kVec32, 1, kF32Upcast, false);
-      else MLX_LAUNCH_K2(float, kVec32, 2, kF32Upcast, false);
+      if (hold == 0) MLX_LAUNCH_K2(float, kVec32, kNTI32, 0, kF32Upcast, false);
+      else if (hold == 1) MLX_LAUNCH_K2(float, kVec32, kNTI32, 1, kF32Upcast, false);
+      else MLX_LAUNCH_K2(float, kVec32, kNTI32, 2, kF32Upcast, false);
     }
   } else {
-    if (f64) MLX_LAUNCH_K2(double, 1, 0, kF64, true);
-    else if (dtype == MLX_DTYPE_F32) MLX_LAUNCH_K2(float, 1, 0, kF32Faithful, true);
-    else MLX_LAUNCH_K2(float, 1, 0, kF32Upcast, true);
+    if (f64) MLX_LAUNCH_K2(double, 1, kNTIGen, 0, kF64, true);
+    else if (dtype == MLX_DTYPE_F32) MLX_LAUNCH_K2(float, 1, kNTIGen, 0, kF32Faithful, true);
+    else MLX_LAUNCH_K2(float, 1, kNTIGen, 0, kF32Upcast, true);
   }
 #undef MLX_LAUNCH_K2
   return hip_status(hipGetLastError(), "k_steric_local launch");

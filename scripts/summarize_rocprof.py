@@ -68,6 +68,21 @@ def main(src, prefix, kernel="k_steric_global"):
         summary["hbm_read_bytes_per_launch_corrected"] = fetch
         summary["hbm_write_bytes_per_launch"] = write
         summary["hbm_traffic_bytes_per_launch"] = fetch + write
+    # the bench line printed by the profiled command (same workload as the committed BENCH line)
+    for log in ("bench_trace.log", "bench_pmc_fetch.log"):
+        path = os.path.join(src, log)
+        if os.path.exists(path):
+            for line in open(path):
+                if line.startswith("{") and '"roofline"' in line:
+                    b = json.loads(line)
+                    summary.setdefault("bench_lines", {})[log] = {
+                        "value": b["value"], "ms_per_step": b["ms_per_step"],
+                        "roofline": b["roofline"], "workload": b["config"]["workload"],
+                    }
+                    summary["cells_per_launch"] = b["roofline"]["cells_per_launch"]
+    if "hbm_traffic_bytes_per_launch" in summary and "cells_per_launch" in summary:
+        summary["hbm_traffic_bytes_per_cell"] = (
+            summary["hbm_traffic_bytes_per_launch"] / summary["cells_per_launch"])
     json.dump(summary, open(prefix + "_summary.json", "w"), indent=1)
     print(json.dumps(summary, indent=1))
 
