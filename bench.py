@@ -120,9 +120,17 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         a.gpus = world
     core.require_device()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
+
+    dev_index = local_rank % torch.cuda.device_count()  # == local_rank on a full node
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    host_staged = world > 1 and dist.get_backend() == "gloo"  # rehearsal on fewer GPUs than ranks
+
+    def allreduce_scalar(value, op, dtype):
+        t = torch.tensor([value], dtype=dtype, device="cpu" if host_staged else dev)
+        dist.all_reduce(t, op=op)
+        return t.item()
 
     nz, ny, nx = (tuple(int(v) for v in a.grid.split(",")) if a.grid else GRID)
     tile = synthetic.tile_bounds(ny, nx, rank, world)
@@ -131,9 +139,7 @@ def main():
     nt_req = a.nt * world
     nt = fit_nt(nt_req, nz, th, tw, dev)
     if world > 1:  # every rank must run the same number of steps
-        t = torch.tensor([nt], device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        nt = int(t.item())
+        nt = int(allreduce_scalar(nt, dist.ReduceOp.MIN, torch.int64))
 
     vol0 = torch.from_numpy(g["volcello"]).to(dev)
     area = torch.from_numpy(g["areacello"]).to(dev)
@@ -175,9 +181,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(allreduce_scalar(elapsed, dist.ReduceOp.MAX, torch.float64))
 
     cells_rank = nt * nz * th * tw
     cells_job = cells_rank * world

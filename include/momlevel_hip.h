@@ -56,6 +56,7 @@ extern "C" {
 #define MLX_FUNC_DRHO_DSAL  2 /* eos/wright.py:88-119  */
 #define MLX_FUNC_ALPHA      3 /* eos/wright.py:122-142 */
 #define MLX_FUNC_BETA       4 /* eos/wright.py:145-165 */
+#define MLX_FUNC_IBH        5 /* dynamic.py:34-36, via mlx_inverse_barometer only */
 
 /* how the pressure argument is laid out */
 #define MLX_P_SCALAR  0 /* p[0] for every cell (calc_pdens, scalar calls)            */
@@ -86,6 +87,17 @@ int mlx_eos_map(const void *T, const void *S, int dtype,
                 int64_t nt, int64_t nz, int64_t plane,
                 int64_t t_stride_T, int64_t t_stride_S,
                 double *out, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * dynamic.inverse_barometer (src/momlevel/dynamic.py:34-36): out = p * (-1.0 / (rho(T,S,p) * gravity))
+ * on the same grid conventions as mlx_eos_map (the reference calls it on (time,yh,xh) surface
+ * fields: pass nz = 1).  p is both the EOS pressure and the numerator.
+ * ------------------------------------------------------------------------------- */
+int mlx_inverse_barometer(const void *T, const void *S, int dtype,
+                          const double *p, int p_mode, int eos, double gravity,
+                          int64_t nt, int64_t nz, int64_t plane,
+                          int64_t t_stride_T, int64_t t_stride_S,
+                          double *out, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * K1  fused EOS + rho*vol0 + sum over (z,y,x) per time step: masso_out[t].

@@ -13,11 +13,13 @@ entry points raise ``MomlevelHipError``.
 __version__ = "0.1.0"
 
 from . import derived
+from . import dynamic
 from . import eos
 from . import reference
 from . import test_data
 from . import util
 from ._lib import MomlevelHipError
+from .dynamic import inverse_barometer
 from .labeled import DataArray, Dataset
 from .steric import halosteric, steric, thermosteric
 
@@ -26,6 +28,8 @@ __all__ = [
     "Dataset",
     "MomlevelHipError",
     "derived",
+    "dynamic",
+    "inverse_barometer",
     "eos",
     "halosteric",
     "reference",

@@ -42,6 +42,10 @@ SIGNATURES = {
         _int,
         [_vp, _vp, _int, _vp, _int, _int, _int, _i64, _i64, _i64, _i64, _i64, _vp, _vp],
     ),
+    "mlx_inverse_barometer": (
+        _int,
+        [_vp, _vp, _int, _vp, _int, _int, _dbl, _i64, _i64, _i64, _i64, _i64, _vp, _vp],
+    ),
     "mlx_steric_global_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "mlx_steric_global": (
         _int,

@@ -131,6 +131,20 @@ def eos_map(T, S, p, eos="wright", func="density", f32_mode="faithful"):
     return out[0] if squeeze else out
 
 
+def inverse_barometer(T, S, p, gravity=9.8, eos="wright", f32_mode="faithful"):
+    """pso * (-1 / (rho(T,S,pso) * gravity)) on a (nt,nz,ny,nx)/(nz,ny,nx) grid -> float64."""
+    require_device()
+    T, S, nt, nz, ny, nx, sT, sS, dt, squeeze = _pair(T, S, f32_mode)
+    pt, p_mode = _pressure(p, nt, nz, ny, nx, T.device, allow4d=True)
+    out = torch.empty((nt, nz, ny, nx), dtype=torch.float64, device=T.device)
+    rc = _lib.load().mlx_inverse_barometer(
+        _ptr(T), _ptr(S), dt, _ptr(pt), p_mode, EOS_IDS[eos.lower()], float(gravity),
+        nt, nz, ny * nx, sT, sS, _ptr(out), _stream(),
+    )
+    _lib.check(rc, "mlx_inverse_barometer")
+    return out[0] if squeeze else out
+
+
 def steric_global_masso(T, S, vol0, p, eos="wright", f32_mode="faithful", events=None):
     """K1: masso[t] = sum_{z,y,x} rho(T,S,p) * vol0  (skipna) -> (nt,) float64.
 

@@ -31,6 +31,7 @@ constexpr int kDrhoDtemp = 1;
 constexpr int kDrhoDsal = 2;
 constexpr int kAlpha = 3;
 constexpr int kBeta = 4;
+constexpr int kIbh = 5;  // inverse barometer height (dynamic.py:34-36); aux = gravity
 
 // src/momlevel/eos/wright.py:6-20
 template <typename R>
@@ -120,7 +121,13 @@ __device__ __forceinline__ double linear_density(TIn Tin, TIn Sin) {
 
 // runtime-dispatched EOS function (generic kernels; eos/func are wave-uniform)
 template <int MODE, typename TIn>
-__device__ __forceinline__ double eos_eval(int eos, int func, TIn T, TIn S, double p) {
+__device__ __forceinline__ double eos_eval(int eos, int func, TIn T, TIn S, double p,
+                                           double aux = 0.0) {
+  if (func == kIbh) {  // pso * (-1.0 / (rho_conv * gravity))
+    const double rho = (eos == kLinear) ? linear_density<MODE, TIn>(T, S)
+                                        : wright_density<MODE, TIn>(T, S, p);
+    return p * (-1.0 / (rho * aux));
+  }
   if (eos == kLinear) {
     return linear_density<MODE, TIn>(T, S);
   }

@@ -280,7 +280,8 @@ __global__ __launch_bounds__(kBlock) void k_eos_map(const TIn* __restrict__ T,
                                                     const double* __restrict__ p, int p_mode,
                                                     int eos, int func, int64_t nz, int64_t plane,
                                                     int64_t t_stride_T, int64_t t_stride_S,
-                                                    int64_t t_base, double* __restrict__ out) {
+                                                    int64_t t_base, double aux,
+                                                    double* __restrict__ out) {
   const int z = blockIdx.y;
   const int64_t t = t_base + blockIdx.z;
   const int64_t tile0 = (int64_t)blockIdx.x * (kBlock * VEC * U);
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void k_eos_map(const TIn* __restrict__ T,
         double pp = pz;
         if (p_mode == MLX_P_FULL3D) pp = p[off[u] + k];
         if (p_mode == MLX_P_FULL4D) pp = p[t * nz * plane + off[u] + k];
-        r.v[k] = eos_eval<MODE, TIn>(eos, func, a[u].v[k], b[u].v[k], pp);
+        r.v[k] = eos_eval<MODE, TIn>(eos, func, a[u].v[k], b[u].v[k], pp, aux);
       } else {
         r.v[k] = eos_eval<MODE, TIn>(kWright, FUNC, a[u].v[k], b[u].v[k], pz);
       }
@@ -588,21 +589,23 @@ int mlx_last_error(char* buf, size_t n) {
 }
 
 // ---------------------------------------------------------------------------- K0
-int mlx_eos_map(const void* T, const void* S, int dtype, const double* p, int p_mode, int eos,
-                int func, int64_t nt, int64_t nz, int64_t plane, int64_t sT, int64_t sS,
-                double* out, void* stream) {
+static int eos_map_impl(const void* T, const void* S, int dtype, const double* p, int p_mode,
+                        int eos, int func, double aux, int64_t nt, int64_t nz, int64_t plane,
+                        int64_t sT, int64_t sS, double* out, void* stream) {
   using namespace mlx;
   if (int rc = check_common(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS, true)) return rc;
   if (!out) return fail(MLX_E_NULL, "out must not be NULL");
-  if (func < MLX_FUNC_DENSITY || func > MLX_FUNC_BETA) return fail(MLX_E_ENUM, "unknown func");
-  if (eos == MLX_EOS_LINEAR && func != MLX_FUNC_DENSITY)
+  if (func < MLX_FUNC_DENSITY || func > MLX_FUNC_IBH) return fail(MLX_E_ENUM, "unknown func");
+  if (eos == MLX_EOS_LINEAR && func != MLX_FUNC_DENSITY && func != MLX_FUNC_IBH)
     return fail(MLX_E_ENUM, "the linear EOS kernel provides density only");
+  if (func == MLX_FUNC_IBH && !p) return fail(MLX_E_NULL, "p must not be NULL");
   hipStream_t st = (hipStream_t)stream;
   const bool f64 = (dtype == MLX_DTYPE_F64);
   const int vec = f64 ? kVec64 : kVec32;
   const bool fast = (eos == MLX_EOS_WRIGHT) && (p_mode == MLX_P_ZPROF) && (plane % vec == 0) &&
                     (sT % vec == 0) && (sS % vec == 0) && aligned(T, 16) && aligned(S, 16) &&
-                    aligned(out, 16) && (f64 || func == MLX_FUNC_DENSITY);
+                    aligned(out, 16) && (f64 || func == MLX_FUNC_DENSITY) &&
+                    func != MLX_FUNC_IBH;
   const double* pp = p ? p : out;  // never dereferenced for the linear EOS
   for (int64_t tb = 0; tb < nt; tb += 32768) {
     const int64_t ntc = (nt - tb < 32768) ? (nt - tb) : 32768;
@@ -612,7 +615,7 @@ int mlx_eos_map(const void* T, const void* S, int dtype, const double* p, int p_
 #define MLX_LAUNCH_K0(TIN, VEC, MODE, FUNC)                                                     \
   hipLaunchKernelGGL((k_eos_map<TIN, VEC, U, MODE, FUNC, false>), grid, dim3(kBlock), 0, st,     \
                      (const TIN*)T, (const TIN*)S, pp, p_mode, eos, func, nz, plane, sT, sS, tb, \
-                     out)
+                     aux, out)
       if (f64) {
         switch (func) {
           case MLX_FUNC_DENSITY: MLX_LAUNCH_K0(double, 2, kF64, kDensity); break;
@@ -633,7 +636,7 @@ int mlx_eos_map(const void* T, const void* S, int dtype, const double* p, int p_
 #define MLX_LAUNCH_K0G(TIN, MODE)                                                               \
   hipLaunchKernelGGL((k_eos_map<TIN, 1, U, MODE, 0, true>), grid, dim3(kBlock), 0, st,           \
                      (const TIN*)T, (const TIN*)S, pp, p_mode, eos, func, nz, plane, sT, sS, tb, \
-                     out)
+                     aux, out)
       if (f64) MLX_LAUNCH_K0G(double, kF64);
       else if (dtype == MLX_DTYPE_F32) MLX_LAUNCH_K0G(float, kF32Faithful);
       else MLX_LAUNCH_K0G(float, kF32Upcast);
@@ -641,6 +644,20 @@ int mlx_eos_map(const void* T, const void* S, int dtype, const double* p, int p_
     }
   }
   return hip_status(hipGetLastError(), "mlx_eos_map launch");
+}
+
+int mlx_eos_map(const void* T, const void* S, int dtype, const double* p, int p_mode, int eos,
+                int func, int64_t nt, int64_t nz, int64_t plane, int64_t sT, int64_t sS,
+                double* out, void* stream) {
+  if (func == MLX_FUNC_IBH) return fail(MLX_E_ENUM, "use mlx_inverse_barometer for MLX_FUNC_IBH");
+  return eos_map_impl(T, S, dtype, p, p_mode, eos, func, 0.0, nt, nz, plane, sT, sS, out, stream);
+}
+
+int mlx_inverse_barometer(const void* T, const void* S, int dtype, const double* p, int p_mode,
+                          int eos, double gravity, int64_t nt, int64_t nz, int64_t plane,
+                          int64_t sT, int64_t sS, double* out, void* stream) {
+  return eos_map_impl(T, S, dtype, p, p_mode, eos, MLX_FUNC_IBH, gravity, nt, nz, plane, sT, sS,
+                      out, stream);
 }
 
 // ---------------------------------------------------------------------------- K1

@@ -20,6 +20,7 @@ __all__ = [
     "calc_beta",
     "calc_dz",
     "calc_masso",
+    "calc_pdens",
     "calc_rho",
     "calc_rhoga",
     "calc_volo",
@@ -47,9 +48,10 @@ def _expand_to(da, dims, sizes):
     return data.reshape(shape)
 
 
-def _apply_eos(func_name, thetao, so, pres, eos):
+def _apply_eos(func_name, thetao, so, pres, eos, eos_func=None):
     """xr.apply_ufunc(eos_func, thetao, so, pres) restated: broadcast by dim name."""
-    eos_func = util.eos_func_from_str(eos, func_name=func_name)
+    if eos_func is None:
+        eos_func = util.eos_func_from_str(eos, func_name=func_name)
     args = [a if isinstance(a, DataArray) else DataArray(np.asarray(a, dtype=np.float64), ())
             for a in (thetao, so, pres)]
     dims = _broadcast_dims(*args)
@@ -75,6 +77,20 @@ def calc_rho(thetao, so, pres, eos="Wright"):
         "units": "kg m-3",
     }
     return rho
+
+
+@accepts_xarray
+def calc_pdens(thetao, so, level=0.0, patm=101325, eos="Wright"):
+    """Potential density referenced to depth ``level`` (p = level*1e4 + patm) (derived.py:447-486)."""
+    assert 0.0 <= level <= 7500.0, "specified level must be between 0 and 7500 m"
+    rhopot = _apply_eos("density", thetao, so, (level * 1.0e4) + patm, eos)
+    rhopot.attrs = {
+        "standard_name": "sea_water_potential_density",
+        "long_name": f"Sea water potential density referenced to {level} m",
+        "comment": f"calculated with the {eos} equation of state",
+        "units": "kg m-3",
+    }
+    return rhopot
 
 
 @accepts_xarray

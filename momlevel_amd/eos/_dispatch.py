@@ -21,7 +21,7 @@ def _as_tensor(x, device):
     return torch.from_numpy(np.ascontiguousarray(a)).to(device)
 
 
-def evaluate(eos, func, T, S, p):
+def evaluate(eos, func, T, S, p, gravity=None):
     """f(T, S, p) with numpy broadcasting; returns the kind of array it was given."""
     core.require_device()
     on_device = any(isinstance(x, torch.Tensor) and x.is_cuda for x in (T, S, p))
@@ -39,6 +39,11 @@ def evaluate(eos, func, T, S, p):
     Tb = Tt.expand(shape).contiguous()
     Sb = St.expand(shape).contiguous()
 
+    def kernel(T4, S4, pp):
+        if func == "inverse_barometer":  # dynamic.py:34-36, fused into the EOS kernel
+            return core.inverse_barometer(T4, S4, pp, gravity=gravity, eos=eos)
+        return core.eos_map(T4, S4, pp, eos=eos, func=func)
+
     out = None
     if pt is not None and len(shape) >= 3 and pt.numel() > 1:
         nz = shape[-3]
@@ -47,7 +52,7 @@ def evaluate(eos, func, T, S, p):
             lead = int(np.prod(shape[:-3])) if len(shape) > 3 else 1
             T4 = Tb.reshape((lead,) + tuple(shape[-3:]))
             S4 = Sb.reshape((lead,) + tuple(shape[-3:]))
-            out = core.eos_map(T4, S4, pt.reshape(nz), eos=eos, func=func).reshape(shape)
+            out = kernel(T4, S4, pt.reshape(nz)).reshape(shape)
     if out is None:
         n = int(np.prod(shape)) if len(shape) else 1
         T3, S3 = Tb.reshape(1, 1, n), Sb.reshape(1, 1, n)
@@ -55,7 +60,7 @@ def evaluate(eos, func, T, S, p):
             pp = pt
         else:
             pp = pt.expand(shape).contiguous().reshape(1, 1, n)
-        out = core.eos_map(T3, S3, pp, eos=eos, func=func).reshape(shape)
+        out = kernel(T3, S3, pp).reshape(shape)
 
     if on_device:
         return out

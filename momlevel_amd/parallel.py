@@ -39,7 +39,10 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # MOMLEVEL_AMD_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer
+            # GPUs than ranks (device tensors are staged through the host for the exchange)
+            backend = os.environ.get("MOMLEVEL_AMD_DIST_BACKEND") or (
+                "nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -64,7 +67,12 @@ def exchange_global(masso, volo, masso0, area_sum, group=None):
     """
     vec = pack_partials(masso, volo, masso0, area_sum)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
+        if vec.is_cuda and dist.get_backend(group) == "gloo":  # rehearsal path, see init_from_env
+            host = vec.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            vec = host.to(vec.device)
+        else:
+            dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
     nt = vec.numel() - 3
     return vec[:nt], vec[nt], vec[nt + 1], vec[nt + 2]
 

@@ -146,6 +146,18 @@ def calc_rho(thetao, so, pres, eos="Wright"):
     return func(thetao, so, pres)
 
 
+def calc_pdens(thetao, so, level=0.0, patm=101325, eos="Wright"):
+    """src/momlevel/derived.py:447-486."""
+    assert 0.0 <= level <= 7500.0, "specified level must be between 0 and 7500 m"
+    return calc_rho(thetao, so, (level * 1.0e4) + patm, eos=eos)
+
+
+def inverse_barometer(tos, sos, pso, gravity=9.8, equation_of_state="Wright"):
+    """src/momlevel/dynamic.py:8-41."""
+    rho_conv = calc_rho(tos, sos, pso, eos=equation_of_state)
+    return pso * (-1.0 / (rho_conv * gravity))
+
+
 def calc_volo(volcello):
     """src/momlevel/derived.py:769-795 -- asserts 3-D, skipna sum."""
     assert volcello.ndim == 3, "Expecting only 3 dimensions for volcello"

@@ -1,0 +1,114 @@
+"""BASELINE.json configs[4]: float32 tolerance study at the 0.25-degree grid (one MI355X).
+
+    python scripts/f32_study.py [--nt 120] > profiles/r01_f32_study.json
+
+Real MOM6 output is float32 on disk.  The reference then computes in numpy's mixed precision
+(al0, p0, lam rounded in float32, the rest in float64 -- SURVEY.md 3.4 #7).  This script
+ (1) times halosteric + thermosteric + steric (global) and local steric on float32 theta/S
+     resident in HBM (half the bytes of fp64), for both float32 interpretations the library
+     offers (MLX_DTYPE_F32 = the reference's mixed precision, MLX_DTYPE_F32_UPCAST);
+ (2) reports, on a sample of time slabs, the error of each interpretation against the
+     float64 evaluation of the same (float32-representable) inputs, and checks the
+     "faithful" mode against the oracle (numpy on float32 arrays) bit for bit.
+Ocean heat content (named in that config) has no reference implementation:
+parity unpinned, not built.
+"""
+
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from momlevel_amd import core, synthetic  # noqa: E402
+from oracle import momlevel_numpy as o  # noqa: E402  (checker)
+
+
+def timed(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nt", type=int, default=120)
+    ap.add_argument("--grid", default="75,1080,1440")
+    a = ap.parse_args()
+    nz, ny, nx = (int(v) for v in a.grid.split(","))
+    nt = a.nt
+    g = synthetic.make_grid(ny, nx, nz)
+    vol0 = torch.from_numpy(g["volcello"]).cuda()
+    pres_h = np.asarray(g["z_l"]) * 1.0e4 + 101325.0
+    pres = torch.from_numpy(pres_h).cuda()
+    shape = (nt, nz, ny, nx)
+    kw = dict(seed=synthetic.SEED, mask3d=vol0)
+    T = core.synth_field(shape, torch.float32, field_id=1, lo=-2.0, scale=34.0, **kw)
+    S = core.synth_field(shape, torch.float32, field_id=2, lo=30.0, scale=10.0, **kw)
+    cells = nt * nz * ny * nx
+    out = {"grid_xyz": [nx, ny, nz], "nt": nt, "dtype_in": "float32", "timings": {}, "errors": {}}
+
+    for mode in ("faithful", "upcast"):
+        for name, Tv, Sv, bpc in (("steric", T, S, 8), ("thermosteric", T, S[0], 4),
+                                  ("halosteric", T[0], S, 4)):
+            ms = timed(lambda: core.steric_global_masso(Tv, Sv, vol0, pres, f32_mode=mode))
+            out["timings"][f"global_{name}_{mode}"] = {
+                "ms": round(ms, 3), "Mcells/s": round(cells / ms / 1e3, 1),
+                "GB/s_algorithmic": round(bpc * cells / ms / 1e6, 1), "bytes_per_cell": bpc}
+    rho0m = core.fold_mask(core.eos_map(T[0], S[0], pres), vol0)
+    zi, dep = torch.from_numpy(g["z_i"]).cuda(), torch.from_numpy(g["deptho"]).cuda()
+    eta = torch.empty((nt, ny, nx), dtype=torch.float64, device="cuda")
+    ms = timed(lambda: core.steric_local(T, S, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=zi,
+                                         deptho=dep, want_delta_rho=False, eta_out=eta))
+    out["timings"]["local_eta_only_faithful"] = {
+        "ms": round(ms, 3), "Mcells/s": round(cells / ms / 1e3, 1),
+        "GB/s_algorithmic": round(8 * cells / ms / 1e6, 1), "bytes_per_cell": 8}
+
+    # ---- tolerance: slabs t = 0, nt//2, nt-1 ------------------------------------------------
+    worst = {"faithful_vs_f64": 0.0, "upcast_vs_f64": 0.0, "pure_f32_vs_f64": 0.0}
+    bit_exact = True
+    for t in sorted({0, nt // 2, nt - 1}):
+        T32, S32 = T[t].cpu().numpy(), S[t].cpu().numpy()
+        ref64 = o.wright_density(T32.astype(np.float64), S32.astype(np.float64),
+                                 pres_h[:, None, None])
+        faithful = core.eos_map(T[t], S[t], pres, f32_mode="faithful").cpu().numpy()
+        upcast = core.eos_map(T[t], S[t], pres, f32_mode="upcast").cpu().numpy()
+        pure32 = o.wright_density(T32, S32, pres_h.astype(np.float32)[:, None, None])
+        oracle_mixed = o.wright_density(T32, S32, pres_h[:, None, None])
+        m = ~np.isnan(ref64)
+        bit_exact &= bool(np.array_equal(faithful[m], oracle_mixed[m])
+                          and np.array_equal(np.isnan(faithful), np.isnan(oracle_mixed)))
+        rel = lambda x: float(np.max(np.abs(x[m].astype(np.float64) - ref64[m]) / ref64[m]))
+        worst["faithful_vs_f64"] = max(worst["faithful_vs_f64"], rel(faithful))
+        worst["upcast_vs_f64"] = max(worst["upcast_vs_f64"], rel(upcast))
+        worst["pure_f32_vs_f64"] = max(worst["pure_f32_vs_f64"], rel(pure32))
+    out["errors"] = {
+        "max_rel_density_error_vs_float64_evaluation": worst,
+        "faithful_mode_bit_identical_to_numpy_mixed_precision": bit_exact,
+        "note": ("faithful = what momlevel computes on float32 input; upcast = float64 arithmetic "
+                 "on the float32 values (exact by construction); pure_f32 = everything in float32 "
+                 "(not offered: loses ~1e-7)"),
+    }
+    # global steric sensitivity: expansion coefficient difference between the two modes
+    mf = core.steric_global_masso(T, S, vol0, pres, f32_mode="faithful").cpu().numpy()
+    mu = core.steric_global_masso(T, S, vol0, pres, f32_mode="upcast").cpu().numpy()
+    out["errors"]["global_expansion_coeff_abs_diff_faithful_vs_upcast"] = float(
+        np.max(np.abs(np.log(mf[0] / mf) - np.log(mu[0] / mu))))
+    out["errors"]["masso_rel_diff_faithful_vs_upcast"] = float(np.max(np.abs(mf - mu) / mu))
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

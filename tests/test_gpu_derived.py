@@ -107,3 +107,30 @@ def test_rhoga(goldens):
     rhoga = derived.calc_rhoga(masso, volo)
     assert np.allclose(rhoga.sum(), goldens["derived"]["rhoga_sum"])
     assert rhoga.attrs["units"] == "kg m-3"
+
+
+def test_calc_pdens(goldens):
+    g = goldens["next_consumers"]
+    r0 = derived.calc_pdens(dset1.thetao, dset1.so, eos="Wright")
+    r2 = derived.calc_pdens(dset1.thetao, dset1.so, level=2000.0, eos="Wright")
+    assert np.allclose(r0.sum(), g["calc_pdens_level0_loose"])      # the reference's own bar
+    assert np.allclose(r2.sum(), g["calc_pdens_level2000_loose"])
+    assert_bit_equal(r0.values, o.calc_pdens(dset1.thetao.values, dset1.so.values))
+    assert_bit_equal(r2.values, o.calc_pdens(dset1.thetao.values, dset1.so.values, level=2000.0))
+    assert r2.attrs["long_name"] == "Sea water potential density referenced to 2000.0 m"
+    with pytest.raises(AssertionError):
+        derived.calc_pdens(dset1.thetao, dset1.so, level=8000.0)
+
+
+def test_inverse_barometer(goldens):
+    from momlevel_amd import inverse_barometer
+
+    d = generate_test_data().isel(z_l=0)
+    result = inverse_barometer(d.thetao, d.so, 101325.0)
+    assert np.allclose(result.sum(), goldens["next_consumers"]["inverse_barometer"])
+    assert result.dims == ("time", "yh", "xh") and result.name == "ibh"
+    assert_bit_equal(result.values, o.inverse_barometer(d.thetao.values, d.so.values, 101325.0))
+    pso = DataArray(101325.0 + np.random.default_rng(5).normal(0, 800.0, (5, 5)), ("yh", "xh"))
+    r2 = inverse_barometer(d.thetao, d.so, pso, gravity=9.81)
+    assert_bit_equal(r2.values, o.inverse_barometer(d.thetao.values, d.so.values, pso.values[None],
+                                                    gravity=9.81))
