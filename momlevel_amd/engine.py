@@ -4,10 +4,12 @@ This is the layer between the labelled front end (steric.py / reference.py /
 derived.py, which mirror the reference's signatures) and the kernels (core.py).
 It owns the time-chunk streaming of host-resident inputs: the reference hands
 ``steric()`` numpy-backed xarray objects of any size, so (time, z, y, x) fields
-are moved to HBM a few time steps at a time -- pinned staging buffers, a
-dedicated copy stream, and the kernels of chunk k overlapping the H2D of chunk
-k+1 -- while the time-invariant reference state stays resident on the device.
+are moved to HBM a few time steps at a time (sized from free HBM), the kernels of
+chunk k overlapping the upload of chunk k+1, while the time-invariant reference
+state stays resident on the device.
 """
+
+import warnings
 
 import numpy as np
 import torch
@@ -34,10 +36,7 @@ def to_device(x, device, dtype=None):
     if isinstance(x, torch.Tensor):
         t = x.to(device)
     else:
-        a = np.ascontiguousarray(x)
-        if a.dtype.byteorder not in ("=", "|"):
-            a = a.astype(a.dtype.newbyteorder("="))
-        t = torch.from_numpy(a).to(device)
+        t = _host_tensor(x).to(device)
     if dtype is not None and t.dtype != dtype:
         t = t.to(dtype)
     return t
@@ -59,13 +58,30 @@ def chunk_steps(nt, bytes_per_step, device, budget_bytes=None):
     return int(max(1, min(nt, budget_bytes // max(1, 2 * bytes_per_step))))
 
 
+def _host_tensor(a, dtype=None):
+    """numpy array (or view) -> CPU torch tensor sharing its memory when it can."""
+    a = np.asarray(a)
+    if dtype is not None and a.dtype != dtype:
+        a = a.astype(dtype)
+    if a.dtype.byteorder not in ("=", "|"):
+        a = a.astype(a.dtype.newbyteorder("="))
+    if not a.flags["C_CONTIGUOUS"]:
+        a = np.ascontiguousarray(a)
+    with warnings.catch_warnings():  # read-only views (e.g. broadcast volcello) are only read
+        warnings.simplefilter("ignore", UserWarning)
+        return torch.from_numpy(a)
+
+
 class TimeChunks:
     """Iterate a (nt, nz, ny, nx) field pair in device-resident time chunks.
 
-    Device-resident fields are sliced (no copy).  Host fields go through pinned
-    staging buffers on a side stream; chunk k+1 is uploaded while the caller's
-    kernels for chunk k run on the current stream.  A (nz,ny,nx) operand (a held
-    field) is uploaded once and yielded unchanged with every chunk.
+    Device-resident fields are sliced (no copy).  Host (numpy) fields are copied chunk by chunk
+    straight from the caller's memory into a fresh device tensor: on the MI355X hosts a
+    pageable hipMemcpy already runs at the PCIe Gen5 rate (56 GB/s measured, the same as from
+    pinned memory), so a staging copy would only halve the rate.  The copy call blocks the
+    host while the PREVIOUS chunk's kernels run asynchronously, so upload and compute overlap;
+    compute is ~400x faster than the link anyway.  A (nz,ny,nx) operand (a held field) is
+    uploaded once and yielded unchanged with every chunk.
     """
 
     def __init__(self, T, S, device, steps=None, extra_bytes_per_step=0):
@@ -74,9 +90,7 @@ class TimeChunks:
         self.nt = max(f.shape[0] for f in self.fields if f.ndim == 4) if any(
             f.ndim == 4 for f in self.fields
         ) else 1
-        self.resident = [
-            (f.ndim == 3) or _is_device(f) for f in self.fields
-        ]
+        self.resident = [(f.ndim == 3) or _is_device(f) for f in self.fields]
         per_step = extra_bytes_per_step
         for f, res in zip(self.fields, self.resident):
             if f.ndim == 4 and not res:
@@ -85,61 +99,32 @@ class TimeChunks:
         if steps is None:
             steps = chunk_steps(self.nt, per_step, device) if per_step else self.nt
         self.steps = max(1, min(int(steps), self.nt))
-        self.copy_stream = torch.cuda.Stream(device=device) if not all(self.resident) else None
         self._held = [
             to_device(f, device, _stream_dtype(f)) if f.ndim == 3 else None for f in self.fields
         ]
 
     def _upload(self, f, t0, t1):
-        """Enqueue H2D of f[t0:t1] on the copy stream; returns (device tensor, pinned keepalive)."""
         dt = _stream_dtype(f)
         src = f[t0:t1]
         if isinstance(src, torch.Tensor):
-            host = src.to(dt).contiguous()
-        else:
-            host = torch.from_numpy(np.ascontiguousarray(src, dtype=np.float32 if dt == torch.float32 else np.float64))
-        pinned = torch.empty(host.shape, dtype=dt, pin_memory=True)
-        pinned.copy_(host)
-        with torch.cuda.stream(self.copy_stream):
-            dev = pinned.to(self.device, non_blocking=True)
-        return dev, pinned
+            return src.to(device=self.device, dtype=dt)
+        host = _host_tensor(src, np.float32 if dt == torch.float32 else np.float64)
+        dev = torch.empty(host.shape, dtype=dt, device=self.device)
+        dev.copy_(host)
+        return dev
 
     def __iter__(self):
-        bounds = [(t0, min(t0 + self.steps, self.nt)) for t0 in range(0, self.nt, self.steps)]
-        pending = None
-
-        def stage(t0, t1):
-            out, keep = [], []
+        for t0 in range(0, self.nt, self.steps):
+            t1 = min(t0 + self.steps, self.nt)
+            cur = []
             for f, res, held in zip(self.fields, self.resident, self._held):
                 if f.ndim == 3:
-                    out.append(held)
+                    cur.append(held)
                 elif res:
-                    out.append(f[t0:t1])
+                    cur.append(f[t0:t1])
                 else:
-                    dev, pin = self._upload(f, t0, t1)
-                    out.append(dev)
-                    keep.append(pin)
-            ev = None
-            if self.copy_stream is not None:
-                ev = torch.cuda.Event()
-                ev.record(self.copy_stream)
-            return out, keep, ev
-
-        if bounds:
-            pending = stage(*bounds[0])
-        for i, (t0, t1) in enumerate(bounds):
-            cur, keep, ev = pending
-            if ev is not None:
-                torch.cuda.current_stream(self.device).wait_event(ev)
-            if i + 1 < len(bounds):
-                pending = stage(*bounds[i + 1])  # overlaps with the caller's kernels below
+                    cur.append(self._upload(f, t0, t1))
             yield t0, t1, cur[0], cur[1]
-            if self.copy_stream is not None:
-                # the chunk's memory may be reused by the allocator only after its kernels ran
-                for t in cur:
-                    if t is not None and t.ndim == 4:
-                        t.record_stream(torch.cuda.current_stream(self.device))
-            del keep
 
 
 # ---------------------------------------------------------------------------------------
@@ -237,9 +222,10 @@ def local_steric(T, S, rho0, vol0, pres, rhozero, z_i=None, deptho=None, dz=None
             d, e = core.steric_local(Tc, Sc, rho0m, surface, pres, neg_inv, dz=dz, z_i=z_i,
                                      deptho=deptho, eos=eos, f32_mode=f32_mode,
                                      want_delta_rho=want_delta_rho)
-            eta[t0:t1] = e.cpu().numpy()
+            # straight into the caller-visible arrays (one D2H pass, no intermediate copy)
+            torch.from_numpy(eta[t0:t1]).copy_(e)
             if want_delta_rho:
-                drho[t0:t1] = d.cpu().numpy()
+                torch.from_numpy(drho[t0:t1]).copy_(d)
         else:
             core.steric_local(Tc, Sc, rho0m, surface, pres, neg_inv, dz=dz, z_i=z_i,
                               deptho=deptho, eos=eos, f32_mode=f32_mode,

@@ -60,8 +60,8 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t n) {
 
 // PF: 0 = loads of a z level issued at the top of its iteration; 1 = next z level's loads issued
 // before this level's arithmetic (register double buffer)
-template <int NTI, int NTL, int NTS, int PF, int MAP, int DRHO>
-__global__ __launch_bounds__(256) void k2(const double* __restrict__ T, const double* __restrict__ S,
+template <int NTI, int NTL, int NTS, int PF, int MAP, int DRHO, int BLK = 256>
+__global__ __launch_bounds__(BLK) void k2(const double* __restrict__ T, const double* __restrict__ S,
                                           const double* __restrict__ rho0m,
                                           const double* __restrict__ surf,
                                           const double* __restrict__ z_i,
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k2(const double* __restrict__ T, const do
                                           int64_t plane, int64_t ts, double* __restrict__ drho,
                                           double* __restrict__ eta) {
   const int64_t bx = MAP ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
-  const int64_t col = (bx * 256 + threadIdx.x) * 2;
+  const int64_t col = (bx * BLK + threadIdx.x) * 2;
   if (col + 2 > plane) return;
   const int t0 = blockIdx.y * NTI;
   const int64_t n3 = (int64_t)nz * plane;
@@ -155,10 +155,10 @@ struct Variant {
   void (*launch)(const Args&);
   int bytes_per_cell;
 };
-template <int NTI, int NTL, int NTS, int PF, int MAP, int DRHO>
+template <int NTI, int NTL, int NTS, int PF, int MAP, int DRHO, int BLK = 256>
 void launch(const Args& a) {
-  dim3 grid((unsigned)((a.plane + 511) / 512), (unsigned)((a.nt + NTI - 1) / NTI));
-  hipLaunchKernelGGL((k2<NTI, NTL, NTS, PF, MAP, DRHO>), grid, dim3(256), 0, 0, a.T, a.S, a.rho0m,
+  dim3 grid((unsigned)((a.plane + 2 * BLK - 1) / (2 * BLK)), (unsigned)((a.nt + NTI - 1) / NTI));
+  hipLaunchKernelGGL((k2<NTI, NTL, NTS, PF, MAP, DRHO, BLK>), grid, dim3(BLK), 0, 0, a.T, a.S, a.rho0m,
                      a.surf, a.z_i, a.deptho, a.p, -1.0 / 1035.0, a.nt, a.nz, a.plane, a.ts, a.drho,
                      a.eta);
 }
@@ -196,19 +196,18 @@ int main(int argc, char** argv) {
   Args a{T, S, rho0m, rho0m, zi, dep, p, nt, nz, plane, n3, drho, eta};
 
   std::vector<Variant> vs = {
-      {"drho NTI8 ld  st  pf0      ", launch<8, 0, 0, 0, 0, 1>, 24},
-      {"drho NTI8 nt  st  pf0      ", launch<8, 1, 0, 0, 0, 1>, 24},
-      {"drho NTI8 nt  nts pf0      ", launch<8, 1, 1, 0, 0, 1>, 24},
-      {"drho NTI8 ld  nts pf0      ", launch<8, 0, 1, 0, 0, 1>, 24},
-      {"drho NTI8 nt  nts pf0 xcd  ", launch<8, 1, 1, 0, 1, 1>, 24},
-      {"drho NTI4 nt  nts pf1      ", launch<4, 1, 1, 1, 0, 1>, 24},
-      {"drho NTI4 nt  nts pf0      ", launch<4, 1, 1, 0, 0, 1>, 24},
-      {"drho NTI16 nt nts pf0      ", launch<16, 1, 1, 0, 0, 1>, 24},
-      {"eta  NTI8 ld      pf0      ", launch<8, 0, 0, 0, 0, 0>, 16},
-      {"eta  NTI8 nt      pf0      ", launch<8, 1, 0, 0, 0, 0>, 16},
-      {"eta  NTI8 nt      pf0 xcd  ", launch<8, 1, 0, 0, 1, 0>, 16},
-      {"eta  NTI4 nt      pf1      ", launch<4, 1, 0, 1, 0, 0>, 16},
-      {"eta  NTI16 nt     pf0      ", launch<16, 1, 0, 0, 0, 0>, 16},
+      {"drho NTI16 nt nts xcd B256 ", launch<16, 1, 1, 0, 1, 1, 256>, 24},
+      {"drho NTI16 nt nts     B256 ", launch<16, 1, 1, 0, 0, 1, 256>, 24},
+      {"drho NTI16 nt nts xcd B512 ", launch<16, 1, 1, 0, 1, 1, 512>, 24},
+      {"drho NTI16 nt nts xcd B128 ", launch<16, 1, 1, 0, 1, 1, 128>, 24},
+      {"drho NTI16 nt nts xcd B64  ", launch<16, 1, 1, 0, 1, 1, 64>, 24},
+      {"drho NTI12 nt nts xcd B256 ", launch<12, 1, 1, 0, 1, 1, 256>, 24},
+      {"drho NTI20 nt nts xcd B256 ", launch<20, 1, 1, 0, 1, 1, 256>, 24},
+      {"drho NTI24 nt nts xcd B256 ", launch<24, 1, 1, 0, 1, 1, 256>, 24},
+      {"eta  NTI16 nt     xcd B256 ", launch<16, 1, 0, 0, 1, 0, 256>, 16},
+      {"eta  NTI16 nt     xcd B512 ", launch<16, 1, 0, 0, 1, 0, 512>, 16},
+      {"eta  NTI16 nt     xcd B128 ", launch<16, 1, 0, 0, 1, 0, 128>, 16},
+      {"eta  NTI24 nt     xcd B256 ", launch<24, 1, 0, 0, 1, 0, 256>, 16},
   };
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
