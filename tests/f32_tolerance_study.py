@@ -1,6 +1,6 @@
 """BASELINE.json configs[4]: float32 tolerance study at the 0.25-degree grid (one MI355X).
 
-    python scripts/f32_study.py [--nt 120] > profiles/r01_f32_study.json
+    python tests/f32_tolerance_study.py [--nt 120] > profiles/r01_f32_study.json
 
 Real MOM6 output is float32 on disk.  The reference then computes in numpy's mixed precision
 (al0, p0, lam rounded in float32, the rest in float64 -- SURVEY.md 3.4 #7).  This script
@@ -25,7 +25,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from momlevel_amd import core, synthetic  # noqa: E402
-from oracle import momlevel_numpy as o  # noqa: E402  (checker)
+from oracle import momlevel_numpy as o  # noqa: E402  (the checker; this study lives under tests/ for that reason)
 
 
 def timed(fn, reps=3):
