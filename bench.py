@@ -275,6 +275,9 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
     ms = _time(lambda: core.steric_global_masso(T, S[0], vol0, pres))
     out["thermosteric_global"] = {"Mcells/s": round(cells / ms / 1e3, 1),
                                   "GB/s_at_8B_per_cell": round(8 * cells / ms / 1e6, 1)}
+    ms = _time(lambda: core.steric_global_masso(T[0], S, vol0, pres))
+    out["halosteric_global"] = {"Mcells/s": round(cells / ms / 1e3, 1),
+                                "GB/s_at_8B_per_cell": round(8 * cells / ms / 1e6, 1)}
     rho0m = core.fold_mask(core.eos_map(T[0], S[0], pres), vol0)
     zi = torch.from_numpy(g["z_i"]).to(dev)
     dep = torch.from_numpy(g["deptho"]).to(dev)

@@ -63,6 +63,77 @@ __device__ __forceinline__ void wright_terms(R T, R S, R& al0, R& p0, R& lam) {
   lam = (K::C0 + K::C4 * S) + T * ((K::C1 + T * (K::C2 + K::C3 * T)) + K::C5 * S);
 }
 
+// ---- held-field hoisting (thermosteric: S fixed in time; halosteric: T fixed) --------------
+// The sub-expressions of al0, p0, lam that depend only on the held field are evaluated once
+// per cell, outside the time loop.  They are the SAME sub-expressions, rounded the same way,
+// so the result stays bit-identical to wright_terms(); only 7 (S held) or 10 (T held) of the
+// ~26 polynomial operations per cell and time step disappear.
+template <typename R>
+struct HeldS {  // terms of S only
+  R a2s, b04s, b5s, c04s, c5s;
+};
+template <typename R>
+struct HeldT {  // terms of T only
+  R t, a01t, bpoly, cpoly;
+};
+
+template <typename R>
+__device__ __forceinline__ HeldS<R> hold_S(R S) {
+  using K = WrightC<R>;
+  HeldS<R> h;
+  h.a2s = K::A2 * S;
+  h.b04s = K::B0 + K::B4 * S;
+  h.b5s = K::B5 * S;
+  h.c04s = K::C0 + K::C4 * S;
+  h.c5s = K::C5 * S;
+  return h;
+}
+
+template <typename R>
+__device__ __forceinline__ HeldT<R> hold_T(R T) {
+  using K = WrightC<R>;
+  HeldT<R> h;
+  h.t = T;
+  h.a01t = K::A0 + K::A1 * T;
+  h.bpoly = K::B1 + T * (K::B2 + K::B3 * T);
+  h.cpoly = K::C1 + T * (K::C2 + K::C3 * T);
+  return h;
+}
+
+template <typename R>
+__device__ __forceinline__ void wright_terms_heldS(R T, const HeldS<R>& h, R& al0, R& p0, R& lam) {
+  using K = WrightC<R>;
+  al0 = (K::A0 + K::A1 * T) + h.a2s;
+  p0 = h.b04s + T * ((K::B1 + T * (K::B2 + K::B3 * T)) + h.b5s);
+  lam = h.c04s + T * ((K::C1 + T * (K::C2 + K::C3 * T)) + h.c5s);
+}
+
+template <typename R>
+__device__ __forceinline__ void wright_terms_heldT(const HeldT<R>& h, R S, R& al0, R& p0, R& lam) {
+  using K = WrightC<R>;
+  al0 = h.a01t + K::A2 * S;
+  p0 = (K::B0 + K::B4 * S) + h.t * (h.bpoly + K::B5 * S);
+  lam = (K::C0 + K::C4 * S) + h.t * (h.cpoly + K::C5 * S);
+}
+
+// rho from (al0, p0, lam) already widened to float64: eos/wright.py:47-48
+__device__ __forceinline__ double wright_density_from_terms(double al0, double p0, double lam,
+                                                            double p) {
+  const double pp0 = p + p0;
+  const double I_denom = 1.0 / (lam + al0 * pp0);
+  return pp0 * I_denom;
+}
+
+// arithmetic type of the polynomial part for a dtype mode
+template <int MODE>
+struct PolyType {
+  typedef double type;
+};
+template <>
+struct PolyType<kF32Faithful> {
+  typedef float type;
+};
+
 // in-situ density, eos/wright.py:44-48.  MODE selects how float32 inputs are treated.
 template <int MODE, typename TIn>
 __device__ __forceinline__ double wright_density(TIn Tin, TIn Sin, double p) {

@@ -160,18 +160,40 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
   if (!GENERIC || p_mode == MLX_P_ZPROF) pz = p[z];
   if (GENERIC && p_mode == MLX_P_SCALAR) pz = p[0];
 
+  // HOLD != 0: the held field is read once and its share of the polynomial is hoisted out of
+  // the time loop (eos_device.hpp, "held-field hoisting"); only the other field streams.
+  typedef typename PolyType<MODE>::type R;
+  HeldS<R> hs[HOLD == 2 ? U : 1][VEC];
+  HeldT<R> ht[HOLD == 1 ? U : 1][VEC];
+  if constexpr (HOLD == 2) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const Pack<TIn, VEC> s0 = load_pack<TIn, VEC, true>(S + off[u]);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) hs[u][k] = hold_S<R>((R)s0.v[k]);
+    }
+  }
+  if constexpr (HOLD == 1) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const Pack<TIn, VEC> t0 = load_pack<TIn, VEC, true>(T + off[u]);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) ht[u][k] = hold_T<R>((R)t0.v[k]);
+    }
+  }
+
   Pack<TIn, VEC> curT[U], curS[U], nxtT[U], nxtS[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    nxtT[u] = load_pack<TIn, VEC, true>(T + (int64_t)tb * t_stride_T + off[u]);
-    nxtS[u] = load_pack<TIn, VEC, true>(S + (int64_t)tb * t_stride_S + off[u]);
+    if (HOLD != 1) nxtT[u] = load_pack<TIn, VEC, true>(T + (int64_t)tb * t_stride_T + off[u]);
+    if (HOLD != 2) nxtS[u] = load_pack<TIn, VEC, true>(S + (int64_t)tb * t_stride_S + off[u]);
   }
 
   for (int t = tb; t < te; ++t) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (HOLD != 1 || t == tb) curT[u] = nxtT[u];
-      if (HOLD != 2 || t == tb) curS[u] = nxtS[u];
+      if (HOLD != 1) curT[u] = nxtT[u];
+      if (HOLD != 2) curS[u] = nxtS[u];
     }
     if (t + 1 < te) {  // issue the next step's loads before this step's arithmetic
 #pragma unroll
@@ -191,8 +213,13 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
         if constexpr (GENERIC) {
           const double pp = (p_mode == MLX_P_FULL3D) ? pc[u][k] : pz;
           rho = eos_eval<MODE, TIn>(eos, kDensity, curT[u].v[k], curS[u].v[k], pp);
-        } else {
+        } else if constexpr (HOLD == 0) {
           rho = wright_density<MODE, TIn>(curT[u].v[k], curS[u].v[k], pz);
+        } else {
+          R al0, p0, lam;
+          if constexpr (HOLD == 2) wright_terms_heldS<R>((R)curT[u].v[k], hs[u][k], al0, p0, lam);
+          else wright_terms_heldT<R>(ht[u][k], (R)curS[u].v[k], al0, p0, lam);
+          rho = wright_density_from_terms((double)al0, (double)p0, (double)lam, pz);
         }
         const double term = rho * vol[u][k];  // derived.py:435
         c += is_nan(term) ? 0.0 : term;       // skipna
@@ -525,6 +552,9 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // cells a K1 block covers within one z level
 constexpr int kU64 = 4, kVec64 = 2;  // 8 cells/thread, 2048 cells/block (fast f64)
 constexpr int kU32 = 2, kVec32 = 4;  // 8 cells/thread (fast f32)
+// NB: every variant of a dtype (steric / thermosteric / halosteric, any nt) must share ONE tiling:
+// the reference state's masso0 (HOLD=0, nt=1) has to equal masso(t=0) of the held-field launches
+// bit for bit, and the partial-sum order is a function of the tiling.
 constexpr int kUGen = 4;             // generic: 4 scalar cells/thread, 1024 cells/block
 constexpr int kTChunk = 32;          // K1 time steps per block (grid.z = ceil(nt / kTChunk))
 constexpr int kNTI64 = 16;           // time steps per K2 thread, f64 (2 columns/thread)

@@ -378,7 +378,9 @@ int main(int argc, char** argv) {
   const int64_t plane = 1080LL * 1440, n3 = plane * nz, n4 = n3 * nt;
   double *T, *S, *vol, *p, *partials;
   CK(hipMalloc(&T, n4 * 8));
-  CK(hipMalloc(&S, n4 * 8));
+  const int64_t spad = getenv("SPAD") ? atoll(getenv("SPAD")) : 0;  // bytes of skew between T and S
+  CK(hipMalloc(&S, n4 * 8 + spad));
+  S = (double*)((char*)S + spad);
   CK(hipMalloc(&vol, n3 * 8));
   CK(hipMalloc(&p, nz * 8));
   CK(hipMalloc(&partials, (size_t)nt * 2 * (n3 / 512 + 1024) * 8));
@@ -396,19 +398,11 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
 
   std::vector<Variant> vs = {
+      {"nt xcd1 B256 U4 zchunk 32     ", launch_z<256, 4, 1, 1, 32>},
+      {"nt xcd1 B256 U8 zchunk 32     ", launch_z<256, 8, 1, 1, 32>},
       {"nt xcd1 B256 U4 one launch    ", launch<256, 4, 1, 1, 0, 1>},
-      {"nt xcd1 B256 U4 zchunk 60     ", launch_z<256, 4, 1, 1, 60>},
-      {"nt xcd1 B256 U4 zchunk 40     ", launch_z<256, 4, 1, 1, 40>},
-      {"nt xcd1 B256 U4 zchunk 30     ", launch_z<256, 4, 1, 1, 30>},
-      {"nt xcd1 B256 U4 zchunk 24     ", launch_z<256, 4, 1, 1, 24>},
-      {"nt xcd1 B256 U4 zchunk 15     ", launch_z<256, 4, 1, 1, 15>},
-      {"nt xcd1 B256 U4 zchunk 8      ", launch_z<256, 4, 1, 1, 8>},
-      {"nt xcd1 B512 U4 one launch    ", launch<512, 4, 1, 1, 0, 1>},
-      {"nt xcd1 B512 U4 zchunk 30     ", launch_z<512, 4, 1, 1, 30>},
-      {"nt xcd1 B256 U8 zchunk 30     ", launch_z<256, 8, 1, 1, 30>},
-      {"nt xcd1 B256 U4 sumonly       ", launch<256, 4, 1, 1, 2, 1>},
-      {"ld      B256 U4 one launch    ", launch<256, 4, 1, 0, 0, 0>},
   };
+  printf("T=%p S=%p spad=%lld\n", (void*)T, (void*)S, (long long)spad);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
