@@ -12,8 +12,6 @@ beyond what input validation and the tests need.
 are only ever *relabelled*; their numbers go through the HIP kernels.
 """
 
-import copy as _copy
-
 import numpy as np
 
 try:  # torch is the device-array container; labelled arrays work without it
@@ -428,18 +426,3 @@ class Dataset:
             out._set(k, v if isinstance(v, DataArray) else DataArray(np.asarray(v), (k,)),
                      is_coord=True)
         return out
-
-
-def where(cond, x, y):
-    """xr.where for the labelled classes (host side)."""
-    cond = cond if isinstance(cond, DataArray) else DataArray(cond)
-    x = x if isinstance(x, DataArray) else DataArray(np.asarray(x, dtype=np.float64), ())
-    (c, dims), (xv, _) = _align(cond, x)
-    if isinstance(y, DataArray):
-        (_, dims2), (yv, _) = _align(DataArray(np.broadcast_to(c, np.broadcast(c, xv).shape), dims), y)
-        return DataArray(np.where(c, xv, yv), dims2)
-    return DataArray(np.where(c, xv, y), dims)
-
-
-def deepcopy(obj):
-    return _copy.deepcopy(obj)

@@ -1,18 +1,17 @@
 """ steric.py - local and global steric sea level on the MI355X
 
-Drop-in for src/momlevel/steric.py:17-196 -- same names, arguments, defaults,
-error behaviour and ``(result, reference)`` return value.  The arithmetic is the
-fused HIP path:
+Drop-in for the public entry points of src/momlevel/steric.py (:17-196): same names,
+arguments, defaults, error behaviour and ``(result, reference)`` return value.  What differs
+is where the numbers come from -- the fused HIP kernels instead of ~30 numpy passes:
 
-* ``domain="global"``: K1 (Wright EOS + rho*volcello_ref + sum over z,y,x per time
-  step) gives masso(t); the remaining ``log`` on nt scalars is host arithmetic as in
-  the reference (steric.py:136-142).
-* ``domain="local"``: K2 (Wright EOS + delta_rho + dz-weighted column sum, dz from
-  calc_dz's default path) gives ``delta_rho`` and the sea level field in one pass.
+* ``domain="global"``: K1 (``mlx_steric_global``: Wright EOS x reference volcello, summed over
+  z,y,x per time step) yields masso(t); the remaining ``log`` on nt scalars stays on the host,
+  as in the reference (steric.py:136-142).
+* ``domain="local"``: K2 (``mlx_steric_local``: EOS, delta_rho and the dz-weighted column sum in
+  one pass, dz evaluated as calc_dz's default path) yields ``delta_rho`` and the height field.
 
-Inputs may be labelled datasets backed by numpy (streamed to HBM in time chunks)
-or by device tensors (processed in place), or xarray Datasets when xarray is
-installed.
+Inputs: labelled datasets backed by numpy (streamed to HBM in time chunks) or by device
+tensors (processed in place); xarray Datasets when xarray is installed (adapters.py).
 """
 
 import numpy as np
@@ -31,9 +30,70 @@ from .util import annual_average, default_coords, eos_func_from_str, validate_da
 
 __all__ = ["halosteric", "steric", "thermosteric"]
 
+_VARIANTS = ("steric", "thermosteric", "halosteric")
 
-def _canonical(da, dims):
-    return da.transpose(*dims).data
+
+def _held_and_streamed(variant, dset, reference):
+    """(thetao, so) with the field the variant freezes taken from the reference state
+    (steric.py:115-125)."""
+    if variant not in _VARIANTS:
+        raise ValueError(f"Unknown variant '{variant}' passed to `steric`")
+    thetao = reference["thetao"] if variant == "halosteric" else dset["thetao"]
+    so = reference["so"] if variant == "thermosteric" else dset["so"]
+    return thetao, so
+
+
+def _check_dz_inputs(levels, interfaces, depth):
+    """calc_dz's sign checks (derived.py:284-292); they stay on the host."""
+    assert bool(np.all(np.nan_to_num(depth.values, nan=0.0) >= 0)), (
+        "Depth values must all be positive-definite"
+    )
+    assert bool(np.all(levels.values >= 0)), (
+        "Vertical coordinate levels must all be positive-definite"
+    )
+    assert bool(np.all(interfaces.values >= 0)), (
+        "Vertical coordinate interfaces must all be positive-definite"
+    )
+
+
+def _global_branch(result, fields, reference, variant, dtype, tcoord, coords_for):
+    """steric.py:134-147 -- masso(t) from K1, then the Boussinesq offline approximation."""
+    T, S, vol0, p, eos = fields
+    masso = engine.global_masso(T, S, vol0, p, eos=eos, f32_mode=_f32_mode()).cpu().numpy()
+    reference_height, sealevel, _expansion_coeff = engine.global_finalize(
+        masso,
+        np.float64(reference["volo"].values),
+        np.float64(reference["rhoga"].values),
+        np.float64(reference["areacello"].sum().values),
+    )
+    result["reference_height"] = DataArray(
+        np.float64(reference_height), (), None,
+        {"long_name": "Reference column height", "units": "m"},
+    )
+    result["reference_height"].encoding["dtype"] = dtype
+    result[variant] = DataArray(sealevel, (tcoord,), coords_for((tcoord,)))
+
+
+def _local_branch(result, fields, dset, reference, variant, dtype, rhozero, names, cdims3,
+                  coords_for):
+    """steric.py:150-166 -- delta_rho and the column integral from K2."""
+    T, S, vol0, p, eos = fields
+    tcoord, zcoord, zbounds = names
+    hdims = cdims3[1:]
+    cdims4 = (tcoord,) + cdims3
+    deptho = dset["deptho"].transpose(*hdims)
+    _check_dz_inputs(dset[zcoord], dset[zbounds], deptho)
+    delta_rho, sealevel = engine.local_steric(
+        T, S, reference["rho"].transpose(*cdims3).data, vol0, p, rhozero,
+        z_i=dset[zbounds].data, deptho=deptho.data, eos=eos, f32_mode=_f32_mode(),
+        want_delta_rho=True,
+    )
+    result["delta_rho"] = DataArray(
+        delta_rho, cdims4, coords_for(cdims4),
+        {"long_name": "change in in situ density from reference state", "units": "kg m-3"},
+    )
+    result["delta_rho"].encoding["dtype"] = dtype
+    result[variant] = DataArray(sealevel, (tcoord,) + hdims, coords_for((tcoord,) + hdims))
 
 
 @accepts_xarray
@@ -52,142 +112,99 @@ def steric(
     annual=False,
     verbose=False,
 ):
-    """Function to calculate steric sea level change
+    """Steric, thermosteric or halosteric sea level change relative to a reference state.
 
-    Calculates the steric, thermosteric, or halosteric sea level change and
-    associated quantities relative to a reference state, locally at each grid
-    point or globally (offline Boussinesq approximation).  Parameters and return
-    value as in the reference (src/momlevel/steric.py:33-82); ``dtype`` is output
-    encoding metadata only, the arithmetic is float64.
+    Parameters (as the reference, src/momlevel/steric.py:33-82)
+    ----------
+    dset : Dataset with thetao, so, volcello (t,z,y,x) and areacello (y,x); for
+        ``domain="local"`` also the z bounds coordinate and ``deptho``
+    reference : Dataset, optional -- a reference state from an earlier call; time index 0 of
+        ``dset`` is used when omitted
+    coord_names : dict, optional -- ``{"t":…, "z":…, "zbounds":…}`` overrides of
+        ``("time", "z_l", "z_i")``
+    varname_map : dict, optional -- variables renamed before anything else
+    rhozero : float -- Boussinesq reference density, kg m-3 (local variant)
+    patm : float or DataArray -- sea-surface atmospheric pressure, Pa
+    equation_of_state : str -- a module of ``momlevel_amd.eos`` ("Wright", "linear")
+    variant : "steric" | "thermosteric" | "halosteric"
+    domain : "local" (column integral per grid point) | "global" (one value per time step)
+    dtype : str -- output ENCODING metadata only; the arithmetic is float64
+    strict : bool -- False downgrades the areacello range check to a warning
+    annual : bool -- days-in-month weighted annual means of the result
+    verbose : bool
 
     Returns
     -------
     (result, reference) : tuple of Datasets
     """
-    # remap variable names, if passed
     dset = dset.rename(varname_map)
+    names = default_coords(coord_names)
+    tcoord, zcoord, zbounds = names
 
-    # default coordinate names
-    tcoord, zcoord, zbounds = default_coords(coord_names)
+    validate_dataset(
+        dset, strict=strict, additional_vars=None if domain == "global" else [zbounds, "deptho"]
+    )
+    pres = pressure_field(dset, zcoord, patm)  # 1 m of depth ~ 1 dbar = 1e4 Pa, plus patm
 
-    # conduct some sanity checks on the input dataset
-    additional_vars = None if domain == "global" else [zbounds, "deptho"]
-    validate_dataset(dset, strict=strict, additional_vars=additional_vars)
-
-    # approximate pressure from depth coordinate (1 m ~ 1 dbar = 1e4 Pa) + patm
-    pres = pressure_field(dset, zcoord, patm)
-
-    if reference is not None:
-        assert isinstance(reference, Dataset), "`reference` must be an xarray Dataset"
-        if verbose:
-            print("Using supplied reference state")
-    else:
+    if reference is None:
         reference = setup_reference_state(
             dset, patm=patm, eos=equation_of_state, coord_names=coord_names
         )
         if verbose:
             print("Generating reference state from first timestep")
-
-    # conduct some sanity checks on the reference state
+    else:
+        assert isinstance(reference, Dataset), "`reference` must be an xarray Dataset"
+        if verbose:
+            print("Using supplied reference state")
     validate_dataset(reference, reference=True, strict=strict)
 
-    # determine which fields, if any, to hold fixed
-    if variant == "thermosteric":
-        thetao = dset["thetao"]
-        so = reference["so"]
-    elif variant == "halosteric":
-        thetao = reference["thetao"]
-        so = dset["so"]
-    elif variant == "steric":
-        thetao = dset["thetao"]
-        so = dset["so"]
-    else:
-        raise ValueError(f"Unknown variant '{variant}' passed to `steric`")
-
-    # canonical (time, z, y, x) layout -- outputs are always time-first (steric.py:154,165)
-    streamed = thetao if tcoord in thetao.dims else so
-    cdims3 = canonical_dims(streamed, tcoord, zcoord)
-    cdims4 = (tcoord,) + cdims3
-    hdims = cdims3[1:]
-
-    def field(da):
-        return _canonical(da, cdims4 if tcoord in da.dims else cdims3)
-
-    T, S = field(thetao), field(so)
-    vol0 = _canonical(reference["volcello"], cdims3)
-    p = pressure_operand(pres, tcoord, cdims3)
+    thetao, so = _held_and_streamed(variant, dset, reference)
     eos_func_from_str(equation_of_state)  # unknown EOS -> ValueError (util.py:247)
-    eos = equation_of_state.lower()
+
+    # canonical (time, z, y, x) layout; outputs are always time-first (steric.py:154,165)
+    cdims3 = canonical_dims(thetao if tcoord in thetao.dims else so, tcoord, zcoord)
+
+    def raw(da):
+        return da.transpose(*(((tcoord,) + cdims3) if tcoord in da.dims else cdims3)).data
 
     def coords_for(dims):
         return {d: dset[d] for d in dims if d in dset.variables}
 
+    fields = (
+        raw(thetao),
+        raw(so),
+        raw(reference["volcello"]),
+        pressure_operand(pres, tcoord, cdims3),
+        equation_of_state.lower(),
+    )
+
     result = Dataset()
-
     if domain == "global":
-        masso = engine.global_masso(T, S, vol0, p, eos=eos, f32_mode=_f32_mode())
-        masso = masso.cpu().numpy()
-        volo = np.float64(reference["volo"].values)
-        rhoga = np.float64(reference["rhoga"].values)
-        area_sum = np.float64(reference["areacello"].sum().values)
-        reference_height, sealevel, _expansion = engine.global_finalize(
-            masso, volo, rhoga, area_sum
-        )
-        rh = DataArray(np.float64(reference_height), (), None,
-                       {"long_name": "Reference column height", "units": "m"})
-        result["reference_height"] = rh
-        result["reference_height"].encoding["dtype"] = dtype
-        result[variant] = DataArray(sealevel, (tcoord,), coords_for((tcoord,)))
+        _global_branch(result, fields, reference, variant, dtype, tcoord, coords_for)
     else:
-        # calc_dz's input checks (derived.py:284-292) stay on the host
-        deptho = dset["deptho"].transpose(*hdims)
-        assert bool(np.all(np.nan_to_num(deptho.values, nan=0.0) >= 0)), (
-            "Depth values must all be positive-definite"
-        )
-        assert bool(np.all(dset[zcoord].values >= 0)), (
-            "Vertical coordinate levels must all be positive-definite"
-        )
-        assert bool(np.all(dset[zbounds].values >= 0)), (
-            "Vertical coordinate interfaces must all be positive-definite"
-        )
-        rho0 = _canonical(reference["rho"], cdims3)
-        delta_rho, sealevel = engine.local_steric(
-            T, S, rho0, vol0, p, rhozero, z_i=dset[zbounds].data, deptho=deptho.data,
-            eos=eos, f32_mode=_f32_mode(), want_delta_rho=True,
-        )
-        dr = DataArray(delta_rho, cdims4, coords_for(cdims4))
-        dr.attrs = {
-            "long_name": "change in in situ density from reference state",
-            "units": "kg m-3",
-        }
-        result["delta_rho"] = dr
-        result["delta_rho"].encoding["dtype"] = dtype
-        result[variant] = DataArray(sealevel, (tcoord,) + hdims, coords_for((tcoord,) + hdims))
+        _local_branch(result, fields, dset, reference, variant, dtype, rhozero, names, cdims3,
+                      coords_for)
 
-    # fix up variable metadata
     result[variant].attrs.update(
         {"long_name": f"{variant.capitalize()} height adjustment", "units": "m"}
     )
     result[variant].encoding["dtype"] = dtype
 
-    # copy coordinate and dimension attributes
+    # coordinate / dimension attributes follow the input dataset (steric.py:177-179)
     for var in set(result.coords).union(result.dims):
         if var in dset.variables and var in result.variables:
             result[var].attrs.update(dset[var].attrs)
 
     if annual:
         result = annual_average(result)
-
     return (result, reference)
 
 
 def halosteric(*args, **kwargs):
-    """Wrapper for halosteric calculation"""
-    result, reference = steric(*args, **kwargs, variant="halosteric")
-    return (result, reference)
+    """``steric(..., variant="halosteric")``: salinity varies, temperature held at the reference."""
+    return steric(*args, **kwargs, variant="halosteric")
 
 
 def thermosteric(*args, **kwargs):
-    """Wrapper for thermosteric calculation"""
-    result, reference = steric(*args, **kwargs, variant="thermosteric")
-    return (result, reference)
+    """``steric(..., variant="thermosteric")``: temperature varies, salinity held."""
+    return steric(*args, **kwargs, variant="thermosteric")

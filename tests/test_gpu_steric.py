@@ -9,7 +9,6 @@ import numpy as np
 import pytest
 import torch
 
-import momlevel_amd
 from momlevel_amd import steric, thermosteric, halosteric, reference as reference_mod, util
 from momlevel_amd.eos import wright
 from momlevel_amd.labeled import DataArray, Dataset

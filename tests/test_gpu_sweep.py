@@ -7,7 +7,7 @@ import torch
 
 from momlevel_amd import core
 from oracle import momlevel_numpy as o
-from conftest import assert_bit_equal, assert_rel
+from conftest import assert_bit_equal
 
 pytestmark = pytest.mark.gpu
 
