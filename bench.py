@@ -191,7 +191,7 @@ def main():
     traffic, traffic_src = measured_traffic(cells_rank)
 
     extras = {}
-    if not a.no_extras and rank == 0:
+    if not a.no_extras and world == 1:
         extras = local_variant_timings(T, S, vol0, pres, g, dev)
 
     cpu, parity = None, None
@@ -214,8 +214,13 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": (f"OM4 0.25deg synthetic grid {nx}x{ny}x{nz}, {nt_req // world} time "
-                             "steps per GPU, fp64, global steric (BASELINE.json configs[2])"),
+                "workload": (
+                    f"OM4 0.25deg synthetic grid {nx}x{ny}x{nz}, {nt} time steps, fp64, global "
+                    "steric (BASELINE.json configs[2])" if world == 1 else
+                    f"OM4 0.25deg synthetic grid {nx}x{ny}x{nz} tiled {layout} (yh x xh), {nt} time "
+                    f"steps, fp64, global steric: every GPU holds all {nt} steps of its "
+                    f"{tw}x{th} tile = the cells of {nt // world} full-grid steps "
+                    "(BASELINE.json configs[3], weak scaling in time)"),
                 "grid_xyz": [nx, ny, nz],
                 "nt_per_gpu_resident": nt,
                 "nt_total": nt,

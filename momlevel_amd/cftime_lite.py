@@ -64,8 +64,16 @@ def _from_day_of_year(year, doy, calendar):
 
 
 def year_midpoint(year, calendar):
-    """bounds[0] + (bounds[1] - bounds[0]) / 2 of util.py:93-98."""
-    return _from_day_of_year(year, days_in_year(year, calendar) / 2.0, calendar)
+    """bounds[0] + (bounds[1] - bounds[0]) / 2 of util.py:93-98 (a cftime.datetime when cftime
+    is installed, so that xarray sees a CFTimeIndex as it does with the reference)."""
+    mid = _from_day_of_year(year, days_in_year(year, calendar) / 2.0, calendar)
+    try:
+        import cftime
+
+        return cftime.datetime(mid.year, mid.month, mid.day, mid.hour, mid.minute,
+                               calendar=calendar)
+    except Exception:
+        return mid
 
 
 def monthly_midpoints(start_year, nyears, calendar):
