@@ -377,15 +377,17 @@ int main(int argc, char** argv) {
   const int nz = 75;
   const int64_t plane = 1080LL * 1440, n3 = plane * nz, n4 = n3 * nt;
   double *T, *S, *vol, *p, *partials;
-  CK(hipMalloc(&T, n4 * 8));
+  const int nt_alloc = getenv("NTALLOC") ? atoi(getenv("NTALLOC")) : nt;
+  const int64_t n4a = n3 * nt_alloc;
+  CK(hipMalloc(&T, n4a * 8));
   const int64_t spad = getenv("SPAD") ? atoll(getenv("SPAD")) : 0;  // bytes of skew between T and S
-  CK(hipMalloc(&S, n4 * 8 + spad));
+  CK(hipMalloc(&S, n4a * 8 + spad));
   S = (double*)((char*)S + spad);
   CK(hipMalloc(&vol, n3 * 8));
   CK(hipMalloc(&p, nz * 8));
   CK(hipMalloc(&partials, (size_t)nt * 2 * (n3 / 512 + 1024) * 8));
-  hipLaunchKernelGGL(fill, dim3(16384), dim3(256), 0, 0, T, n4, n3, -2.0, 34.0, 1ULL);
-  hipLaunchKernelGGL(fill, dim3(16384), dim3(256), 0, 0, S, n4, n3, 30.0, 10.0, 2ULL);
+  hipLaunchKernelGGL(fill, dim3(16384), dim3(256), 0, 0, T, n4a, n3, -2.0, 34.0, 1ULL);
+  hipLaunchKernelGGL(fill, dim3(16384), dim3(256), 0, 0, S, n4a, n3, 30.0, 10.0, 2ULL);
   hipLaunchKernelGGL(fill, dim3(16384), dim3(256), 0, 0, vol, n3, n3, 1e9, 1e11, 3ULL);
   std::vector<double> ph(nz);
   double zc = 0;
@@ -410,7 +412,7 @@ int main(int argc, char** argv) {
   for (int r = 0; r < rounds + 1; ++r) {
     for (size_t i = 0; i < vs.size(); ++i) {
       CK(hipEventRecord(e0, 0));
-      vs[i].launch(T, S, vol, p, nt, plane, n3, partials, nz, 0);
+      vs[i].launch(T, S, vol, p, nt, plane, getenv("TS0") ? (int64_t)atoll(getenv("TS0")) * n3 / 1000 : n3, partials, nz, 0);
       CK(hipEventRecord(e1, 0));
       CK(hipEventSynchronize(e1));
       CK(hipGetLastError());

@@ -134,6 +134,74 @@ __global__ __launch_bounds__(BLK) void k2(const double* __restrict__ T, const do
   }
 }
 
+// half-batched: 16 time steps per thread (rho0m amortised over 16) but only 8 steps' loads in
+// flight at a time -> fewer VGPRs, 3 waves/SIMD
+template <int NTS, int MAP, int DRHO, int PARTS>
+__global__ __launch_bounds__(256) void k2hb(const double* __restrict__ T, const double* __restrict__ S,
+                                            const double* __restrict__ rho0m,
+                                            const double* __restrict__ surf,
+                                            const double* __restrict__ z_i,
+                                            const double* __restrict__ deptho,
+                                            const double* __restrict__ p, double c, int nt, int nz,
+                                            int64_t plane, int64_t ts, double* __restrict__ drho,
+                                            double* __restrict__ eta) {
+  constexpr int NTI = 16, H = NTI / PARTS;
+  const int64_t bx = MAP ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+  const int64_t col = (bx * 256 + threadIdx.x) * 2;
+  if (col + 2 > plane) return;
+  const int t0 = blockIdx.y * NTI;
+  const int64_t n3 = (int64_t)nz * plane;
+  double acc[NTI][2];
+#pragma unroll
+  for (int j = 0; j < NTI; ++j) acc[j][0] = acc[j][1] = 0.0;
+  const D2 depth = ld2<0>(deptho + col);
+  for (int z = 0; z < nz; ++z) {
+    const int64_t off = (int64_t)z * plane + col;
+    const D2 r0 = ld2<0>(rho0m + off);
+    const double ztop = z_i[z], zbot = z_i[z + 1];
+    const double dz0 = dz_default(depth.v[0], ztop, zbot), dz1 = dz_default(depth.v[1], ztop, zbot);
+    const double pz = p[z];
+#pragma unroll
+    for (int h = 0; h < PARTS; ++h) {
+      D2 a[H], b[H];
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        const int64_t t = (t0 + h * H + j < nt) ? (t0 + h * H + j) : (nt - 1);
+        a[j] = ld2<1>(T + t * ts + off);
+        b[j] = ld2<1>(S + t * ts + off);
+      }
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        const int jj = h * H + j;
+        if (t0 + jj < nt) {
+          D2 d;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const double rho = wright_density<kF64, double>(a[j].v[k], b[j].v[k], pz);
+            double dr = rho - r0.v[k];
+            dr = is_nan(dr) ? canonical_nan() : dr;
+            d.v[k] = dr;
+            const double term = (k ? dz1 : dz0) * dr;
+            acc[jj][k] += is_nan(term) ? 0.0 : term;
+          }
+          if (DRHO) st2<NTS>(drho + (int64_t)(t0 + jj) * n3 + off, d);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const D2 sf = ld2<0>(surf + col);
+#pragma unroll
+  for (int j = 0; j < NTI; ++j) {
+    if (t0 + j < nt) {
+      D2 e;
+      e.v[0] = is_nan(sf.v[0]) ? canonical_nan() : c * acc[j][0];
+      e.v[1] = is_nan(sf.v[1]) ? canonical_nan() : c * acc[j][1];
+      st2<0>(eta + (int64_t)(t0 + j) * plane + col, e);
+    }
+  }
+}
+
 __global__ void fill(double* x, int64_t n, int64_t n3, double lo, double scale, unsigned long long seed) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -161,6 +229,13 @@ void launch(const Args& a) {
   hipLaunchKernelGGL((k2<NTI, NTL, NTS, PF, MAP, DRHO, BLK>), grid, dim3(BLK), 0, 0, a.T, a.S, a.rho0m,
                      a.surf, a.z_i, a.deptho, a.p, -1.0 / 1035.0, a.nt, a.nz, a.plane, a.ts, a.drho,
                      a.eta);
+}
+
+template <int NTS, int MAP, int DRHO, int PARTS>
+void launch_hb(const Args& a) {
+  dim3 grid((unsigned)((a.plane + 511) / 512), (unsigned)((a.nt + 15) / 16));
+  hipLaunchKernelGGL((k2hb<NTS, MAP, DRHO, PARTS>), grid, dim3(256), 0, 0, a.T, a.S, a.rho0m, a.surf,
+                     a.z_i, a.deptho, a.p, -1.0 / 1035.0, a.nt, a.nz, a.plane, a.ts, a.drho, a.eta);
 }
 
 int main(int argc, char** argv) {
@@ -197,17 +272,11 @@ int main(int argc, char** argv) {
 
   std::vector<Variant> vs = {
       {"drho NTI16 nt nts xcd B256 ", launch<16, 1, 1, 0, 1, 1, 256>, 24},
-      {"drho NTI16 nt nts     B256 ", launch<16, 1, 1, 0, 0, 1, 256>, 24},
-      {"drho NTI16 nt nts xcd B512 ", launch<16, 1, 1, 0, 1, 1, 512>, 24},
-      {"drho NTI16 nt nts xcd B128 ", launch<16, 1, 1, 0, 1, 1, 128>, 24},
-      {"drho NTI16 nt nts xcd B64  ", launch<16, 1, 1, 0, 1, 1, 64>, 24},
-      {"drho NTI12 nt nts xcd B256 ", launch<12, 1, 1, 0, 1, 1, 256>, 24},
-      {"drho NTI20 nt nts xcd B256 ", launch<20, 1, 1, 0, 1, 1, 256>, 24},
-      {"drho NTI24 nt nts xcd B256 ", launch<24, 1, 1, 0, 1, 1, 256>, 24},
+      {"drho NTI16 2 half-batches  ", launch_hb<1, 1, 1, 2>, 24},
+      {"drho NTI16 4 quarter-batch ", launch_hb<1, 1, 1, 4>, 24},
       {"eta  NTI16 nt     xcd B256 ", launch<16, 1, 0, 0, 1, 0, 256>, 16},
-      {"eta  NTI16 nt     xcd B512 ", launch<16, 1, 0, 0, 1, 0, 512>, 16},
-      {"eta  NTI16 nt     xcd B128 ", launch<16, 1, 0, 0, 1, 0, 128>, 16},
-      {"eta  NTI24 nt     xcd B256 ", launch<24, 1, 0, 0, 1, 0, 256>, 16},
+      {"eta  NTI16 2 half-batches  ", launch_hb<1, 1, 0, 2>, 16},
+      {"eta  NTI16 4 quarter-batch ", launch_hb<1, 1, 0, 4>, 16},
   };
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
