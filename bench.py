@@ -119,7 +119,7 @@ def cpu_baseline_fused(T, S, g, pres, gpu_masso, slabs=2):
         from oracle import wright_c  # checker / timed baseline, never the product
     except Exception:
         return None
-    os.environ.setdefault("OMP_NUM_THREADS", "16")  # the 1-GPU box's CPU share
+    wright_c.set_threads(min(16, os.cpu_count() or 1))  # the 1-GPU box's CPU share is 16 cores
     vol = g["volcello"]
     wright_c.masso_slab(T[0].cpu().numpy(), S[0].cpu().numpy(), vol, pres)  # warm the thread pool
     spent, err = 0.0, 0.0

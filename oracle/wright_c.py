@@ -32,6 +32,8 @@ def load():
         lib.oracle_masso_slab.argtypes = [dp, dp, dp, dp, ctypes.c_int64, ctypes.c_int64, dp]
         lib.oracle_masso_slab.restype = ctypes.c_double
         lib.oracle_num_threads.restype = ctypes.c_int
+        lib.oracle_set_threads.argtypes = [ctypes.c_int]
+        lib.oracle_set_threads.restype = None
         _lib = lib
     return _lib
 
@@ -60,3 +62,7 @@ def masso_slab(T, S, vol, pz):
 
 def num_threads():
     return load().oracle_num_threads()
+
+
+def set_threads(n):
+    load().oracle_set_threads(int(n))

@@ -59,6 +59,13 @@ double oracle_masso_slab(const double *T, const double *S, const double *vol, co
   return total;
 }
 
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+  extern void omp_set_num_threads(int);
+  if (n > 0) omp_set_num_threads(n);
+#endif
+}
+
 int oracle_num_threads(void) {
   int n = 1;
 #ifdef _OPENMP
