@@ -113,9 +113,10 @@ def steric_global_tile(T, S, vol0, areacello, pres, variant="steric", eos="wrigh
         Tv, Sv = T, S
     else:
         raise ValueError(f"Unknown variant '{variant}' passed to `steric`")
-    _rho0, volo, masso0 = engine.reference_state(T[0], S[0], vol0, pres, eos=eos,
-                                                 f32_mode=f32_mode)
+    _rho0, volo, _ = engine.reference_state(T[0], S[0], vol0, pres, eos=eos, f32_mode=f32_mode,
+                                            with_masso=False)
     masso = engine.global_masso(Tv, Sv, vol0, pres, eos=eos, f32_mode=f32_mode)
+    masso0 = masso[0]  # the reference slab is step 0 of this record: same launch, same bits
     area = core.nansum(engine.to_device(areacello, masso.device, torch.float64))
     masso, volo, masso0, area = exchange_global(masso, volo, masso0, area, group=group)
     out = finalize(masso, volo, masso0, area)

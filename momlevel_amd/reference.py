@@ -45,20 +45,9 @@ def _f32_mode():
     return os.environ.get("MOMLEVEL_AMD_F32_MODE", "faithful")
 
 
-@accepts_xarray
-def setup_reference_state(
-    dset, patm=101325.0, eos="Wright", coord_names=None, time_index=0
-):
-    """Function to generate reference dataset
-
-    Values are taken from time level ``time_index`` of an input dataset holding
-    thetao, so, volcello and areacello (src/momlevel/reference.py:15-85).
-
-    Returns
-    -------
-    Dataset of reference values: thetao, so, volcello, rho (z,y,x); volo, masso,
-    rhoga (scalars); areacello.
-    """
+def _setup(dset, patm, eos, coord_names, time_index, defer_masso):
+    """setup_reference_state, optionally leaving masso / rhoga to the caller (steric() with
+    domain="global" reads them off its own K1 launch: engine.reference_state)."""
     coords = default_coords(coord_names)
     tcoord = coords[0]
     zcoord = coords[1]
@@ -81,7 +70,8 @@ def setup_reference_state(
 
     on_device = T0.is_device or S0.is_device or V0.is_device
     rho0, volo, masso0 = engine.reference_state(
-        T0.data, S0.data, V0.data, p, eos=eos.lower(), f32_mode=_f32_mode()
+        T0.data, S0.data, V0.data, p, eos=eos.lower(), f32_mode=_f32_mode(),
+        with_masso=not defer_masso,
     )
 
     rho = DataArray(rho0 if on_device else rho0.cpu().numpy(), cdims, T0.coords)
@@ -93,18 +83,43 @@ def setup_reference_state(
     }
     reference["rho"] = rho.transpose(*reference["thetao"].dims)
 
-    volo_h, masso_h = float(volo.item()), float(masso0.item())
+    volo_h = float(volo.item())
+    masso_h = float("nan") if masso0 is None else float(masso0.item())
     reference["volo"] = DataArray(
-        np.float64(volo_h), (), None,
+        np.array(volo_h), (), None,
         {"standard_name": "sea_water_volume", "long_name": "Sea Water Volume", "units": "m3"},
     )
     reference["masso"] = DataArray(
-        np.float64(masso_h), (), None,
+        np.array(masso_h), (), None,
         {"standard_name": "sea_water_mass", "long_name": "Sea Water Mass", "units": "kg"},
     )
     reference["rhoga"] = DataArray(
-        np.float64(masso_h) / np.float64(volo_h), (), None,
+        np.array(np.float64(masso_h) / np.float64(volo_h)), (), None,
         {"long_name": "Global Average Sea Water Density", "units": "kg m-3"},
     )
     reference["areacello"] = dset["areacello"]
     return reference
+
+
+def set_reference_masso(reference, masso0):
+    """Fill the deferred masso / rhoga of a reference built with ``defer_masso``."""
+    masso0 = np.float64(masso0)
+    reference["masso"].data[...] = masso0
+    reference["rhoga"].data[...] = masso0 / np.float64(reference["volo"].values)
+
+
+@accepts_xarray
+def setup_reference_state(
+    dset, patm=101325.0, eos="Wright", coord_names=None, time_index=0
+):
+    """Function to generate reference dataset
+
+    Values are taken from time level ``time_index`` of an input dataset holding
+    thetao, so, volcello and areacello (src/momlevel/reference.py:15-85).
+
+    Returns
+    -------
+    Dataset of reference values: thetao, so, volcello, rho (z,y,x); volo, masso,
+    rhoga (scalars); areacello.
+    """
+    return _setup(dset, patm, eos, coord_names, time_index, defer_masso=False)

@@ -21,10 +21,11 @@ from .adapters import accepts_xarray
 from .labeled import DataArray, Dataset
 from .reference import (
     _f32_mode,
+    _setup,
     canonical_dims,
     pressure_field,
     pressure_operand,
-    setup_reference_state,
+    set_reference_masso,
 )
 from .util import annual_average, default_coords, eos_func_from_str, validate_dataset
 
@@ -56,10 +57,12 @@ def _check_dz_inputs(levels, interfaces, depth):
     )
 
 
-def _global_branch(result, fields, reference, variant, dtype, tcoord, coords_for):
+def _global_branch(result, fields, reference, variant, dtype, tcoord, coords_for, deferred):
     """steric.py:134-147 -- masso(t) from K1, then the Boussinesq offline approximation."""
     T, S, vol0, p, eos = fields
     masso = engine.global_masso(T, S, vol0, p, eos=eos, f32_mode=_f32_mode()).cpu().numpy()
+    if deferred:  # the self-generated reference is time index 0 of this very record
+        set_reference_masso(reference, masso[0])
     reference_height, sealevel, _expansion_coeff = engine.global_finalize(
         masso,
         np.float64(reference["volo"].values),
@@ -146,10 +149,10 @@ def steric(
     )
     pres = pressure_field(dset, zcoord, patm)  # 1 m of depth ~ 1 dbar = 1e4 Pa, plus patm
 
+    deferred = reference is None and domain == "global"
     if reference is None:
-        reference = setup_reference_state(
-            dset, patm=patm, eos=equation_of_state, coord_names=coord_names
-        )
+        # domain="global": masso0 is masso(t=0) of the K1 launch below (same kernel, same bits)
+        reference = _setup(dset, patm, equation_of_state, coord_names, 0, defer_masso=deferred)
         if verbose:
             print("Generating reference state from first timestep")
     else:
@@ -180,7 +183,7 @@ def steric(
 
     result = Dataset()
     if domain == "global":
-        _global_branch(result, fields, reference, variant, dtype, tcoord, coords_for)
+        _global_branch(result, fields, reference, variant, dtype, tcoord, coords_for, deferred)
     else:
         _local_branch(result, fields, dset, reference, variant, dtype, rhozero, names, cdims3,
                       coords_for)
