@@ -1,0 +1,73 @@
+"""Run every hot kernel a few times on resident synthetic data -- the command profiled with
+rocprofv3 for the per-kernel evidence under profiles/ (K1 steric / thermosteric / halosteric,
+K2 with and without delta_rho, K0).
+
+    python scripts/profile_variants.py [--nt 40] [--reps 3]
+"""
+
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from momlevel_amd import core, synthetic  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nt", type=int, default=40)
+    ap.add_argument("--reps", type=int, default=3)
+    a = ap.parse_args()
+    nz, ny, nx = 75, 1080, 1440
+    nt = a.nt
+    g = synthetic.make_grid(ny, nx, nz)
+    vol0 = torch.from_numpy(g["volcello"]).cuda()
+    pres = torch.from_numpy(np.asarray(g["z_l"]) * 1.0e4 + 101325.0).cuda()
+    shape = (nt, nz, ny, nx)
+    kw = dict(seed=synthetic.SEED, mask3d=vol0)
+    T = core.synth_field(shape, field_id=1, lo=-2.0, scale=34.0, **kw)
+    S = core.synth_field(shape, field_id=2, lo=30.0, scale=10.0, **kw)
+    rho0 = core.eos_map(T[0], S[0], pres)
+    rho0m = core.fold_mask(rho0, vol0)
+    zi = torch.from_numpy(g["z_i"]).cuda()
+    dep = torch.from_numpy(g["deptho"]).cuda()
+    drho = torch.empty(shape, dtype=torch.float64, device="cuda")
+    eta = torch.empty((nt, ny, nx), dtype=torch.float64, device="cuda")
+    rho = drho  # K0 output buffer (same size)
+    cells = nt * nz * ny * nx
+    cases = [
+        ("K1 steric", 16, lambda: core.steric_global_masso(T, S, vol0, pres)),
+        ("K1 thermosteric", 8, lambda: core.steric_global_masso(T, S[0], vol0, pres)),
+        ("K1 halosteric", 8, lambda: core.steric_global_masso(T[0], S, vol0, pres)),
+        ("K2 local eta only", 16, lambda: core.steric_local(
+            T, S, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=zi, deptho=dep,
+            want_delta_rho=False, eta_out=eta)),
+        ("K2 local + delta_rho", 24, lambda: core.steric_local(
+            T, S, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=zi, deptho=dep,
+            delta_rho_out=drho, eta_out=eta)),
+    ]
+    for name, bpc, fn in cases:
+        fn()
+        torch.cuda.synchronize()
+        ms = []
+        for _ in range(a.reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        m = float(np.mean(ms))
+        print(json.dumps({"kernel": name, "cells_per_launch": cells, "algorithmic_bytes_per_cell": bpc,
+                          "mean_ms": round(m, 3), "Mcells/s": round(cells / m / 1e3, 1),
+                          "GB/s": round(bpc * cells / m / 1e6, 1),
+                          "frac_of_8TBs": round(bpc * cells / m / 1e6 / 8000.0, 4)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
