@@ -111,9 +111,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 //
 // grid = (ceil(plane / (kBlock*VEC*U)), nz, ceil(nt/t_chunk)); each thread owns U packs of
 // VEC adjacent cells of ONE z level, keeps their vol0 (and p, if FULL3D) in registers and
-// loops over the time steps of its chunk.  Per time step it parks its partial in LDS row t%kNTC; every kNTC steps the block
-// reduces the parked rows (fixed order) and writes partials[t][block].  A second kernel
-// (k_reduce_rows) sums partials[t][:] in a fixed order -> masso[t].
+// loops over the time steps of its chunk.  Per time step it parks its partial in LDS row
+// (t - chunk start) % kNTC; every kNTC steps the block reduces the parked rows (fixed order) and
+// writes partials[t][block].  A second kernel (k_reduce_rows) sums partials[t][:] in a fixed
+// order -> masso[t].
 //
 // HOLD: 0 = both fields stream, 1 = T is time-invariant (halosteric), 2 = S is
 // (thermosteric); the held field is loaded once.  GENERIC (VEC==1 instantiation)
