@@ -182,7 +182,9 @@ def main():
         """One pass of the hot path over the resident batch (what momlevel.steric(global) does)."""
         _rho0, volo, _ = engine.reference_state(T[0], S[0], vol0, pres, with_masso=False)
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        masso = engine.global_masso(T, S, vol0, pres, events=ev)
+        # skip_dry=False: the headline loads every cell, wet or dry, as the metric defines a cell
+        # (BASELINE.md section 2); the product default skips dry lines (see "land_skipping" below)
+        masso = engine.global_masso(T, S, vol0, pres, events=ev, skip_dry=False)
         masso0 = masso[0]  # reference slab = step 0 of the record (as steric() does)
         asum = core.nansum(area)
         red = parallel.exchange_global(masso, volo, masso0, asum)
@@ -304,21 +306,31 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
     nt, nz, ny, nx = T.shape
     cells = nt * nz * ny * nx
     out = {}
-    ms = _time(lambda: core.steric_global_masso(T, S[0], vol0, pres))
+    ms = _time(lambda: core.steric_global_masso(T, S[0], vol0, pres, skip_dry=False))
     out["thermosteric_global"] = {"Mcells/s": round(cells / ms / 1e3, 1),
                                   "GB/s_at_8B_per_cell": round(8 * cells / ms / 1e6, 1)}
-    ms = _time(lambda: core.steric_global_masso(T[0], S, vol0, pres))
+    ms = _time(lambda: core.steric_global_masso(T[0], S, vol0, pres, skip_dry=False))
     out["halosteric_global"] = {"Mcells/s": round(cells / ms / 1e3, 1),
                                 "GB/s_at_8B_per_cell": round(8 * cells / ms / 1e6, 1)}
+    # the product default (MLX_FLAG_SKIP_DRY): theta/S of all-dry 16-byte packs are never loaded;
+    # bit-identical results, fewer HBM bytes than the 16 B/cell the metric counts
+    ms = _time(lambda: core.steric_global_masso(T, S, vol0, pres, skip_dry=True))
+    dry = float(torch.isnan(vol0).double().mean().item())
+    out["land_skipping"] = {
+        "steric_global_Mcells/s": round(cells / ms / 1e3, 1),
+        "dry_cell_fraction": round(dry, 4),
+        "note": "same outputs bit for bit; not the headline: the metric counts dry cells as loaded",
+    }
     rho0m = core.fold_mask(core.eos_map(T[0], S[0], pres), vol0)
     zi = torch.from_numpy(g["z_i"]).to(dev)
     dep = torch.from_numpy(g["deptho"]).to(dev)
     eta = torch.empty((nt, ny, nx), dtype=torch.float64, device=dev)
     ms = _time(lambda: core.steric_local(T, S, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=zi,
-                                         deptho=dep, want_delta_rho=False, eta_out=eta))
+                                         deptho=dep, want_delta_rho=False, eta_out=eta,
+                                         skip_dry=False))
     out["local_eta_only"] = {"Mcells/s": round(cells / ms / 1e3, 1),
                              "GB/s_at_16B_per_cell": round(16 * cells / ms / 1e6, 1)}
-    chunk = min(nt, 8)
+    chunk = min(nt, 16)
     free, _ = torch.cuda.mem_get_info(dev)
     if free > chunk * nz * ny * nx * 8 + (2 << 30):
         drho = torch.empty((chunk, nz, ny, nx), dtype=torch.float64, device=dev)
@@ -327,12 +339,21 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
             for t0 in range(0, nt - chunk + 1, chunk):
                 core.steric_local(T[t0:t0 + chunk], S[t0:t0 + chunk], rho0m, vol0[0], pres,
                                   -1.0 / 1035.0, z_i=zi, deptho=dep, delta_rho_out=drho,
-                                  eta_out=eta[t0:t0 + chunk])
+                                  eta_out=eta[t0:t0 + chunk], skip_dry=False)
 
         ms = _time(run, reps=2)
         done = (nt // chunk) * chunk * nz * ny * nx
         out["local_with_delta_rho"] = {"Mcells/s": round(done / ms / 1e3, 1),
                                        "GB/s_at_24B_per_cell": round(24 * done / ms / 1e6, 1)}
+
+        def run_skip():
+            for t0 in range(0, nt - chunk + 1, chunk):
+                core.steric_local(T[t0:t0 + chunk], S[t0:t0 + chunk], rho0m, vol0[0], pres,
+                                  -1.0 / 1035.0, z_i=zi, deptho=dep, delta_rho_out=drho,
+                                  eta_out=eta[t0:t0 + chunk], skip_dry=True)
+
+        ms = _time(run_skip, reps=2)
+        out["land_skipping"]["local_with_delta_rho_Mcells/s"] = round(done / ms / 1e3, 1)
     return out
 
 

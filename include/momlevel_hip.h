@@ -70,6 +70,13 @@ extern "C" {
                            in float32, the rest in float64        */
 #define MLX_DTYPE_F32_UPCAST 2 /* float32 storage, upcast to float64 before any math  */
 
+/* flags of the fused steric entry points */
+#define MLX_FLAG_SKIP_DRY 1 /* do not load theta/S where the reference volcello (K1) / rho0m (K2)
+                               is NaN: those cells contribute exactly nothing (a NaN product is
+                               skipped) resp. are NaN whatever theta/S hold, so the results are
+                               bit-identical while whole cache lines of land and sub-bottom cells
+                               never leave HBM.  0 = load every cell, wet or dry.               */
+
 int mlx_version(void);
 /* copies the calling thread's last error text into buf (NUL-terminated); returns its length */
 int mlx_last_error(char *buf, size_t n);
@@ -113,7 +120,7 @@ size_t mlx_steric_global_workspace_bytes(int64_t nt, int64_t nz, int64_t plane);
 int mlx_steric_global(const void *T, const void *S, int dtype,
                       const double *vol0, const double *p, int p_mode, int eos,
                       int64_t nt, int64_t nz, int64_t plane,
-                      int64_t t_stride_T, int64_t t_stride_S,
+                      int64_t t_stride_T, int64_t t_stride_S, int flags,
                       double *masso_out, void *workspace, size_t workspace_bytes,
                       void *stream);
 
@@ -138,7 +145,7 @@ int mlx_steric_local(const void *T, const void *S, int dtype,
                      const double *dz, const double *z_i, const double *deptho,
                      const double *p, int p_mode, int eos, double neg_inv_rhozero,
                      int64_t nt, int64_t nz, int64_t plane,
-                     int64_t t_stride_T, int64_t t_stride_S,
+                     int64_t t_stride_T, int64_t t_stride_S, int flags,
                      double *delta_rho_out, double *eta_out, void *stream);
 
 /* ---------------------------------------------------------------------------------

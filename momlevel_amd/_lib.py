@@ -17,6 +17,7 @@ EOS_WRIGHT, EOS_LINEAR = 0, 1
 FUNC_DENSITY, FUNC_DRHO_DTEMP, FUNC_DRHO_DSAL, FUNC_ALPHA, FUNC_BETA = 0, 1, 2, 3, 4
 P_SCALAR, P_ZPROF, P_FULL3D, P_FULL4D = 0, 1, 2, 3
 DTYPE_F64, DTYPE_F32, DTYPE_F32_UPCAST = 0, 1, 2
+FLAG_SKIP_DRY = 1
 
 EOS_IDS = {"wright": EOS_WRIGHT, "linear": EOS_LINEAR}
 FUNC_IDS = {
@@ -49,13 +50,14 @@ SIGNATURES = {
     "mlx_steric_global_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "mlx_steric_global": (
         _int,
-        [_vp, _vp, _int, _vp, _vp, _int, _int, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp],
+        [_vp, _vp, _int, _vp, _vp, _int, _int, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp, _sz,
+         _vp],
     ),
     "mlx_fold_mask": (_int, [_vp, _vp, _i64, _vp, _vp]),
     "mlx_steric_local": (
         _int,
         [_vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _dbl,
-         _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
+         _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp],
     ),
     "mlx_nansum_workspace_bytes": (_sz, [_i64]),
     "mlx_nansum": (_int, [_vp, _i64, _vp, _vp, _sz, _vp]),

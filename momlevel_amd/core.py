@@ -145,12 +145,24 @@ def inverse_barometer(T, S, p, gravity=9.8, eos="wright", f32_mode="faithful"):
     return out[0] if squeeze else out
 
 
-def steric_global_masso(T, S, vol0, p, eos="wright", f32_mode="faithful", events=None):
+def skip_dry_default():
+    """Land / sub-bottom skipping is exact, so it is on unless MOMLEVEL_AMD_SKIP_DRY=0."""
+    import os
+
+    return os.environ.get("MOMLEVEL_AMD_SKIP_DRY", "1") != "0"
+
+
+def steric_global_masso(T, S, vol0, p, eos="wright", f32_mode="faithful", events=None,
+                        skip_dry=None):
     """K1: masso[t] = sum_{z,y,x} rho(T,S,p) * vol0  (skipna) -> (nt,) float64.
 
     ``events=(start, end)``: two ``torch.cuda.Event(enable_timing=True)`` recorded on the
     launch stream immediately around the kernel launches (bench.py's per-launch timing).
+    ``skip_dry``: MLX_FLAG_SKIP_DRY (None = the default policy, on); results are bit-identical
+    either way.
     """
+    if skip_dry is None:
+        skip_dry = skip_dry_default()
     require_device()
     T, S, nt, nz, ny, nx, sT, sS, dt, _ = _pair(T, S, f32_mode)
     vol0 = _f64(vol0, T.device)
@@ -165,7 +177,8 @@ def steric_global_masso(T, S, vol0, p, eos="wright", f32_mode="faithful", events
         events[0].record()
     rc = lib.mlx_steric_global(
         _ptr(T), _ptr(S), dt, _ptr(vol0), _ptr(pt), p_mode, EOS_IDS[eos.lower()],
-        nt, nz, ny * nx, sT, sS, _ptr(out), _ptr(ws), nbytes, _stream(),
+        nt, nz, ny * nx, sT, sS, _lib.FLAG_SKIP_DRY if skip_dry else 0,
+        _ptr(out), _ptr(ws), nbytes, _stream(),
     )
     if events is not None:
         events[1].record()
@@ -186,9 +199,12 @@ def fold_mask(rho0, vol0):
 
 def steric_local(T, S, rho0m, vol0_surface, p, neg_inv_rhozero, dz=None, z_i=None,
                  deptho=None, eos="wright", f32_mode="faithful", want_delta_rho=True,
-                 delta_rho_out=None, eta_out=None):
-    """K2: (delta_rho (nt,nz,ny,nx) or None, eta (nt,ny,nx))."""
+                 delta_rho_out=None, eta_out=None, skip_dry=None):
+    """K2: (delta_rho (nt,nz,ny,nx) or None, eta (nt,ny,nx)).  ``skip_dry``: see
+    steric_global_masso."""
     require_device()
+    if skip_dry is None:
+        skip_dry = skip_dry_default()
     T, S, nt, nz, ny, nx, sT, sS, dt, _ = _pair(T, S, f32_mode)
     dev = T.device
     rho0m = _f64(rho0m, dev)
@@ -216,7 +232,8 @@ def steric_local(T, S, rho0m, vol0_surface, p, neg_inv_rhozero, dz=None, z_i=Non
     rc = _lib.load().mlx_steric_local(
         _ptr(T), _ptr(S), dt, _ptr(rho0m), _ptr(vol0_surface), _ptr(dz), _ptr(z_i),
         _ptr(deptho), _ptr(pt), p_mode, EOS_IDS[eos.lower()], float(neg_inv_rhozero),
-        nt, nz, ny * nx, sT, sS, _ptr(drho), _ptr(eta), _stream(),
+        nt, nz, ny * nx, sT, sS, _lib.FLAG_SKIP_DRY if skip_dry else 0,
+        _ptr(drho), _ptr(eta), _stream(),
     )
     _lib.check(rc, "mlx_steric_local")
     return drho, eta

@@ -119,8 +119,11 @@ __device__ __forceinline__ double wave_sum(double v) {
 // HOLD: 0 = both fields stream, 1 = T is time-invariant (halosteric), 2 = S is
 // (thermosteric); the held field is loaded once.  GENERIC (VEC==1 instantiation)
 // takes eos/p_mode at run time and honours any stride, incl. 0, by reloading.
+// SKIP (MLX_FLAG_SKIP_DRY): a pack whose vol0 is NaN in every cell contributes exactly 0
+// whatever theta/S hold (rho*NaN is skipped), so its lanes neither load nor compute; whole
+// 64/128-byte lines of land or sub-bottom cells then never leave HBM.  Same bits out.
 // ------------------------------------------------------------------------------------
-template <typename TIn, int VEC, int U, int HOLD, int MODE, bool GENERIC>
+template <typename TIn, int VEC, int U, int HOLD, int MODE, bool GENERIC, bool SKIP = false>
 __global__ __launch_bounds__(kBlock) void k_steric_global(
     const TIn* __restrict__ T, const TIn* __restrict__ S, const double* __restrict__ vol0,
     const double* __restrict__ p, int p_mode, int eos, int nt, int t_chunk, int64_t plane,
@@ -142,6 +145,7 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
   int64_t off[U];  // offset of pack u inside a (z,y,x) slab; clamped when past the plane
   double vol[U][VEC];
   double pc[U][VEC];
+  bool alive[U];   // SKIP: false when every cell of the pack is dry (always true otherwise)
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     int64_t i = tile0 + ((int64_t)u * kBlock + tid) * VEC;
@@ -149,8 +153,13 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
     i = valid ? i : 0;
     off[u] = zoff + i;
     Pack<double, VEC> v = load_pack<double, VEC>(vol0 + off[u]);
+    bool any_wet = false;
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) vol[u][k] = valid ? v.v[k] : canonical_nan();
+    for (int k = 0; k < VEC; ++k) {
+      vol[u][k] = valid ? v.v[k] : canonical_nan();
+      any_wet = any_wet || !is_nan(vol[u][k]);
+    }
+    alive[u] = !SKIP || any_wet;
     if (GENERIC && p_mode == MLX_P_FULL3D) {
       Pack<double, VEC> q = load_pack<double, VEC>(p + off[u]);
 #pragma unroll
@@ -169,7 +178,8 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
   if constexpr (HOLD == 2) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const Pack<TIn, VEC> s0 = load_pack<TIn, VEC, true>(S + off[u]);
+      Pack<TIn, VEC> s0 = {};
+      if (alive[u]) s0 = load_pack<TIn, VEC, true>(S + off[u]);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) hs[u][k] = hold_S<R>((R)s0.v[k]);
     }
@@ -177,7 +187,8 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
   if constexpr (HOLD == 1) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const Pack<TIn, VEC> t0 = load_pack<TIn, VEC, true>(T + off[u]);
+      Pack<TIn, VEC> t0 = {};
+      if (alive[u]) t0 = load_pack<TIn, VEC, true>(T + off[u]);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) ht[u][k] = hold_T<R>((R)t0.v[k]);
     }
@@ -186,8 +197,12 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
   Pack<TIn, VEC> curT[U], curS[U], nxtT[U], nxtS[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    if (HOLD != 1) nxtT[u] = load_pack<TIn, VEC, true>(T + (int64_t)tb * t_stride_T + off[u]);
-    if (HOLD != 2) nxtS[u] = load_pack<TIn, VEC, true>(S + (int64_t)tb * t_stride_S + off[u]);
+    nxtT[u] = {};
+    nxtS[u] = {};
+    if (alive[u]) {
+      if (HOLD != 1) nxtT[u] = load_pack<TIn, VEC, true>(T + (int64_t)tb * t_stride_T + off[u]);
+      if (HOLD != 2) nxtS[u] = load_pack<TIn, VEC, true>(S + (int64_t)tb * t_stride_S + off[u]);
+    }
   }
 
   for (int t = tb; t < te; ++t) {
@@ -199,15 +214,18 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
     if (t + 1 < te) {  // issue the next step's loads before this step's arithmetic
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (HOLD != 1)
-          nxtT[u] = load_pack<TIn, VEC, true>(T + (int64_t)(t + 1) * t_stride_T + off[u]);
-        if (HOLD != 2)
-          nxtS[u] = load_pack<TIn, VEC, true>(S + (int64_t)(t + 1) * t_stride_S + off[u]);
+        if (alive[u]) {
+          if (HOLD != 1)
+            nxtT[u] = load_pack<TIn, VEC, true>(T + (int64_t)(t + 1) * t_stride_T + off[u]);
+          if (HOLD != 2)
+            nxtS[u] = load_pack<TIn, VEC, true>(S + (int64_t)(t + 1) * t_stride_S + off[u]);
+        }
       }
     }
     double c = 0.0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      if (SKIP && !alive[u]) continue;  // adds exactly nothing: c + 0.0 == c
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         double rho;
@@ -379,7 +397,7 @@ __device__ __forceinline__ double dz_default(double depth, double ztop, double z
 // (scripts/tune_k2.hip) than NTI=8 at 4 waves/SIMD: half the rho0m re-reads and twice the
 // bytes in flight per wave.  theta/S loads and the delta_rho stores use the nt policy.
 // ------------------------------------------------------------------------------------
-template <typename TIn, int VEC, int NTI, int HOLD, int MODE, bool GENERIC>
+template <typename TIn, int VEC, int NTI, int HOLD, int MODE, bool GENERIC, bool SKIP = false>
 __global__ __launch_bounds__(kBlock) void k_steric_local(
     const TIn* __restrict__ T, const TIn* __restrict__ S, const double* __restrict__ rho0m,
     const double* __restrict__ vol0_surface, const double* __restrict__ dz,
@@ -403,9 +421,13 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
   double pz = 0.0;
   if (GENERIC && p_mode == MLX_P_SCALAR) pz = p[0];
 
+  // rho0m of level z+1 is fetched while level z is processed, so that the dry test (SKIP) and the
+  // theta/S loads of a level never wait for a dependent load
+  Pack<double, VEC> r0n = load_pack<double, VEC>(rho0m + col);
   for (int z = 0; z < nz; ++z) {
     const int64_t off = (int64_t)z * plane + col;
-    const Pack<double, VEC> r0 = load_pack<double, VEC>(rho0m + off);
+    const Pack<double, VEC> r0 = r0n;
+    if (z + 1 < nz) r0n = load_pack<double, VEC>(rho0m + off + plane);
     Pack<double, VEC> dzv;
     if (dz != nullptr) {
       dzv = load_pack<double, VEC>(dz + off);
@@ -418,14 +440,27 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
     Pack<double, VEC> pfull;
     if (GENERIC && p_mode == MLX_P_FULL3D) pfull = load_pack<double, VEC>(p + off);
 
-    Pack<TIn, VEC> hT, hS;
-    if (HOLD == 1) hT = load_pack<TIn, VEC>(T + off);
-    if (HOLD == 2) hS = load_pack<TIn, VEC>(S + off);
+    // SKIP (MLX_FLAG_SKIP_DRY): where rho0m is NaN in every cell of the pack, delta_rho is NaN and
+    // the column sum unchanged whatever theta/S hold -> their loads are masked off, same bits
+    bool alive = true;
+    if constexpr (SKIP) {
+      alive = false;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) alive = alive || !is_nan(r0.v[k]);
+    }
+
+    Pack<TIn, VEC> hT = {}, hS = {};
+    if (alive) {
+      if (HOLD == 1) hT = load_pack<TIn, VEC>(T + off);
+      if (HOLD == 2) hS = load_pack<TIn, VEC>(S + off);
+    }
 
     Pack<TIn, VEC> a[NTI], b[NTI];
 #pragma unroll
     for (int j = 0; j < NTI; ++j) {
-      if (t0 + j < nt) {  // block-uniform: the ragged last chunk issues no surplus loads
+      a[j] = {};
+      b[j] = {};
+      if (alive && t0 + j < nt) {  // the ragged last chunk issues no surplus loads
         const int64_t t = t0 + j;
         if (HOLD != 1) a[j] = load_pack<TIn, VEC, true>(T + t * t_stride_T + off);
         if (HOLD != 2) b[j] = load_pack<TIn, VEC, true>(S + t * t_stride_S + off);
@@ -435,6 +470,9 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
     for (int j = 0; j < NTI; ++j) {
       if (t0 + j < nt) {
         Pack<double, VEC> d;
+        // dry lanes (SKIP) run the same arithmetic on zeros: rho - NaN is NaN and the NaN term is
+        // skipped, exactly as if theta/S had been loaded.  Only their LOADS are masked -- a
+        // divergent store path would split every partly-dry line into two transactions.
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
           const TIn tv = (HOLD == 1) ? hT.v[k] : a[j].v[k];
@@ -701,9 +739,11 @@ size_t mlx_steric_global_workspace_bytes(int64_t nt, int64_t nz, int64_t plane) 
 
 int mlx_steric_global(const void* T, const void* S, int dtype, const double* vol0, const double* p,
                       int p_mode, int eos, int64_t nt, int64_t nz, int64_t plane, int64_t sT,
-                      int64_t sS, double* masso_out, void* workspace, size_t workspace_bytes,
-                      void* stream) {
+                      int64_t sS, int flags, double* masso_out, void* workspace,
+                      size_t workspace_bytes, void* stream) {
   using namespace mlx;
+  if (flags & ~MLX_FLAG_SKIP_DRY) return fail(MLX_E_ENUM, "unknown flag bits");
+  const bool skip_dry = (flags & MLX_FLAG_SKIP_DRY) != 0;
   if (int rc = check_common(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS, false)) return rc;
   if (!vol0 || !masso_out) return fail(MLX_E_NULL, "vol0 and masso_out must not be NULL");
   if (!workspace) return fail(MLX_E_NULL, "workspace must not be NULL");
@@ -716,10 +756,15 @@ int mlx_steric_global(const void* T, const void* S, int dtype, const double* vol
   dim3 grid((unsigned)pl.grid_x, (unsigned)nz, (unsigned)ceil_div(nt, kTChunk));
   const double* pp = p ? p : vol0;
   const int hold = (sT == 0) ? 1 : ((sS == 0) ? 2 : 0);
-#define MLX_LAUNCH_K1(TIN, VEC, U, HOLD, MODE, GEN)                                              \
-  hipLaunchKernelGGL((k_steric_global<TIN, VEC, U, HOLD, MODE, GEN>), grid, dim3(kBlock), 0, st, \
-                     (const TIN*)T, (const TIN*)S, vol0, pp, p_mode, eos, (int)nt, kTChunk, plane, \
-                     sT, sS, partials, pl.nblk_total)
+#define MLX_LAUNCH_K1S(TIN, VEC, U, HOLD, MODE, GEN, SKIP)                                        \
+  hipLaunchKernelGGL((k_steric_global<TIN, VEC, U, HOLD, MODE, GEN, SKIP>), grid, dim3(kBlock), 0, \
+                     st, (const TIN*)T, (const TIN*)S, vol0, pp, p_mode, eos, (int)nt, kTChunk,    \
+                     plane, sT, sS, partials, pl.nblk_total)
+#define MLX_LAUNCH_K1(TIN, VEC, U, HOLD, MODE, GEN)                 \
+  do {                                                              \
+    if (!GEN && skip_dry) MLX_LAUNCH_K1S(TIN, VEC, U, HOLD, MODE, GEN, (!GEN)); \
+    else MLX_LAUNCH_K1S(TIN, VEC, U, HOLD, MODE, GEN, false);       \
+  } while (0)
   if (pl.fast) {
     if (dtype == MLX_DTYPE_F64) {
       if (hold == 0) MLX_LAUNCH_K1(double, kVec64, kU64, 0, kF64, false);
@@ -740,6 +785,7 @@ int mlx_steric_global(const void* T, const void* S, int dtype, const double* vol
     else MLX_LAUNCH_K1(float, 1, kUGen, 0, kF32Upcast, true);
   }
 #undef MLX_LAUNCH_K1
+#undef MLX_LAUNCH_K1S
   if (int rc = hip_status(hipGetLastError(), "k_steric_global launch")) return rc;
   hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)nt), dim3(kBlock), 0, st, partials,
                      pl.nblk_total, masso_out);
@@ -761,8 +807,10 @@ int mlx_steric_local(const void* T, const void* S, int dtype, const double* rho0
                      const double* vol0_surface, const double* dz, const double* z_i,
                      const double* deptho, const double* p, int p_mode, int eos,
                      double neg_inv_rhozero, int64_t nt, int64_t nz, int64_t plane, int64_t sT,
-                     int64_t sS, double* delta_rho_out, double* eta_out, void* stream) {
+                     int64_t sS, int flags, double* delta_rho_out, double* eta_out, void* stream) {
   using namespace mlx;
+  if (flags & ~MLX_FLAG_SKIP_DRY) return fail(MLX_E_ENUM, "unknown flag bits");
+  const bool skip_dry = (flags & MLX_FLAG_SKIP_DRY) != 0;
   if (int rc = check_common(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS, false)) return rc;
   if (!rho0m || !vol0_surface || !eta_out)
     return fail(MLX_E_NULL, "rho0m, vol0_surface and eta_out must not be NULL");
@@ -783,11 +831,16 @@ int mlx_steric_local(const void* T, const void* S, int dtype, const double* rho0
   const int v = fast ? vec : 1;
   const int nti = fast ? (f64 ? kNTI64 : kNTI32) : kNTIGen;
   dim3 grid((unsigned)ceil_div(plane, (int64_t)kBlock * v), (unsigned)ceil_div(nt, nti));
-#define MLX_LAUNCH_K2(TIN, VEC, NTI, HOLD, MODE, GEN)                                            \
-  hipLaunchKernelGGL((k_steric_local<TIN, VEC, NTI, HOLD, MODE, GEN>), grid, dim3(kBlock), 0,    \
-                     st, (const TIN*)T, (const TIN*)S, rho0m, vol0_surface, dz, z_i, deptho, pp, \
-                     p_mode, eos, neg_inv_rhozero, (int)nt, (int)nz, plane, sT, sS,              \
+#define MLX_LAUNCH_K2S(TIN, VEC, NTI, HOLD, MODE, GEN, SKIP)                                      \
+  hipLaunchKernelGGL((k_steric_local<TIN, VEC, NTI, HOLD, MODE, GEN, SKIP>), grid, dim3(kBlock),  \
+                     0, st, (const TIN*)T, (const TIN*)S, rho0m, vol0_surface, dz, z_i, deptho,  \
+                     pp, p_mode, eos, neg_inv_rhozero, (int)nt, (int)nz, plane, sT, sS,          \
                      delta_rho_out, eta_out)
+#define MLX_LAUNCH_K2(TIN, VEC, NTI, HOLD, MODE, GEN)                               \
+  do {                                                                              \
+    if (!GEN && skip_dry) MLX_LAUNCH_K2S(TIN, VEC, NTI, HOLD, MODE, GEN, (!GEN));   \
+    else MLX_LAUNCH_K2S(TIN, VEC, NTI, HOLD, MODE, GEN, false);                     \
+  } while (0)
   if (fast) {
     if (f64) {
       if (hold == 0) MLX_LAUNCH_K2(double, kVec64, kNTI64, 0, kF64, false);
@@ -808,6 +861,7 @@ int mlx_steric_local(const void* T, const void* S, int dtype, const double* rho0
     else MLX_LAUNCH_K2(float, 1, kNTIGen, 0, kF32Upcast, true);
   }
 #undef MLX_LAUNCH_K2
+#undef MLX_LAUNCH_K2S
   return hip_status(hipGetLastError(), "k_steric_local launch");
 }
 

@@ -157,7 +157,7 @@ def reference_state(T0, S0, vol0, pres, eos="wright", f32_mode="faithful", with_
 # global variant (src/momlevel/steric.py:134-147)
 # ---------------------------------------------------------------------------------------
 def global_masso(T, S, vol0, pres, eos="wright", f32_mode="faithful", steps=None,
-                 events=None):
+                 events=None, skip_dry=None):
     """masso(t) for every time step of (T, S) -> (nt,) float64 device tensor.
 
     Device-resident fields are processed by ONE K1 launch over all time steps; host
@@ -170,10 +170,11 @@ def global_masso(T, S, vol0, pres, eos="wright", f32_mode="faithful", steps=None
     if chunks.steps >= chunks.nt:
         for _t0, _t1, Tc, Sc in chunks:
             return core.steric_global_masso(Tc, Sc, vol0, pres, eos=eos, f32_mode=f32_mode,
-                                            events=events)
+                                            events=events, skip_dry=skip_dry)
     out = torch.empty(chunks.nt, dtype=torch.float64, device=dev)
     for t0, t1, Tc, Sc in chunks:
-        out[t0:t1] = core.steric_global_masso(Tc, Sc, vol0, pres, eos=eos, f32_mode=f32_mode)
+        out[t0:t1] = core.steric_global_masso(Tc, Sc, vol0, pres, eos=eos, f32_mode=f32_mode,
+                                              skip_dry=skip_dry)
     return out
 
 

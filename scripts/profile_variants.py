@@ -41,15 +41,20 @@ def main():
     rho = drho  # K0 output buffer (same size)
     cells = nt * nz * ny * nx
     cases = [
-        ("K1 steric", 16, lambda: core.steric_global_masso(T, S, vol0, pres)),
-        ("K1 thermosteric", 8, lambda: core.steric_global_masso(T, S[0], vol0, pres)),
-        ("K1 halosteric", 8, lambda: core.steric_global_masso(T[0], S, vol0, pres)),
+        ("K1 steric", 16, lambda: core.steric_global_masso(T, S, vol0, pres, skip_dry=False)),
+        ("K1 thermosteric", 8, lambda: core.steric_global_masso(T, S[0], vol0, pres, skip_dry=False)),
+        ("K1 halosteric", 8, lambda: core.steric_global_masso(T[0], S, vol0, pres, skip_dry=False)),
         ("K2 local eta only", 16, lambda: core.steric_local(
             T, S, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=zi, deptho=dep,
-            want_delta_rho=False, eta_out=eta)),
+            want_delta_rho=False, eta_out=eta, skip_dry=False)),
         ("K2 local + delta_rho", 24, lambda: core.steric_local(
             T, S, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=zi, deptho=dep,
-            delta_rho_out=drho, eta_out=eta)),
+            delta_rho_out=drho, eta_out=eta, skip_dry=False)),
+        ("K1 steric, dry lines skipped", 16,
+         lambda: core.steric_global_masso(T, S, vol0, pres, skip_dry=True)),
+        ("K2 local + delta_rho, dry lines skipped", 24, lambda: core.steric_local(
+            T, S, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=zi, deptho=dep,
+            delta_rho_out=drho, eta_out=eta, skip_dry=True)),
     ]
     for name, bpc, fn in cases:
         fn()

@@ -53,7 +53,7 @@ def test_enum_values_match_header():
 def test_argument_errors_need_no_gpu():
     """Argument validation happens before any HIP call, so it is testable here."""
     lib = _lib.load()
-    rc = lib.mlx_steric_global(None, None, 0, None, None, 1, 0, 1, 1, 1, 0, 0, None, None, 0, None)
+    rc = lib.mlx_steric_global(None, None, 0, None, None, 1, 0, 1, 1, 1, 0, 0, 0, None, None, 0, None)
     assert rc == -1  # MLX_E_NULL
     assert "NULL" in _lib.last_error()
     assert lib.mlx_nansum(None, 0, None, None, 0, None) == -1

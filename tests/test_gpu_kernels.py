@@ -112,7 +112,7 @@ def test_abi_error_codes():
     lib = _lib.load()
     ws = torch.empty(1, dtype=torch.float64, device="cuda")
     rc = lib.mlx_steric_global(T.data_ptr(), S.data_ptr(), 0, vol0.data_ptr(), vol0.data_ptr(), 1,
-                               0, 2, 3, 32, 96, 96, ws.data_ptr(), ws.data_ptr(), 8, None)
+                               0, 2, 3, 32, 96, 96, 0, ws.data_ptr(), ws.data_ptr(), 8, None)
     assert rc == -4 and "workspace" in _lib.last_error()
     with pytest.raises(TypeError):
         core.steric_global_masso(T.cpu(), S, vol0, pres)
@@ -222,3 +222,34 @@ def test_single_process_tile_pipeline_matches_labelled_api():
     assert_rel(out["masso"], ref["masso"], 1e-10)
     assert_rel(out["reference_height"], ref["reference_height"], 1e-10)
     assert np.allclose(out["expansion_coeff"], ref["expansion_coeff"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_skip_dry_is_bit_identical(dtype):
+    """MLX_FLAG_SKIP_DRY only removes loads of cells that contribute exactly nothing."""
+    g, vol0, T, S, pres = make_case(20, 12, 64, 96, dtype)
+    # inconsistent masks on purpose: finite theta/S under NaN vol0 and NaN theta over wet cells
+    T = T.clone()
+    T[:, 0, :4, :8] = 3.0
+    T[3, 5, 10:20, 30:50] = float("nan")
+    for Tv, Sv in ((T, S), (T, S[0]), (T[0], S)):
+        dense = core.steric_global_masso(Tv, Sv, vol0, pres, skip_dry=False)
+        sparse = core.steric_global_masso(Tv, Sv, vol0, pres, skip_dry=True)
+        assert torch.equal(dense, sparse)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_skip_dry_local_is_bit_identical(dtype):
+    g, vol0, T, S, pres = make_case(19, 12, 64, 96, dtype)
+    T = T.clone()
+    T[:, 0, :4, :8] = 3.0  # finite theta under NaN vol0
+    rho0m = core.fold_mask(core.eos_map(T[0], S[0], pres), vol0)
+    for Tv, Sv in ((T, S), (T, S[0]), (T[0], S)):
+        outs = []
+        for skip in (False, True):
+            d, e = core.steric_local(Tv, Sv, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=g["z_i"],
+                                     deptho=g["deptho"], skip_dry=skip)
+            outs.append((d.cpu().numpy(), e.cpu().numpy()))
+        assert_bit_equal(outs[1][0], outs[0][0], "delta_rho")
+        assert_bit_equal(outs[1][1], outs[0][1], "eta")
+        assert np.array_equal(outs[1][0].view(np.int64), outs[0][0].view(np.int64))  # NaN payloads too
