@@ -260,7 +260,7 @@ def main():
                 "hbm_resident_gb": round(2 * cells_rank * 8 / 1e9, 1),
             },
             "roofline": {
-                "kernel": "k_steric_global<double,2,4,0,0,false>",
+                "kernel": "k_steric_global<double,2,4,0,0,false,false>",
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
