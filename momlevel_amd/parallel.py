@@ -125,3 +125,26 @@ def steric_global_tile(T, S, vol0, areacello, pres, variant="steric", eos="wrigh
         if not abs(err) < 0.02:
             raise ValueError("Errors found in dataset.")
     return out
+
+
+def steric_local_tile(T, S, vol0, pres, z_i, deptho, rhozero=1035.0, variant="steric",
+                      eos="wright", f32_mode="faithful", want_delta_rho=True):
+    """Local steric of a horizontally tiled grid: columns are independent, so a rank simply runs
+    the fused K2 pass on its own (nt,nz,ny_t,nx_t) tile -- NO collective on this path (SURVEY.md
+    8e); gathering the (time,yh,xh) tiles, if wanted at all, is an output step of the caller.
+
+    Returns (delta_rho or None, eta) for the tile; the reference state is time index 0.
+    """
+    from . import core
+
+    if variant == "thermosteric":
+        Tv, Sv = T, S[0]
+    elif variant == "halosteric":
+        Tv, Sv = T[0], S
+    elif variant == "steric":
+        Tv, Sv = T, S
+    else:
+        raise ValueError(f"Unknown variant '{variant}' passed to `steric`")
+    rho0 = core.eos_map(T[0], S[0], pres, eos=eos, f32_mode=f32_mode)
+    return engine.local_steric(Tv, Sv, rho0, vol0, pres, rhozero, z_i=z_i, deptho=deptho, eos=eos,
+                               f32_mode=f32_mode, want_delta_rho=want_delta_rho, out_host=False)

@@ -400,8 +400,11 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
 
   std::vector<Variant> vs = {
+      {"nt xcd1 B256 U4 zchunk 24     ", launch_z<256, 4, 1, 1, 24>},
       {"nt xcd1 B256 U4 zchunk 32     ", launch_z<256, 4, 1, 1, 32>},
-      {"nt xcd1 B256 U8 zchunk 32     ", launch_z<256, 8, 1, 1, 32>},
+      {"nt xcd1 B256 U4 zchunk 40     ", launch_z<256, 4, 1, 1, 40>},
+      {"nt xcd1 B256 U4 zchunk 48     ", launch_z<256, 4, 1, 1, 48>},
+      {"nt xcd1 B256 U4 zchunk 64     ", launch_z<256, 4, 1, 1, 64>},
       {"nt xcd1 B256 U4 one launch    ", launch<256, 4, 1, 1, 0, 1>},
   };
   printf("T=%p S=%p spad=%lld\n", (void*)T, (void*)S, (long long)spad);

@@ -253,3 +253,20 @@ def test_skip_dry_local_is_bit_identical(dtype):
         assert_bit_equal(outs[1][0], outs[0][0], "delta_rho")
         assert_bit_equal(outs[1][1], outs[0][1], "eta")
         assert np.array_equal(outs[1][0].view(np.int64), outs[0][0].view(np.int64))  # NaN payloads too
+
+
+def test_local_tiles_need_no_exchange():
+    """parallel.steric_local_tile on the 2x4 tiles of a grid == the whole grid, bit for bit."""
+    nt, nz, ny, nx = 5, 9, 32, 64
+    g, vol0, T, S, pres = make_case(nt, nz, ny, nx)
+    zi, dep = g["z_i"], torch.from_numpy(g["deptho"]).cuda()
+    for variant in ("steric", "thermosteric", "halosteric"):
+        dfull, efull = parallel.steric_local_tile(T, S, vol0, pres, zi, dep, variant=variant)
+        for rank in range(8):
+            y0, y1, x0, x1 = synthetic.tile_bounds(ny, nx, rank, 8)
+            d, e = parallel.steric_local_tile(
+                T[:, :, y0:y1, x0:x1].contiguous(), S[:, :, y0:y1, x0:x1].contiguous(),
+                vol0[:, y0:y1, x0:x1].contiguous(), pres, zi, dep[y0:y1, x0:x1].contiguous(),
+                variant=variant)
+            assert_bit_equal(d.cpu().numpy(), dfull[:, :, y0:y1, x0:x1].cpu().numpy(), "delta_rho tile")
+            assert_bit_equal(e.cpu().numpy(), efull[:, y0:y1, x0:x1].cpu().numpy(), "eta tile")
