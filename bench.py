@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target seconds of CPU-baseline work (0 disables it)")
     ap.add_argument("--no-extras", action="store_true", help="skip the local-variant timings")
+    ap.add_argument("--input-dtype", choices=["f64", "f32"], default="f64",
+                    help="storage type of theta/S (f32 = BASELINE.json configs[4]; the headline is f64)")
     return ap.parse_args()
 
 
@@ -72,12 +74,12 @@ def measured_traffic(cells_per_launch):
     return None, None
 
 
-def fit_nt(nt, nz, ny, nx, device):
+def fit_nt(nt, nz, ny, nx, device, itemsize=8):
     """Largest nt <= requested whose theta+S fit in free HBM with ~14 GB of headroom."""
     free, _ = torch.cuda.mem_get_info(device)
     n3 = nz * ny * nx
     headroom = 14 * (1 << 30) + 6 * n3 * 8
-    cap = int((free - headroom) // (2 * n3 * 8))
+    cap = int((free - headroom) // (2 * n3 * itemsize))
     return max(1, min(nt, cap))
 
 
@@ -161,7 +163,10 @@ def main():
     th, tw = tile[1] - tile[0], tile[3] - tile[2]
     g = synthetic.make_grid(ny, nx, nz, tile=tile)
     nt_req = a.nt * world
-    nt = fit_nt(nt_req, nz, th, tw, dev)
+    f32 = a.input_dtype == "f32"
+    tdtype = torch.float32 if f32 else torch.float64
+    bytes_per_cell = BYTES_PER_CELL // 2 if f32 else BYTES_PER_CELL
+    nt = fit_nt(nt_req, nz, th, tw, dev, itemsize=4 if f32 else 8)
     if world > 1:  # every rank must run the same number of steps
         nt = int(allreduce_scalar(nt, dist.ReduceOp.MIN, torch.int64))
 
@@ -170,9 +175,9 @@ def main():
     pres = torch.from_numpy(np.asarray(g["z_l"]) * 1.0e4 + 101325.0).to(dev)
     shape = (nt, nz, th, tw)
     kw = dict(seed=synthetic.SEED, mask3d=vol0, global_hw=(ny, nx), origin=g["origin"], device=dev)
-    T = core.synth_field(shape, torch.float64, field_id=synthetic.FIELD_THETAO,
+    T = core.synth_field(shape, tdtype, field_id=synthetic.FIELD_THETAO,
                          lo=synthetic.THETA_LO, scale=synthetic.THETA_SCALE, **kw)
-    S = core.synth_field(shape, torch.float64, field_id=synthetic.FIELD_SO,
+    S = core.synth_field(shape, tdtype, field_id=synthetic.FIELD_SO,
                          lo=synthetic.SO_LO, scale=synthetic.SO_SCALE, **kw)
     torch.cuda.synchronize(dev)
 
@@ -213,18 +218,19 @@ def main():
     cells_rank = nt * nz * th * tw
     cells_job = cells_rank * world
     k1_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in launch_ms]))
-    achieved = BYTES_PER_CELL * cells_rank / (k1_ms * 1e-3) / 1e9
+    achieved = bytes_per_cell * cells_rank / (k1_ms * 1e-3) / 1e9
 
-    traffic, traffic_src = measured_traffic(cells_rank)
+    traffic, traffic_src = (None, None) if f32 else measured_traffic(cells_rank)
 
     extras = {}
-    if not a.no_extras and world == 1:
+    if not a.no_extras and world == 1 and not f32:
         extras = local_variant_timings(T, S, vol0, pres, g, dev)
 
     cpu, parity, cpu_fused = None, None, None
     if world == 1 and a.cpu_seconds > 0:
         cpu, parity = cpu_baseline(T, S, g, pres.cpu().numpy(), a.cpu_seconds, out["masso"])
-        cpu_fused = cpu_baseline_fused(T, S, g, pres.cpu().numpy(), out["masso"])
+        if not f32:  # the C restatement is float64 only
+            cpu_fused = cpu_baseline_fused(T, S, g, pres.cpu().numpy(), out["masso"])
 
     if rank == 0:
         layout = {1: "1x1", 2: "1x2", 4: "2x2", 8: "2x4"}.get(world, f"1x{world}")
@@ -239,11 +245,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64" if not f32 else "f64 (float32 theta/S: polynomial in f32 as numpy does, rest f64)",
             "data": "synthetic",
             "config": {
                 "workload": (
-                    f"OM4 0.25deg synthetic grid {nx}x{ny}x{nz}, {nt} time steps, fp64, global "
+                    f"OM4 0.25deg synthetic grid {nx}x{ny}x{nz}, {nt} time steps, "
+                    f"{'fp32 theta/S (BASELINE.json configs[4])' if f32 else 'fp64'}, global "
                     "steric (BASELINE.json configs[2])" if world == 1 else
                     f"OM4 0.25deg synthetic grid {nx}x{ny}x{nz} tiled {layout} (yh x xh), {nt} time "
                     f"steps, fp64, global steric: every GPU holds all {nt} steps of its "
@@ -257,10 +264,12 @@ def main():
                 "variant": "steric",
                 "domain": "global",
                 "collective": "none" if world == 1 else f"1 all_reduce of {nt + 3} f64 per step",
-                "hbm_resident_gb": round(2 * cells_rank * 8 / 1e9, 1),
+                "input_dtype": a.input_dtype,
+                "hbm_resident_gb": round(2 * cells_rank * (4 if f32 else 8) / 1e9, 1),
             },
             "roofline": {
-                "kernel": "k_steric_global<double,2,4,0,0,false,false>",
+                "kernel": ("k_steric_global<float,4,2,0,1,false,false>" if f32
+                           else "k_steric_global<double,2,4,0,0,false,false>"),
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
@@ -270,8 +279,8 @@ def main():
                 "traffic_unit": "GB per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc)",
                 "traffic_source": traffic_src,
                 "launch_ms": round(k1_ms, 4),
-                "algorithmic_bytes_per_cell": BYTES_PER_CELL,
-                "algorithmic_gb_per_launch": round(BYTES_PER_CELL * cells_rank / 1e9, 2),
+                "algorithmic_bytes_per_cell": bytes_per_cell,
+                "algorithmic_gb_per_launch": round(bytes_per_cell * cells_rank / 1e9, 2),
                 "cells_per_launch": cells_rank,
                 "time_loop_steps_per_block": 32,
             },
