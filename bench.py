@@ -321,6 +321,11 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
     ms = _time(lambda: core.steric_global_masso(T[0], S, vol0, pres, skip_dry=False))
     out["halosteric_global"] = {"Mcells/s": round(cells / ms / 1e3, 1),
                                 "GB/s_at_8B_per_cell": round(8 * cells / ms / 1e6, 1)}
+    # calibration: this box's plain streaming-read rate through the same 16-byte nt loads
+    # (skipna sum of the theta record) -- the practical ceiling K1's 16 B/cell runs against
+    ms = _time(lambda: core.nansum(T))
+    out["stream_read_probe"] = {"GB/s": round(8 * cells / ms / 1e6, 1),
+                                "note": "mlx_nansum over theta (one 112 GB stream, nt loads)"}
     # the product default (MLX_FLAG_SKIP_DRY): theta/S of all-dry 16-byte packs are never loaded;
     # bit-identical results, fewer HBM bytes than the 16 B/cell the metric counts
     ms = _time(lambda: core.steric_global_masso(T, S, vol0, pres, skip_dry=True))
