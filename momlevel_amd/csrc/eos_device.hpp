@@ -177,6 +177,40 @@ __device__ __forceinline__ double wright_drho_dsal(double T, double S, double p)
   return I2 * (lam * (K::B4 + K::B5 * T) - pp0 * (pp0 * K::A2 + (K::C4 + K::C5 * T)));
 }
 
+// ---- float32 theta/S, numpy's mixed precision (MODE kF32Faithful) for the derivatives ---------
+// With float32 arrays and python-float constants numpy keeps every sub-expression that involves
+// only T, S and constants in float32, and promotes to float64 wherever the float64 pressure
+// enters.  Written out operator by operator for eos/wright.py:74-83 and :108-117:
+__device__ __forceinline__ double wright_drho_dtemp_f32(float T, float S, double p) {
+  using K = WrightC<float>;
+  float al0, p0, lam;
+  wright_terms<float>(T, S, al0, p0, lam);
+  const double pp0 = p + (double)p0;
+  double I2 = 1.0 / ((double)lam + (double)al0 * pp0);
+  I2 = I2 * I2;
+  // lam * (B1 + T*(2.0*B2 + 3.0*B3*T) + B5*S): float32 throughout (2.0*B2 and 3.0*B3 are python
+  // floats folded in float64 first, then rounded to float32 when they meet the array)
+  const float two_b2 = (float)(2.0 * WrightC<double>::B2), three_b3 = (float)(3.0 * WrightC<double>::B3);
+  const float two_c2 = (float)(WrightC<double>::C2 * 2.0), three_c3 = (float)(WrightC<double>::C3 * 3.0);
+  const float a = lam * ((K::B1 + T * (two_b2 + three_b3 * T)) + K::B5 * S);
+  const float cpoly = (K::C1 + T * (two_c2 + three_c3 * T)) + K::C5 * S;
+  const double b = pp0 * (pp0 * WrightC<double>::A1 + (double)cpoly);
+  return I2 * ((double)a - b);
+}
+
+__device__ __forceinline__ double wright_drho_dsal_f32(float T, float S, double p) {
+  using K = WrightC<float>;
+  float al0, p0, lam;
+  wright_terms<float>(T, S, al0, p0, lam);
+  const double pp0 = p + (double)p0;
+  double I2 = 1.0 / ((double)lam + (double)al0 * pp0);
+  I2 = I2 * I2;
+  const float a = lam * (K::B4 + K::B5 * T);
+  const float c = K::C4 + K::C5 * T;
+  const double b = pp0 * (pp0 * WrightC<double>::A2 + (double)c);
+  return I2 * ((double)a - b);
+}
+
 // eos/linear.py:55-56 with rho_ref=None: 1000 + ((-0.2*T) + (0.8*S))
 template <int MODE, typename TIn>
 __device__ __forceinline__ double linear_density(TIn Tin, TIn Sin) {
@@ -206,15 +240,23 @@ __device__ __forceinline__ double eos_eval(int eos, int func, TIn T, TIn S, doub
     case kDensity:
       return wright_density<MODE, TIn>(T, S, p);
     case kDrhoDtemp:
-      return wright_drho_dtemp((double)T, (double)S, p);
+      if constexpr (MODE == kF32Faithful) return wright_drho_dtemp_f32(T, S, p);
+      else return wright_drho_dtemp((double)T, (double)S, p);
     case kDrhoDsal:
-      return wright_drho_dsal((double)T, (double)S, p);
+      if constexpr (MODE == kF32Faithful) return wright_drho_dsal_f32(T, S, p);
+      else return wright_drho_dsal((double)T, (double)S, p);
     case kAlpha:  // eos/wright.py:142
-      return -1.0 * (wright_drho_dtemp((double)T, (double)S, p) /
-                     wright_density<kF64, double>((double)T, (double)S, p));
+      if constexpr (MODE == kF32Faithful)
+        return -1.0 * (wright_drho_dtemp_f32(T, S, p) / wright_density<MODE, TIn>(T, S, p));
+      else
+        return -1.0 * (wright_drho_dtemp((double)T, (double)S, p) /
+                       wright_density<kF64, double>((double)T, (double)S, p));
     default:  // kBeta, eos/wright.py:165
-      return wright_drho_dsal((double)T, (double)S, p) /
-             wright_density<kF64, double>((double)T, (double)S, p);
+      if constexpr (MODE == kF32Faithful)
+        return wright_drho_dsal_f32(T, S, p) / wright_density<MODE, TIn>(T, S, p);
+      else
+        return wright_drho_dsal((double)T, (double)S, p) /
+               wright_density<kF64, double>((double)T, (double)S, p);
   }
 }
 

@@ -85,6 +85,9 @@ def main():
     out["f32_T"], out["f32_S"] = T32, S32
     out["f32_density"] = ref.density(T32, S32, out["blk_p"])
     assert out["f32_density"].dtype == np.float64
+    for fn in ("drho_dtemp", "drho_dsal", "alpha", "beta"):
+        out[f"f32_{fn}"] = getattr(ref, fn)(T32, S32, out["blk_p"])
+        assert out[f"f32_{fn}"].dtype == np.float64
 
     # scalars of tests/test_wright.py:11-12,30-31,50-51,70-71,120-121
     out["scalar_args"] = np.array([18.0, 35.0, 200000.0])

@@ -71,6 +71,13 @@ def test_float32_inputs_follow_numpy_mixed_precision(wright_vectors):
     assert_bit_equal(got, v["f32_density"], "float32 theta/S, float64 p")
 
 
+@pytest.mark.parametrize("func", ["drho_dtemp", "drho_dsal", "alpha", "beta"])
+def test_float32_derivatives_follow_numpy_mixed_precision(wright_vectors, func):
+    v = wright_vectors
+    got = FUNCS[func](v["f32_T"], v["f32_S"], v["blk_p"])
+    assert_bit_equal(got, v[f"f32_{func}"], f"float32 {func}")
+
+
 def test_float32_upcast_mode_is_plain_float64(wright_vectors):
     from momlevel_amd import core
 
