@@ -319,3 +319,26 @@ def test_xarray_round_trip_if_available():
     assert isinstance(res, xr.Dataset) and isinstance(ref, xr.Dataset)
     base, _ = steric(dset)
     assert_bit_equal(res["steric"].values, base["steric"].values)
+
+
+def test_memory_mapped_inputs_stream_from_disk(tmp_path, monkeypatch):
+    """theta/S larger than host RAM live in .npy files: np.load(mmap_mode='r') arrays are sliced
+    chunk by chunk by engine.TimeChunks, so only one time chunk is ever resident on the host."""
+    from momlevel_amd import engine
+
+    d = _masked_dataset(nt=9)
+    base, _ = steric(d)
+    gbase, _ = steric(d, domain="global")
+    dm = d.copy()
+    for k in ("thetao", "so"):
+        path = tmp_path / f"{k}.npy"
+        np.save(path, d[k].values)
+        mm = np.load(path, mmap_mode="r")
+        dm[k] = DataArray(mm, d[k].dims)
+        assert isinstance(mm, np.memmap) and np.shares_memory(dm[k].data, mm)  # a view, not a copy
+    monkeypatch.setattr(engine, "chunk_steps", lambda nt, b, dev, budget_bytes=None: 4)
+    res, _ = steric(dm)
+    gres, _ = steric(dm, domain="global")
+    assert_bit_equal(res["steric"].values, base["steric"].values)
+    assert_bit_equal(res["delta_rho"].values, base["delta_rho"].values)
+    assert_bit_equal(gres["steric"].values, gbase["steric"].values)
