@@ -1,6 +1,8 @@
 """GPU: randomised sweep of shapes / dtypes / variants / pressure layouts / NaN patterns through
 the C ABI, each case against the oracle.  Deterministic seeds: a failure names its case."""
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -40,7 +42,7 @@ def draw(seed):
                 vol=vol, z_i=z_i, z_l=z_l, deptho=deptho, pres=pres)
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MOMLEVEL_SWEEP_SEEDS", "48"))))
 def test_random_case(seed):
     c = draw(seed)
     T, S, vol, pres = c["T"], c["S"], c["vol"], c["pres"]
