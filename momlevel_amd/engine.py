@@ -189,6 +189,22 @@ def global_finalize(masso, volo, rhoga, area_sum):
 # ---------------------------------------------------------------------------------------
 # local variant (src/momlevel/steric.py:150-166)
 # ---------------------------------------------------------------------------------------
+_PINNED_OUTPUT_LIMIT = 32 * _GIB
+
+
+def _host_output(shape):
+    """float64 host array for results copied back from the device.  Page-locked when it is not
+    huge: the D2H copy then runs at the link rate and the pages are already resident (a fresh
+    np.empty pays a page fault per 4 KiB on first touch).  The numpy view keeps the pinned
+    tensor alive."""
+    nbytes = int(np.prod(shape)) * 8
+    if 0 < nbytes <= _PINNED_OUTPUT_LIMIT:
+        try:
+            return torch.empty(shape, dtype=torch.float64, pin_memory=True).numpy()
+        except RuntimeError:
+            pass
+    return np.empty(shape, dtype=np.float64)
+
 def local_steric(T, S, rho0, vol0, pres, rhozero, z_i=None, deptho=None, dz=None,
                  eos="wright", f32_mode="faithful", want_delta_rho=True, out_host=None,
                  steps=None):
@@ -217,8 +233,8 @@ def local_steric(T, S, rho0, vol0, pres, rhozero, z_i=None, deptho=None, dz=None
     chunks = TimeChunks(T, S, dev, steps=steps, extra_bytes_per_step=extra)
     nt = chunks.nt
     if out_host:
-        eta = np.empty((nt, ny, nx), dtype=np.float64)
-        drho = np.empty((nt, nz, ny, nx), dtype=np.float64) if want_delta_rho else None
+        eta = _host_output((nt, ny, nx))
+        drho = _host_output((nt, nz, ny, nx)) if want_delta_rho else None
     else:
         eta = torch.empty((nt, ny, nx), dtype=torch.float64, device=dev)
         drho = (
