@@ -9,6 +9,7 @@ chunk k overlapping the upload of chunk k+1, while the time-invariant reference
 state stays resident on the device.
 """
 
+import os
 import warnings
 
 import numpy as np
@@ -54,7 +55,7 @@ def chunk_steps(nt, bytes_per_step, device, budget_bytes=None):
     """Time steps per chunk so that the double-buffered chunk fits the HBM budget."""
     if budget_bytes is None:
         free, _total = torch.cuda.mem_get_info(device)
-        budget_bytes = min(free // 3, 24 * _GIB)
+        budget_bytes = min(free // 3, 4 * _GIB)  # small chunks: deeper H2D|compute|D2H overlap
     return int(max(1, min(nt, budget_bytes // max(1, 2 * bytes_per_step))))
 
 
@@ -76,12 +77,12 @@ class TimeChunks:
     """Iterate a (nt, nz, ny, nx) field pair in device-resident time chunks.
 
     Device-resident fields are sliced (no copy).  Host (numpy) fields are copied chunk by chunk
-    straight from the caller's memory into a fresh device tensor: on the MI355X hosts a
-    pageable hipMemcpy already runs at the PCIe Gen5 rate (56 GB/s measured, the same as from
-    pinned memory), so a staging copy would only halve the rate.  The copy call blocks the
-    host while the PREVIOUS chunk's kernels run asynchronously, so upload and compute overlap;
-    compute is ~400x faster than the link anyway.  A (nz,ny,nx) operand (a held field) is
-    uploaded once and yielded unchanged with every chunk.
+    straight from the caller's memory into a fresh device tensor -- no staging copy (a pageable
+    hipMemcpy already runs at the PCIe Gen5 rate on the MI355X hosts, 56 GB/s measured; staging
+    through a pinned buffer halved it).  The chunk's pages are page-locked in place
+    (hipHostRegister) for the duration of the copy so that it can run asynchronously on a copy
+    stream: chunk k+1 uploads while chunk k's kernels run and its results download on a third
+    stream.  A (nz,ny,nx) operand (a held field) is uploaded once and yielded with every chunk.
     """
 
     def __init__(self, T, S, device, steps=None, extra_bytes_per_step=0):
@@ -102,6 +103,23 @@ class TimeChunks:
         self._held = [
             to_device(f, device, _stream_dtype(f)) if f.ndim == 3 else None for f in self.fields
         ]
+        # asynchronous uploads: the caller's pages are page-locked in place for the duration of
+        # the copy (hipHostRegister), so the H2D of a chunk runs on its own stream and overlaps
+        # the previous chunk's kernels and result download; any failure falls back to a blocking copy
+        self._copy_stream = None if all(self.resident) else torch.cuda.Stream(device=device)
+        self._registered = []  # (pointer, completion event, keep-alive tensor)
+
+    def _release(self, wait=False):
+        cudart = torch.cuda.cudart()
+        keep = []
+        for ptr, ev, host in self._registered:
+            if wait:
+                ev.synchronize()
+            if ev.query():
+                cudart.cudaHostUnregister(ptr)
+            else:
+                keep.append((ptr, ev, host))
+        self._registered = keep
 
     def _upload(self, f, t0, t1):
         dt = _stream_dtype(f)
@@ -110,21 +128,49 @@ class TimeChunks:
             return src.to(device=self.device, dtype=dt)
         host = _host_tensor(src, np.float32 if dt == torch.float32 else np.float64)
         dev = torch.empty(host.shape, dtype=dt, device=self.device)
+        if self._copy_stream is not None and os.environ.get("MOMLEVEL_AMD_ASYNC_H2D", "1") != "0":
+            ptr, nbytes = host.data_ptr(), host.numel() * host.element_size()
+            try:
+                rc = torch.cuda.cudart().cudaHostRegister(ptr, nbytes, 0)
+            except RuntimeError:
+                rc = 1
+            if int(rc) == 0:
+                main = torch.cuda.current_stream(self.device)
+                self._copy_stream.wait_stream(main)  # `dev` may reuse memory main is done with
+                with torch.cuda.stream(self._copy_stream):
+                    dev.copy_(host, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self._copy_stream)
+                dev.record_stream(self._copy_stream)
+                main.wait_event(ev)
+                self._registered.append((ptr, ev, host))
+                return dev
         dev.copy_(host)
         return dev
 
+    def _stage(self, t0, t1):
+        cur = []
+        for f, res, held in zip(self.fields, self.resident, self._held):
+            if f.ndim == 3:
+                cur.append(held)
+            elif res:
+                cur.append(f[t0:t1])
+            else:
+                cur.append(self._upload(f, t0, t1))
+        return cur
+
     def __iter__(self):
-        for t0 in range(0, self.nt, self.steps):
-            t1 = min(t0 + self.steps, self.nt)
-            cur = []
-            for f, res, held in zip(self.fields, self.resident, self._held):
-                if f.ndim == 3:
-                    cur.append(held)
-                elif res:
-                    cur.append(f[t0:t1])
-                else:
-                    cur.append(self._upload(f, t0, t1))
-            yield t0, t1, cur[0], cur[1]
+        bounds = [(t0, min(t0 + self.steps, self.nt)) for t0 in range(0, self.nt, self.steps)]
+        try:
+            nxt = self._stage(*bounds[0]) if bounds else None
+            for i, (t0, t1) in enumerate(bounds):
+                cur = nxt
+                # chunk i+1 starts uploading before the caller enqueues chunk i's kernels
+                nxt = self._stage(*bounds[i + 1]) if i + 1 < len(bounds) else None
+                yield t0, t1, cur[0], cur[1]
+                self._release()
+        finally:
+            self._release(wait=True)
 
 
 # ---------------------------------------------------------------------------------------
@@ -241,19 +287,29 @@ def local_steric(T, S, rho0, vol0, pres, rhozero, z_i=None, deptho=None, dz=None
             torch.empty((nt, nz, ny, nx), dtype=torch.float64, device=dev)
             if want_delta_rho else None
         )
+    # results go back on their own stream: the D2H of chunk k then overlaps the H2D of chunk
+    # k+1 (PCIe is full duplex, the copies use different DMA engines)
+    d2h = torch.cuda.Stream(device=dev) if out_host else None
+    main = torch.cuda.current_stream(dev)
     for t0, t1, Tc, Sc in chunks:
         if out_host:
             d, e = core.steric_local(Tc, Sc, rho0m, surface, pres, neg_inv, dz=dz, z_i=z_i,
                                      deptho=deptho, eos=eos, f32_mode=f32_mode,
                                      want_delta_rho=want_delta_rho)
-            # straight into the caller-visible arrays (one D2H pass, no intermediate copy)
-            torch.from_numpy(eta[t0:t1]).copy_(e)
-            if want_delta_rho:
-                torch.from_numpy(drho[t0:t1]).copy_(d)
+            d2h.wait_stream(main)
+            with torch.cuda.stream(d2h):
+                # straight into the caller-visible arrays (one D2H pass, no intermediate copy)
+                torch.from_numpy(eta[t0:t1]).copy_(e, non_blocking=True)
+                e.record_stream(d2h)
+                if want_delta_rho:
+                    torch.from_numpy(drho[t0:t1]).copy_(d, non_blocking=True)
+                    d.record_stream(d2h)
         else:
             core.steric_local(Tc, Sc, rho0m, surface, pres, neg_inv, dz=dz, z_i=z_i,
                               deptho=deptho, eos=eos, f32_mode=f32_mode,
                               want_delta_rho=want_delta_rho,
                               delta_rho_out=drho[t0:t1] if want_delta_rho else None,
                               eta_out=eta[t0:t1])
+    if d2h is not None:
+        d2h.synchronize()  # the host arrays are complete when we return
     return drho, eta

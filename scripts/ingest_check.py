@@ -37,7 +37,7 @@ def dataset(nt, nz, ny, nx, dtype=np.float64):
 
 
 def main():
-    nt, nz, ny, nx = 12, 75, 576, 360
+    nt, nz, ny, nx = 48, 75, 576, 360  # 12 GB of fp64 theta+S: several upload chunks
     for dtype in (np.float64, np.float32):
         d = dataset(nt, nz, ny, nx, dtype)
         cells = nt * nz * ny * nx
