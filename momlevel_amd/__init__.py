@@ -21,7 +21,7 @@ from . import util
 from ._lib import MomlevelHipError
 from .dynamic import inverse_barometer
 from .labeled import DataArray, Dataset
-from .steric import halosteric, steric, thermosteric
+from .steric import halosteric, steric, steric_variants, thermosteric
 
 __all__ = [
     "DataArray",
@@ -34,6 +34,7 @@ __all__ = [
     "halosteric",
     "reference",
     "steric",
+    "steric_variants",
     "test_data",
     "thermosteric",
     "util",

@@ -76,6 +76,8 @@ def to_xarray(obj):
 def _map(obj, fn):
     if isinstance(obj, tuple):
         return tuple(_map(o, fn) for o in obj)
+    if isinstance(obj, dict):
+        return {k: _map(v, fn) for k, v in obj.items()}
     return fn(obj)
 
 

@@ -313,3 +313,99 @@ def local_steric(T, S, rho0, vol0, pres, rhozero, z_i=None, deptho=None, dz=None
     if d2h is not None:
         d2h.synchronize()  # the host arrays are complete when we return
     return drho, eta
+
+
+# ---------------------------------------------------------------------------------------
+# several variants from ONE upload of theta/S (the PCIe-bound case: host inputs)
+# ---------------------------------------------------------------------------------------
+VARIANTS = ("steric", "thermosteric", "halosteric")
+
+
+def _streamed_pair(variants, T, S, T0, S0):
+    """What has to stream for this set of variants: a field only some variant varies."""
+    need_T = any(v != "halosteric" for v in variants)
+    need_S = any(v != "thermosteric" for v in variants)
+    return (T if need_T else T0), (S if need_S else S0)
+
+
+def _variant_operands(variant, Tc, Sc, T0, S0):
+    """(theta, S) of one variant for the current chunk (steric.py:115-125)."""
+    return (T0 if variant == "halosteric" else Tc), (S0 if variant == "thermosteric" else Sc)
+
+
+def global_masso_variants(T, S, T0, S0, vol0, pres, variants, eos="wright", f32_mode="faithful",
+                          steps=None, skip_dry=None):
+    """masso(t) of every requested variant; theta/S chunks are uploaded once and reused."""
+    dev = device_of(T, S, vol0)
+    vol0 = to_device(vol0, dev, torch.float64)
+    pres = to_device(pres, dev, torch.float64)
+    T0 = to_device(T0, dev, _stream_dtype(T0))
+    S0 = to_device(S0, dev, _stream_dtype(S0))
+    Ts, Ss = _streamed_pair(variants, T, S, T0, S0)
+    chunks = TimeChunks(Ts, Ss, dev, steps=steps)
+    nt = T.shape[0]
+    out = {v: torch.empty(nt, dtype=torch.float64, device=dev) for v in variants}
+    for t0, t1, Tc, Sc in chunks:
+        for v in variants:
+            Tv, Sv = _variant_operands(v, Tc, Sc, T0, S0)
+            out[v][t0:t1] = core.steric_global_masso(Tv, Sv, vol0, pres, eos=eos,
+                                                     f32_mode=f32_mode, skip_dry=skip_dry)
+    return out
+
+
+def local_steric_variants(T, S, T0, S0, rho0, vol0, pres, rhozero, variants, z_i=None,
+                          deptho=None, dz=None, eos="wright", f32_mode="faithful",
+                          want_delta_rho=True, out_host=None, steps=None):
+    """{variant: (delta_rho, eta)}; theta/S chunks are uploaded once and reused."""
+    dev = device_of(T, S, rho0, vol0)
+    vol0 = to_device(vol0, dev, torch.float64)
+    rho0 = to_device(rho0, dev, torch.float64)
+    pres = to_device(pres, dev, torch.float64)
+    T0 = to_device(T0, dev, _stream_dtype(T0))
+    S0 = to_device(S0, dev, _stream_dtype(S0))
+    rho0m = core.fold_mask(rho0, vol0)
+    surface = vol0[0].contiguous()
+    if dz is not None:
+        dz = to_device(dz, dev, torch.float64)
+    else:
+        z_i = to_device(z_i, dev, torch.float64)
+        deptho = to_device(deptho, dev, torch.float64)
+    neg_inv = -1.0 / float(rhozero)
+    nz, ny, nx = tuple(vol0.shape)
+    nt = T.shape[0]
+    if out_host is None:
+        out_host = not (_is_device(T) or _is_device(S))
+    n_out = len(variants)
+    extra = n_out * nz * ny * nx * 8 if (want_delta_rho and out_host) else 0
+    Ts, Ss = _streamed_pair(variants, T, S, T0, S0)
+    chunks = TimeChunks(Ts, Ss, dev, steps=steps, extra_bytes_per_step=extra)
+
+    def alloc(shape):
+        return _host_output(shape) if out_host else torch.empty(shape, dtype=torch.float64,
+                                                                device=dev)
+
+    eta = {v: alloc((nt, ny, nx)) for v in variants}
+    drho = {v: (alloc((nt, nz, ny, nx)) if want_delta_rho else None) for v in variants}
+    d2h = torch.cuda.Stream(device=dev) if out_host else None
+    main = torch.cuda.current_stream(dev)
+    for t0, t1, Tc, Sc in chunks:
+        for v in variants:
+            Tv, Sv = _variant_operands(v, Tc, Sc, T0, S0)
+            kw = dict(dz=dz, z_i=z_i, deptho=deptho, eos=eos, f32_mode=f32_mode,
+                      want_delta_rho=want_delta_rho)
+            if out_host:
+                d, e = core.steric_local(Tv, Sv, rho0m, surface, pres, neg_inv, **kw)
+                d2h.wait_stream(main)
+                with torch.cuda.stream(d2h):
+                    torch.from_numpy(eta[v][t0:t1]).copy_(e, non_blocking=True)
+                    e.record_stream(d2h)
+                    if want_delta_rho:
+                        torch.from_numpy(drho[v][t0:t1]).copy_(d, non_blocking=True)
+                        d.record_stream(d2h)
+            else:
+                core.steric_local(Tv, Sv, rho0m, surface, pres, neg_inv,
+                                  delta_rho_out=drho[v][t0:t1] if want_delta_rho else None,
+                                  eta_out=eta[v][t0:t1], **kw)
+    if d2h is not None:
+        d2h.synchronize()
+    return {v: (drho[v], eta[v]) for v in variants}

@@ -29,19 +29,15 @@ from .reference import (
 )
 from .util import annual_average, default_coords, eos_func_from_str, validate_dataset
 
-__all__ = ["halosteric", "steric", "thermosteric"]
+__all__ = ["halosteric", "steric", "steric_variants", "thermosteric"]
 
 _VARIANTS = ("steric", "thermosteric", "halosteric")
 
 
-def _held_and_streamed(variant, dset, reference):
-    """(thetao, so) with the field the variant freezes taken from the reference state
-    (steric.py:115-125)."""
-    if variant not in _VARIANTS:
-        raise ValueError(f"Unknown variant '{variant}' passed to `steric`")
-    thetao = reference["thetao"] if variant == "halosteric" else dset["thetao"]
-    so = reference["so"] if variant == "thermosteric" else dset["so"]
-    return thetao, so
+def _check_variants(variants):
+    for v in variants:
+        if v not in _VARIANTS:  # steric.py:125
+            raise ValueError(f"Unknown variant '{v}' passed to `steric`")
 
 
 def _check_dz_inputs(levels, interfaces, depth):
@@ -57,46 +53,123 @@ def _check_dz_inputs(levels, interfaces, depth):
     )
 
 
-def _global_branch(result, fields, reference, variant, dtype, tcoord, coords_for, deferred):
+def _global_results(ops, reference, variants, dtype, tcoord, coords_for, deferred):
     """steric.py:134-147 -- masso(t) from K1, then the Boussinesq offline approximation."""
-    T, S, vol0, p, eos = fields
-    masso = engine.global_masso(T, S, vol0, p, eos=eos, f32_mode=_f32_mode()).cpu().numpy()
-    if deferred:  # the self-generated reference is time index 0 of this very record
-        set_reference_masso(reference, masso[0])
-    reference_height, sealevel, _expansion_coeff = engine.global_finalize(
-        masso,
-        np.float64(reference["volo"].values),
-        np.float64(reference["rhoga"].values),
-        np.float64(reference["areacello"].sum().values),
-    )
-    result["reference_height"] = DataArray(
-        np.float64(reference_height), (), None,
-        {"long_name": "Reference column height", "units": "m"},
-    )
-    result["reference_height"].encoding["dtype"] = dtype
-    result[variant] = DataArray(sealevel, (tcoord,), coords_for((tcoord,)))
+    T, S, T0, S0, vol0, p, eos = ops
+    masso = engine.global_masso_variants(T, S, T0, S0, vol0, p, variants, eos=eos,
+                                         f32_mode=_f32_mode())
+    masso = {v: m.cpu().numpy() for v, m in masso.items()}
+    if deferred:  # the self-generated reference is time index 0 of this very record: every
+        # variant sees (theta0, S0) there, so any of them carries masso0 (same kernel, same bits)
+        set_reference_masso(reference, masso[variants[0]][0])
+    out = {}
+    for v in variants:
+        reference_height, sealevel, _expansion_coeff = engine.global_finalize(
+            masso[v],
+            np.float64(reference["volo"].values),
+            np.float64(reference["rhoga"].values),
+            np.float64(reference["areacello"].sum().values),
+        )
+        result = Dataset()
+        result["reference_height"] = DataArray(
+            np.float64(reference_height), (), None,
+            {"long_name": "Reference column height", "units": "m"},
+        )
+        result["reference_height"].encoding["dtype"] = dtype
+        result[v] = DataArray(sealevel, (tcoord,), coords_for((tcoord,)))
+        out[v] = result
+    return out
 
 
-def _local_branch(result, fields, dset, reference, variant, dtype, rhozero, names, cdims3,
-                  coords_for):
+def _local_results(ops, dset, reference, variants, dtype, rhozero, names, cdims3, coords_for):
     """steric.py:150-166 -- delta_rho and the column integral from K2."""
-    T, S, vol0, p, eos = fields
+    T, S, T0, S0, vol0, p, eos = ops
     tcoord, zcoord, zbounds = names
     hdims = cdims3[1:]
     cdims4 = (tcoord,) + cdims3
     deptho = dset["deptho"].transpose(*hdims)
     _check_dz_inputs(dset[zcoord], dset[zbounds], deptho)
-    delta_rho, sealevel = engine.local_steric(
-        T, S, reference["rho"].transpose(*cdims3).data, vol0, p, rhozero,
+    fields = engine.local_steric_variants(
+        T, S, T0, S0, reference["rho"].transpose(*cdims3).data, vol0, p, rhozero, variants,
         z_i=dset[zbounds].data, deptho=deptho.data, eos=eos, f32_mode=_f32_mode(),
         want_delta_rho=True,
     )
-    result["delta_rho"] = DataArray(
-        delta_rho, cdims4, coords_for(cdims4),
-        {"long_name": "change in in situ density from reference state", "units": "kg m-3"},
+    out = {}
+    for v in variants:
+        delta_rho, sealevel = fields[v]
+        result = Dataset()
+        result["delta_rho"] = DataArray(
+            delta_rho, cdims4, coords_for(cdims4),
+            {"long_name": "change in in situ density from reference state", "units": "kg m-3"},
+        )
+        result["delta_rho"].encoding["dtype"] = dtype
+        result[v] = DataArray(sealevel, (tcoord,) + hdims, coords_for((tcoord,) + hdims))
+        out[v] = result
+    return out
+
+
+def _steric_many(dset, variants, reference, coord_names, varname_map, rhozero, patm,
+                 equation_of_state, domain, dtype, strict, annual, verbose):
+    """The body of steric() for one or several variants sharing one reference state and one
+    pass of theta/S through the device.  Returns ({variant: result}, reference)."""
+    dset = dset.rename(varname_map)
+    names = default_coords(coord_names)
+    tcoord, zcoord, zbounds = names
+
+    validate_dataset(
+        dset, strict=strict, additional_vars=None if domain == "global" else [zbounds, "deptho"]
     )
-    result["delta_rho"].encoding["dtype"] = dtype
-    result[variant] = DataArray(sealevel, (tcoord,) + hdims, coords_for((tcoord,) + hdims))
+    pres = pressure_field(dset, zcoord, patm)  # 1 m of depth ~ 1 dbar = 1e4 Pa, plus patm
+
+    deferred = reference is None and domain == "global"
+    if reference is None:
+        # domain="global": masso0 is masso(t=0) of the K1 launch below (same kernel, same bits)
+        reference = _setup(dset, patm, equation_of_state, coord_names, 0, defer_masso=deferred)
+        if verbose:
+            print("Generating reference state from first timestep")
+    else:
+        assert isinstance(reference, Dataset), "`reference` must be an xarray Dataset"
+        if verbose:
+            print("Using supplied reference state")
+    validate_dataset(reference, reference=True, strict=strict)
+
+    _check_variants(variants)
+    eos_func_from_str(equation_of_state)  # unknown EOS -> ValueError (util.py:247)
+
+    # canonical (time, z, y, x) layout; outputs are always time-first (steric.py:154,165)
+    cdims3 = canonical_dims(dset["thetao"], tcoord, zcoord)
+    cdims4 = (tcoord,) + cdims3
+
+    def coords_for(dims):
+        return {d: dset[d] for d in dims if d in dset.variables}
+
+    ops = (
+        dset["thetao"].transpose(*cdims4).data,
+        dset["so"].transpose(*cdims4).data,
+        reference["thetao"].transpose(*cdims3).data,
+        reference["so"].transpose(*cdims3).data,
+        reference["volcello"].transpose(*cdims3).data,
+        pressure_operand(pres, tcoord, cdims3),
+        equation_of_state.lower(),
+    )
+    if domain == "global":
+        results = _global_results(ops, reference, variants, dtype, tcoord, coords_for, deferred)
+    else:
+        results = _local_results(ops, dset, reference, variants, dtype, rhozero, names, cdims3,
+                                 coords_for)
+
+    for variant, result in results.items():
+        result[variant].attrs.update(
+            {"long_name": f"{variant.capitalize()} height adjustment", "units": "m"}
+        )
+        result[variant].encoding["dtype"] = dtype
+        # coordinate / dimension attributes follow the input dataset (steric.py:177-179)
+        for var in set(result.coords).union(result.dims):
+            if var in dset.variables and var in result.variables:
+                result[var].attrs.update(dset[var].attrs)
+        if annual:
+            results[variant] = annual_average(result)
+    return results, reference
 
 
 @accepts_xarray
@@ -140,67 +213,45 @@ def steric(
     -------
     (result, reference) : tuple of Datasets
     """
-    dset = dset.rename(varname_map)
-    names = default_coords(coord_names)
-    tcoord, zcoord, zbounds = names
-
-    validate_dataset(
-        dset, strict=strict, additional_vars=None if domain == "global" else [zbounds, "deptho"]
+    results, reference = _steric_many(
+        dset, (variant,), reference, coord_names, varname_map, rhozero, patm, equation_of_state,
+        domain, dtype, strict, annual, verbose,
     )
-    pres = pressure_field(dset, zcoord, patm)  # 1 m of depth ~ 1 dbar = 1e4 Pa, plus patm
+    return (results[variant], reference)
 
-    deferred = reference is None and domain == "global"
-    if reference is None:
-        # domain="global": masso0 is masso(t=0) of the K1 launch below (same kernel, same bits)
-        reference = _setup(dset, patm, equation_of_state, coord_names, 0, defer_masso=deferred)
-        if verbose:
-            print("Generating reference state from first timestep")
-    else:
-        assert isinstance(reference, Dataset), "`reference` must be an xarray Dataset"
-        if verbose:
-            print("Using supplied reference state")
-    validate_dataset(reference, reference=True, strict=strict)
 
-    thetao, so = _held_and_streamed(variant, dset, reference)
-    eos_func_from_str(equation_of_state)  # unknown EOS -> ValueError (util.py:247)
+@accepts_xarray
+def steric_variants(
+    dset,
+    variants=("steric", "thermosteric", "halosteric"),
+    reference=None,
+    coord_names=None,
+    varname_map=None,
+    rhozero=1035.0,
+    patm=101325.0,
+    equation_of_state="Wright",
+    domain="local",
+    dtype="float32",
+    strict=True,
+    annual=False,
+    verbose=False,
+):
+    """EXTENSION (not in momlevel): several variants in one call.
 
-    # canonical (time, z, y, x) layout; outputs are always time-first (steric.py:154,165)
-    cdims3 = canonical_dims(thetao if tcoord in thetao.dims else so, tcoord, zcoord)
+    ``steric``, ``thermosteric`` and ``halosteric`` of the same dataset are usually wanted
+    together, and with host-resident inputs each call is bound by moving theta/S over PCIe.
+    This entry point uploads every time chunk once and runs the requested variants on it, with
+    one shared reference state.  Each result is bit-identical to the corresponding single call.
 
-    def raw(da):
-        return da.transpose(*(((tcoord,) + cdims3) if tcoord in da.dims else cdims3)).data
-
-    def coords_for(dims):
-        return {d: dset[d] for d in dims if d in dset.variables}
-
-    fields = (
-        raw(thetao),
-        raw(so),
-        raw(reference["volcello"]),
-        pressure_operand(pres, tcoord, cdims3),
-        equation_of_state.lower(),
+    Returns
+    -------
+    (results, reference) : ``results`` maps variant name -> result Dataset
+    """
+    results, reference = _steric_many(
+        dset, tuple(variants), reference, coord_names, varname_map, rhozero, patm,
+        equation_of_state, domain, dtype, strict, annual, verbose,
     )
-
-    result = Dataset()
-    if domain == "global":
-        _global_branch(result, fields, reference, variant, dtype, tcoord, coords_for, deferred)
-    else:
-        _local_branch(result, fields, dset, reference, variant, dtype, rhozero, names, cdims3,
-                      coords_for)
-
-    result[variant].attrs.update(
-        {"long_name": f"{variant.capitalize()} height adjustment", "units": "m"}
-    )
-    result[variant].encoding["dtype"] = dtype
-
-    # coordinate / dimension attributes follow the input dataset (steric.py:177-179)
-    for var in set(result.coords).union(result.dims):
-        if var in dset.variables and var in result.variables:
-            result[var].attrs.update(dset[var].attrs)
-
-    if annual:
-        result = annual_average(result)
-    return (result, reference)
+    return (results, reference)
 
 
 def halosteric(*args, **kwargs):

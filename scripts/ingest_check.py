@@ -56,5 +56,29 @@ def main():
                   f"H2D {inb/dt/1e9:5.1f} GB/s  D2H {outb/dt/1e9:5.1f} GB/s")
 
 
+def variants_check():
+    """three separate calls vs the steric_variants extension (one upload)."""
+    nt, nz, ny, nx = 48, 75, 576, 360
+    d = dataset(nt, nz, ny, nx, np.float64)
+    cells = nt * nz * ny * nx
+    for domain in ("global", "local"):
+        best3, best1 = float("inf"), float("inf")
+        for rep in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for v in ("steric", "thermosteric", "halosteric"):
+                m.steric(d, variant=v, domain=domain)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            m.steric_variants(d, domain=domain)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            if rep:
+                best3, best1 = min(best3, t1 - t0), min(best1, t2 - t1)
+        print(f"three variants, {domain:6s}: 3 calls {best3*1e3:8.1f} ms   steric_variants "
+              f"{best1*1e3:8.1f} ms   ({best3/best1:.2f}x)  {3*cells/best1/1e6:8.1f} Mcells/s")
+
+
 if __name__ == "__main__":
     main()
+    variants_check()

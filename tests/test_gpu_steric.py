@@ -342,3 +342,24 @@ def test_memory_mapped_inputs_stream_from_disk(tmp_path, monkeypatch):
     assert_bit_equal(res["steric"].values, base["steric"].values)
     assert_bit_equal(res["delta_rho"].values, base["delta_rho"].values)
     assert_bit_equal(gres["steric"].values, gbase["steric"].values)
+
+
+@pytest.mark.parametrize("domain", ["local", "global"])
+def test_steric_variants_extension_matches_single_calls(domain, monkeypatch):
+    """One upload of theta/S, three variants: each bit-identical to its own steric() call."""
+    from momlevel_amd import engine, steric_variants
+
+    d = _masked_dataset(nt=7)
+    monkeypatch.setattr(engine, "chunk_steps", lambda nt, b, dev, budget_bytes=None: 3)
+    results, reference = steric_variants(d, domain=domain)
+    assert set(results) == {"steric", "thermosteric", "halosteric"}
+    for variant, res in results.items():
+        single, ref1 = steric(d, variant=variant, domain=domain)
+        assert_bit_equal(res[variant].values, single[variant].values, variant)
+        if domain == "local":
+            assert_bit_equal(res["delta_rho"].values, single["delta_rho"].values)
+        else:
+            assert float(res[variant][0]) == 0.0
+            assert float(reference["masso"]) == float(ref1["masso"])
+    with pytest.raises(ValueError):
+        steric_variants(d, variants=("steric", "bogus"))
