@@ -21,9 +21,36 @@ def _as_tensor(x, device):
     return torch.from_numpy(np.ascontiguousarray(a)).to(device)
 
 
+_HOST_CHUNK_ELEMS = 1 << 28  # 2 GiB of float64 per operand and chunk
+
+
+def _evaluate_host_chunked(eos, func, T, S, p, gravity):
+    """Large host arrays: walk the leading axis of the broadcast shape in chunks so that the
+    device never holds more than a few GiB (the result is a host array anyway)."""
+    arrs = [np.asarray(x) for x in (T, S, p if p is not None else 0.0)]
+    shape = np.broadcast_shapes(*(a.shape for a in arrs))
+    rows = max(1, _HOST_CHUNK_ELEMS // max(1, int(np.prod(shape[1:]))))
+    out = np.empty(shape, dtype=np.float64)
+
+    def part(a, i0, i1):  # slice the leading axis unless the operand broadcasts along it
+        if a.ndim == len(shape) and a.shape[0] == shape[0] and shape[0] > 1:
+            return a[i0:i1]
+        return a
+
+    for i0 in range(0, shape[0], rows):
+        i1 = min(i0 + rows, shape[0])
+        out[i0:i1] = evaluate(eos, func, part(arrs[0], i0, i1), part(arrs[1], i0, i1),
+                              None if p is None else part(arrs[2], i0, i1), gravity=gravity)
+    return out
+
+
 def evaluate(eos, func, T, S, p, gravity=None):
     """f(T, S, p) with numpy broadcasting; returns the kind of array it was given."""
     core.require_device()
+    if not any(isinstance(x, torch.Tensor) for x in (T, S, p)):
+        shape = np.broadcast_shapes(*(np.shape(x) for x in (T, S, p) if x is not None))
+        if len(shape) >= 1 and int(np.prod(shape)) > _HOST_CHUNK_ELEMS and shape[0] > 1:
+            return _evaluate_host_chunked(eos, func, T, S, p, gravity)
     on_device = any(isinstance(x, torch.Tensor) and x.is_cuda for x in (T, S, p))
     scalar_in = all(np.ndim(x) == 0 and not isinstance(x, torch.Tensor) for x in (T, S, p))
     device = next(

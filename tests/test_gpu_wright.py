@@ -110,3 +110,18 @@ def test_device_tensors_stay_on_device():
 def test_linear_eos():
     got = linear.density(thetao, so)
     assert_bit_equal(got, o.linear_density(thetao, so))
+
+
+def test_large_host_arrays_are_chunked(monkeypatch):
+    """calc_rho-style calls on host arrays larger than the chunk limit walk the leading axis."""
+    from momlevel_amd.eos import _dispatch
+
+    monkeypatch.setattr(_dispatch, "_HOST_CHUNK_ELEMS", 1000)
+    r = np.random.default_rng(5)
+    T = r.uniform(-2, 32, (7, 5, 6, 10))
+    S = r.uniform(30, 40, (7, 5, 6, 10))
+    pz = np.linspace(1e5, 5e7, 5)[:, None, None]
+    assert_bit_equal(density(T, S, pz), o.wright_density(T, S, pz))
+    p4 = r.uniform(1e5, 5e7, (7, 5, 6, 10))
+    assert_bit_equal(alpha(T, S, p4), o.wright_alpha(T, S, p4))
+    assert_bit_equal(density(T, S[0], 2.0e5), o.wright_density(T, S[0], 2.0e5))
