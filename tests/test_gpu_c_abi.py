@@ -53,3 +53,20 @@ def test_c_abi_demo_matches_python_path():
     assert volo_c == volo
     assert exp_c[0] == 0.0
     assert np.allclose(exp_c, np.log((masso[0] / volo) / (masso / volo)), rtol=0, atol=1e-15)
+
+
+def test_integration_md_level1_stub_runs_as_printed(wright_vectors):
+    """The ctypes stub INTEGRATION.md offers a momlevel maintainer must work verbatim (only the
+    library path is made absolute)."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(\"\"\" wright_hip\.py.*?)```", text, flags=re.S).group(1)
+    code = code.replace('ctypes.CDLL("libmomlevel_hip.so")',
+                        f'ctypes.CDLL({os.path.join(ROOT, "momlevel_amd", "libmomlevel_hip.so")!r})')
+    ns = {}
+    exec(compile(code, "wright_hip.py", "exec"), ns)
+    v = wright_vectors
+    for name in ("density", "drho_dtemp", "drho_dsal", "alpha", "beta"):
+        got = ns[name](v["blk_T"], v["blk_S"], v["blk_p"])
+        ref = v[f"blk_{name}"]
+        assert got.shape == ref.shape and np.array_equal(got, ref), name
+    assert ns["density"](18.0, 35.0, 2.0e5) == v["scalar_out"][0]
