@@ -90,6 +90,8 @@ def _pair(T, S, f32_mode):
     squeeze = nt is None
     if squeeze:
         nt = 1
+    if nt == 0 or nz * ny * nx == 0:
+        raise ValueError(f"empty field: shape {(nt, nz, ny, nx)} has no cells")
     return T, S, nt, nz, ny, nx, sT, sS, _dtype_code(T, f32_mode), squeeze
 
 

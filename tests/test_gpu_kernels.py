@@ -270,3 +270,18 @@ def test_local_tiles_need_no_exchange():
                 variant=variant)
             assert_bit_equal(d.cpu().numpy(), dfull[:, :, y0:y1, x0:x1].cpu().numpy(), "delta_rho tile")
             assert_bit_equal(e.cpu().numpy(), efull[:, y0:y1, x0:x1].cpu().numpy(), "eta tile")
+
+
+def test_empty_record_is_rejected_cleanly():
+    """nt = 0 (an empty time axis) is an error, never a launch: ValueError from the Python layer,
+    MLX_E_SHAPE from the ABI itself."""
+    g, vol0, T, S, pres = make_case(2, 3, 4, 8)
+    with pytest.raises(ValueError, match="empty field"):
+        core.steric_global_masso(T[:0], S[:0], vol0, pres)
+    with pytest.raises(ValueError, match="empty field"):
+        core.eos_map(T[:0], S[:0], pres)
+    lib = _lib.load()
+    ws = torch.empty(16, dtype=torch.float64, device="cuda")
+    rc = lib.mlx_steric_global(T.data_ptr(), S.data_ptr(), 0, vol0.data_ptr(), vol0.data_ptr(), 1,
+                               0, 0, 3, 32, 96, 96, 0, ws.data_ptr(), ws.data_ptr(), 128, None)
+    assert rc == -2  # MLX_E_SHAPE
