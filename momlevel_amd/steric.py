@@ -14,6 +14,8 @@ Inputs: labelled datasets backed by numpy (streamed to HBM in time chunks) or by
 tensors (processed in place); xarray Datasets when xarray is installed (adapters.py).
 """
 
+import os
+
 import numpy as np
 
 from . import engine
@@ -89,20 +91,25 @@ def _local_results(ops, dset, reference, variants, dtype, rhozero, names, cdims3
     cdims4 = (tcoord,) + cdims3
     deptho = dset["deptho"].transpose(*hdims)
     _check_dz_inputs(dset[zcoord], dset[zbounds], deptho)
+    # opt-in (not reference behaviour): MOMLEVEL_AMD_DELTA_RHO=0 leaves the 4-D delta_rho field
+    # out of the result -- the kernel then skips its 8 B/cell store and nothing 4-D comes back
+    want_delta_rho = os.environ.get("MOMLEVEL_AMD_DELTA_RHO", "1") != "0"
     fields = engine.local_steric_variants(
         T, S, T0, S0, reference["rho"].transpose(*cdims3).data, vol0, p, rhozero, variants,
         z_i=dset[zbounds].data, deptho=deptho.data, eos=eos, f32_mode=_f32_mode(),
-        want_delta_rho=True,
+        want_delta_rho=want_delta_rho,
     )
     out = {}
     for v in variants:
         delta_rho, sealevel = fields[v]
         result = Dataset()
-        result["delta_rho"] = DataArray(
-            delta_rho, cdims4, coords_for(cdims4),
-            {"long_name": "change in in situ density from reference state", "units": "kg m-3"},
-        )
-        result["delta_rho"].encoding["dtype"] = dtype
+        if want_delta_rho:
+            result["delta_rho"] = DataArray(
+                delta_rho, cdims4, coords_for(cdims4),
+                {"long_name": "change in in situ density from reference state",
+                 "units": "kg m-3"},
+            )
+            result["delta_rho"].encoding["dtype"] = dtype
         result[v] = DataArray(sealevel, (tcoord,) + hdims, coords_for((tcoord,) + hdims))
         out[v] = result
     return out

@@ -363,3 +363,12 @@ def test_steric_variants_extension_matches_single_calls(domain, monkeypatch):
             assert float(reference["masso"]) == float(ref1["masso"])
     with pytest.raises(ValueError):
         steric_variants(d, variants=("steric", "bogus"))
+
+
+def test_delta_rho_can_be_elided(monkeypatch):
+    d = _masked_dataset()
+    base, _ = steric(d)
+    monkeypatch.setenv("MOMLEVEL_AMD_DELTA_RHO", "0")
+    res, _ = steric(d)
+    assert "delta_rho" not in res
+    assert_bit_equal(res["steric"].values, base["steric"].values)
