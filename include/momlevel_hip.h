@@ -168,6 +168,17 @@ int mlx_masso(const double *rho, const double *vol, int64_t nt, int64_t n3,
               void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------
+ * util.annual_average (src/momlevel/util.py:85-92): per-group weighted mean over the leading
+ * (time) axis, groups of group_len consecutive steps (12 monthly steps per year), weights =
+ * days in month.  x is (ngroups*group_len, n), w (ngroups*group_len), out (ngroups, n):
+ *   out[g,i] = sum_j nan0(x[gL+j,i]) * w[gL+j]  /  sum_j [x[gL+j,i] not NaN] * w[gL+j]
+ * (xarray's weighted mean: NaNs carry no weight; 0 total weight gives NaN).  Terms are added
+ * in time order.
+ * ------------------------------------------------------------------------------- */
+int mlx_group_weighted_mean(const double *x, const double *w, int64_t ngroups, int64_t group_len,
+                            int64_t n, double *out, void *stream);
+
+/* ---------------------------------------------------------------------------------
  * derived.calc_dz (src/momlevel/derived.py:249-325): dz_out[z,i] from z_i[nz+1] and
  * depth[plane] (NaN depth -> 0).  has_bottom=0 ignores `bottom`.  fraction != 0
  * returns the cell fraction (NaN where dz or the cell thickness is 0).

@@ -62,6 +62,7 @@ SIGNATURES = {
     "mlx_nansum_workspace_bytes": (_sz, [_i64]),
     "mlx_nansum": (_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
     "mlx_masso": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "mlx_group_weighted_mean": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "mlx_calc_dz": (_int, [_vp, _vp, _i64, _i64, _dbl, _dbl, _int, _int, _vp, _vp]),
     "mlx_synth_field": (
         _int,

@@ -278,6 +278,25 @@ def masso(rho, vol):
     return out
 
 
+def group_weighted_mean(x, w, group_len, out=None):
+    """Per-group weighted mean over the leading axis (annual_average's arithmetic): x (nt, ...)
+    with nt = ngroups*group_len, w (nt,) -> (ngroups, ...); NaNs carry no weight."""
+    require_device()
+    x = _f64(x, x.device)
+    w = _f64(w, x.device).reshape(-1)
+    nt = x.shape[0]
+    if nt % group_len or w.numel() != nt:
+        raise ValueError("the time axis must hold whole groups and one weight per step")
+    ngroups = nt // group_len
+    n = x[0].numel()
+    if out is None:
+        out = torch.empty((ngroups,) + tuple(x.shape[1:]), dtype=torch.float64, device=x.device)
+    rc = _lib.load().mlx_group_weighted_mean(_ptr(x), _ptr(w), ngroups, group_len, n, _ptr(out),
+                                             _stream())
+    _lib.check(rc, "mlx_group_weighted_mean")
+    return out
+
+
 def calc_dz(z_i, depth, top=0.0, bottom=None, fraction=False):
     """derived.calc_dz core on device -> (nz, ny, nx)."""
     require_device()

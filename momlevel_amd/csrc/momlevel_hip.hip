@@ -523,6 +523,35 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
   }
 }
 
+// util.annual_average core (util.py:85-92): weighted mean over groups of L consecutive steps.
+// grid = (ceil(n/(kBlock*VEC)), ngroups); streams x once, 16-byte nt loads when VEC == 2.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_group_weighted_mean(const double* __restrict__ x,
+                                                                const double* __restrict__ w,
+                                                                int64_t L, int64_t n,
+                                                                double* __restrict__ out) {
+  const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
+  if (i + VEC > n) return;
+  const int64_t g = blockIdx.y;
+  double num[VEC], den[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) num[k] = den[k] = 0.0;
+  for (int64_t j = 0; j < L; ++j) {
+    const double wj = w[g * L + j];
+    const Pack<double, VEC> v = load_pack<double, VEC, true>(x + (g * L + j) * n + i);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const bool bad = is_nan(v.v[k]);
+      num[k] += (bad ? 0.0 : v.v[k]) * wj;
+      den[k] += (bad ? 0.0 : 1.0) * wj;
+    }
+  }
+  Pack<double, VEC> r;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) r.v[k] = num[k] / ((den[k] != 0.0) ? den[k] : canonical_nan());
+  store_pack<VEC, true>(out + g * n + i, r);
+}
+
 // derived.calc_dz, derived.py:295-323 with explicit top/bottom/fraction
 __global__ __launch_bounds__(kBlock) void k_calc_dz(const double* __restrict__ z_i,
                                                     const double* __restrict__ depth, int64_t nz,
@@ -927,6 +956,24 @@ int mlx_masso(const double* rho, const double* vol, int64_t nt, int64_t n3, int6
   hipLaunchKernelGGL(mlx::k_reduce_rows, dim3((unsigned)nt), dim3(mlx::kBlock), 0, st,
                      (const double*)workspace, nb, masso_out);
   return hip_status(hipGetLastError(), "mlx_masso launch");
+}
+
+int mlx_group_weighted_mean(const double* x, const double* w, int64_t ngroups, int64_t group_len,
+                            int64_t n, double* out, void* stream) {
+  if (!x || !w || !out) return fail(MLX_E_NULL, "x, w, out must not be NULL");
+  if (ngroups <= 0 || group_len <= 0 || n <= 0 || ngroups > 65535)
+    return fail(MLX_E_SHAPE, "need 0 < ngroups <= 65535, group_len > 0, n > 0");
+  hipStream_t st = (hipStream_t)stream;
+  if (n % 2 == 0 && aligned(x, 16) && aligned(out, 16)) {
+    dim3 grid((unsigned)ceil_div(n, (int64_t)mlx::kBlock * 2), (unsigned)ngroups);
+    hipLaunchKernelGGL(mlx::k_group_weighted_mean<2>, grid, dim3(mlx::kBlock), 0, st, x, w,
+                       group_len, n, out);
+  } else {
+    dim3 grid((unsigned)ceil_div(n, (int64_t)mlx::kBlock), (unsigned)ngroups);
+    hipLaunchKernelGGL(mlx::k_group_weighted_mean<1>, grid, dim3(mlx::kBlock), 0, st, x, w,
+                       group_len, n, out);
+  }
+  return hip_status(hipGetLastError(), "k_group_weighted_mean launch");
 }
 
 int mlx_calc_dz(const double* z_i, const double* depth, int64_t nz, int64_t plane, double top,

@@ -355,8 +355,13 @@ def global_masso_variants(T, S, T0, S0, vol0, pres, variants, eos="wright", f32_
 
 def local_steric_variants(T, S, T0, S0, rho0, vol0, pres, rhozero, variants, z_i=None,
                           deptho=None, dz=None, eos="wright", f32_mode="faithful",
-                          want_delta_rho=True, out_host=None, steps=None):
-    """{variant: (delta_rho, eta)}; theta/S chunks are uploaded once and reused."""
+                          want_delta_rho=True, out_host=None, steps=None, annual_weights=None):
+    """{variant: (delta_rho, eta)}; theta/S chunks are uploaded once and reused.
+
+    ``annual_weights`` (nt,), nt a multiple of 12, whole years back to back: the days-in-month
+    weighted annual means (util.annual_average) are taken ON THE DEVICE, chunk by chunk, so only
+    1/12 of delta_rho / eta is ever stored or copied back; the outputs are (nt/12, ...).
+    """
     dev = device_of(T, S, rho0, vol0)
     vol0 = to_device(vol0, dev, torch.float64)
     rho0 = to_device(rho0, dev, torch.float64)
@@ -376,31 +381,54 @@ def local_steric_variants(T, S, T0, S0, rho0, vol0, pres, rhozero, variants, z_i
     if out_host is None:
         out_host = not (_is_device(T) or _is_device(S))
     n_out = len(variants)
-    extra = n_out * nz * ny * nx * 8 if (want_delta_rho and out_host) else 0
+    annual = annual_weights is not None
+    extra = n_out * nz * ny * nx * 8 if (want_delta_rho and (out_host or annual)) else 0
     Ts, Ss = _streamed_pair(variants, T, S, T0, S0)
+    if annual:
+        if nt % 12:
+            raise ValueError("annual means need whole years (12 steps each)")
+        w_dev = to_device(np.asarray(annual_weights, dtype=np.float64), dev, torch.float64)
+        # whole years per chunk; device-resident inputs are chunked too (delta_rho of the full
+        # record would not fit beside them)
+        per_step = extra + 2 * nz * ny * nx * 8
+        if steps is None:
+            steps = chunk_steps(nt, per_step, dev)
+        steps = max(12, (int(steps) // 12) * 12)
     chunks = TimeChunks(Ts, Ss, dev, steps=steps, extra_bytes_per_step=extra)
+    nt_out = nt // 12 if annual else nt
 
     def alloc(shape):
         return _host_output(shape) if out_host else torch.empty(shape, dtype=torch.float64,
                                                                 device=dev)
 
-    eta = {v: alloc((nt, ny, nx)) for v in variants}
-    drho = {v: (alloc((nt, nz, ny, nx)) if want_delta_rho else None) for v in variants}
+    eta = {v: alloc((nt_out, ny, nx)) for v in variants}
+    drho = {v: (alloc((nt_out, nz, ny, nx)) if want_delta_rho else None) for v in variants}
     d2h = torch.cuda.Stream(device=dev) if out_host else None
     main = torch.cuda.current_stream(dev)
     for t0, t1, Tc, Sc in chunks:
+        o0, o1 = (t0 // 12, t1 // 12) if annual else (t0, t1)
         for v in variants:
             Tv, Sv = _variant_operands(v, Tc, Sc, T0, S0)
             kw = dict(dz=dz, z_i=z_i, deptho=deptho, eos=eos, f32_mode=f32_mode,
                       want_delta_rho=want_delta_rho)
-            if out_host:
+            if annual:  # K2 on the chunk, then the fused annual-mean epilogue on the device
                 d, e = core.steric_local(Tv, Sv, rho0m, surface, pres, neg_inv, **kw)
+                e = core.group_weighted_mean(e, w_dev[t0:t1], 12,
+                                             out=None if out_host else eta[v][o0:o1])
+                if want_delta_rho:
+                    d = core.group_weighted_mean(d, w_dev[t0:t1], 12,
+                                                 out=None if out_host else drho[v][o0:o1])
+                if not out_host:
+                    continue
+            if out_host:
+                if not annual:
+                    d, e = core.steric_local(Tv, Sv, rho0m, surface, pres, neg_inv, **kw)
                 d2h.wait_stream(main)
                 with torch.cuda.stream(d2h):
-                    torch.from_numpy(eta[v][t0:t1]).copy_(e, non_blocking=True)
+                    torch.from_numpy(eta[v][o0:o1]).copy_(e, non_blocking=True)
                     e.record_stream(d2h)
                     if want_delta_rho:
-                        torch.from_numpy(drho[v][t0:t1]).copy_(d, non_blocking=True)
+                        torch.from_numpy(drho[v][o0:o1]).copy_(d, non_blocking=True)
                         d.record_stream(d2h)
             else:
                 core.steric_local(Tv, Sv, rho0m, surface, pres, neg_inv,

@@ -29,7 +29,13 @@ from .reference import (
     pressure_operand,
     set_reference_masso,
 )
-from .util import annual_average, default_coords, eos_func_from_str, validate_dataset
+from .util import (
+    AnnualPlan,
+    annual_average,
+    default_coords,
+    eos_func_from_str,
+    validate_dataset,
+)
 
 __all__ = ["halosteric", "steric", "steric_variants", "thermosteric"]
 
@@ -83,8 +89,10 @@ def _global_results(ops, reference, variants, dtype, tcoord, coords_for, deferre
     return out
 
 
-def _local_results(ops, dset, reference, variants, dtype, rhozero, names, cdims3, coords_for):
-    """steric.py:150-166 -- delta_rho and the column integral from K2."""
+def _local_results(ops, dset, reference, variants, dtype, rhozero, names, cdims3, coords_for,
+                   plan=None):
+    """steric.py:150-166 -- delta_rho and the column integral from K2.  ``plan`` (an
+    util.AnnualPlan): the annual means are taken on the device, fused behind K2."""
     T, S, T0, S0, vol0, p, eos = ops
     tcoord, zcoord, zbounds = names
     hdims = cdims3[1:]
@@ -97,8 +105,16 @@ def _local_results(ops, dset, reference, variants, dtype, rhozero, names, cdims3
     fields = engine.local_steric_variants(
         T, S, T0, S0, reference["rho"].transpose(*cdims3).data, vol0, p, rhozero, variants,
         z_i=dset[zbounds].data, deptho=deptho.data, eos=eos, f32_mode=_f32_mode(),
-        want_delta_rho=want_delta_rho,
+        want_delta_rho=want_delta_rho, annual_weights=None if plan is None else plan.weights,
     )
+    if plan is not None:  # the results carry the mid-year time axis (util.py:93-105)
+        inner = coords_for
+
+        def coords_for(dims):  # noqa: F811
+            c = inner(dims)
+            if tcoord in c:
+                c[tcoord] = plan.time
+            return c
     out = {}
     for v in variants:
         delta_rho, sealevel = fields[v]
@@ -159,11 +175,16 @@ def _steric_many(dset, variants, reference, coord_names, varname_map, rhozero, p
         pressure_operand(pres, tcoord, cdims3),
         equation_of_state.lower(),
     )
+    plan = None
+    if annual and domain != "global":
+        plan = AnnualPlan(dset[tcoord], tcoord)  # asserts 12 steps per year (util.py:85)
+        if not plan.contiguous:
+            plan = None  # unusual time axis: average on the host afterwards
     if domain == "global":
         results = _global_results(ops, reference, variants, dtype, tcoord, coords_for, deferred)
     else:
         results = _local_results(ops, dset, reference, variants, dtype, rhozero, names, cdims3,
-                                 coords_for)
+                                 coords_for, plan)
 
     for variant, result in results.items():
         result[variant].attrs.update(
@@ -174,7 +195,7 @@ def _steric_many(dset, variants, reference, coord_names, varname_map, rhozero, p
         for var in set(result.coords).union(result.dims):
             if var in dset.variables and var in result.variables:
                 result[var].attrs.update(dset[var].attrs)
-        if annual:
+        if annual and plan is None:
             results[variant] = annual_average(result)
     return results, reference
 

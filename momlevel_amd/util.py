@@ -165,26 +165,44 @@ def _annual_mean_array(values, years, weights):
     return np.stack(out, axis=0)
 
 
+class AnnualPlan:
+    """Calendar bookkeeping of annual_average for one time coordinate."""
+
+    def __init__(self, time_da, tcoord):
+        from .cftime_lite import year_midpoint
+
+        time_values = list(time_da.values)
+        calendar = time_values[0].calendar
+        self.years, self.weights = _annual_weights(time_values)
+        self.year_list = sorted(set(self.years.tolist()))
+        for yr in self.year_list:
+            assert int(np.sum(self.years == yr)) == 12  # util.py:85
+        new_time = [year_midpoint(int(y), calendar) for y in self.year_list]
+        self.time = DataArray(np.array(new_time, dtype=object), (tcoord,), None, time_da.attrs,
+                              tcoord)
+        # whole years stored back to back in ascending order: the device kernel's layout
+        self.contiguous = bool(np.array_equal(self.years, np.repeat(self.year_list, 12)))
+
+
 def annual_average(xobj, tcoord="time"):
     """Days-in-month weighted annual means (util.py:49-119).
 
     Accepts a labelled Dataset or DataArray; asserts 12 steps per year; the new
     time axis holds the mid-points of the years.
     """
-    from .cftime_lite import year_midpoint
-
-    time_values = list(xobj[tcoord].values)
-    calendar = time_values[0].calendar
-    years, weights = _annual_weights(time_values)
-    new_time = [year_midpoint(int(y), calendar) for y in sorted(set(years.tolist()))]
-    tattrs = xobj[tcoord].attrs
-    time_da = DataArray(np.array(new_time, dtype=object), (tcoord,), None, tattrs, tcoord)
+    plan = AnnualPlan(xobj[tcoord], tcoord)
+    years, weights, time_da = plan.years, plan.weights, plan.time
 
     def avg(da):
         if tcoord not in da.dims:
             return da
         moved = da.transpose(tcoord, ...)
-        res = _annual_mean_array(moved.values.astype(np.float64), years, weights)
+        if moved.is_device and plan.contiguous:  # device-resident data: mlx_group_weighted_mean
+            from . import core
+
+            res = core.group_weighted_mean(moved.data.contiguous(), weights, 12)
+        else:
+            res = _annual_mean_array(moved.values.astype(np.float64), years, weights)
         coords = {k: v for k, v in moved.coords.items() if tcoord not in v.dims}
         coords[tcoord] = time_da
         out = DataArray(res, moved.dims, coords, da.attrs, da.name)

@@ -372,3 +372,49 @@ def test_delta_rho_can_be_elided(monkeypatch):
     res, _ = steric(d)
     assert "delta_rho" not in res
     assert_bit_equal(res["steric"].values, base["steric"].values)
+
+
+def test_annual_means_fused_on_device_match_the_oracle(monkeypatch):
+    """annual=True, domain='local': the days-in-month weighted means are taken on the device behind
+    K2 (mlx_group_weighted_mean), 12-step chunks; bit-identical to the host formula."""
+    from momlevel_amd import engine
+
+    od = o.generate_test_data(start_year=1983, nyears=2, calendar="julian")
+    ores, _ = o.steric(od["thetao"], od["so"], od["volcello"], od["areacello"], od["z_l"],
+                       od["z_i"], od["deptho"])
+    st = o.annual_average(ores["steric"], od["time_year"], od["time_days_in_month"])
+    dr = o.annual_average(ores["delta_rho"], od["time_year"], od["time_days_in_month"])
+    from momlevel_amd import core
+
+    calls = []
+    real = core.group_weighted_mean
+
+    def spy(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+
+    monkeypatch.setattr(core, "group_weighted_mean", spy)
+    monkeypatch.setattr(engine, "chunk_steps", lambda nt, b, dev, budget_bytes=None: 12)
+    res, _ = steric(dset3, annual=True)
+    assert calls, "the fused device epilogue was not used"
+    assert len(res["time"]) == 2 and res["time"].values[1].year == 1984
+    assert_bit_equal(res["steric"].values, st, "annual steric")
+    assert_bit_equal(res["delta_rho"].values, dr, "annual delta_rho")
+    assert res["steric"].dims == ("time", "yh", "xh")
+    gres, _ = steric(dset3, annual=True, domain="global")  # tiny: host formula
+    assert len(gres["time"]) == 2 and gres["steric"].dims == ("time",)
+
+
+def test_annual_average_of_device_resident_results():
+    d = dset3.copy()
+    for k in ("thetao", "so", "volcello"):
+        d[k] = DataArray(torch.from_numpy(dset3[k].values).cuda(), dset3[k].dims)
+    res, _ = steric(d, annual=True)
+    base, _ = steric(dset3, annual=True)
+    assert res["steric"].is_device
+    assert_bit_equal(res["steric"].values, base["steric"].values)
+    assert_bit_equal(res["delta_rho"].values, base["delta_rho"].values)
+    monthly, _ = steric(d)  # util.annual_average on device-backed monthly results
+    ann = util.annual_average(monthly)
+    assert ann["steric"].is_device
+    assert_bit_equal(ann["steric"].values, base["steric"].values)
