@@ -107,26 +107,24 @@ def _local_results(ops, dset, reference, variants, dtype, rhozero, names, cdims3
         z_i=dset[zbounds].data, deptho=deptho.data, eos=eos, f32_mode=_f32_mode(),
         want_delta_rho=want_delta_rho, annual_weights=None if plan is None else plan.weights,
     )
-    if plan is not None:  # the results carry the mid-year time axis (util.py:93-105)
-        inner = coords_for
+    def result_coords(dims):
+        coords = coords_for(dims)
+        if plan is not None and tcoord in coords:
+            coords[tcoord] = plan.time  # the mid-year time axis of util.py:93-105
+        return coords
 
-        def coords_for(dims):  # noqa: F811
-            c = inner(dims)
-            if tcoord in c:
-                c[tcoord] = plan.time
-            return c
     out = {}
     for v in variants:
         delta_rho, sealevel = fields[v]
         result = Dataset()
         if want_delta_rho:
             result["delta_rho"] = DataArray(
-                delta_rho, cdims4, coords_for(cdims4),
+                delta_rho, cdims4, result_coords(cdims4),
                 {"long_name": "change in in situ density from reference state",
                  "units": "kg m-3"},
             )
             result["delta_rho"].encoding["dtype"] = dtype
-        result[v] = DataArray(sealevel, (tcoord,) + hdims, coords_for((tcoord,) + hdims))
+        result[v] = DataArray(sealevel, (tcoord,) + hdims, result_coords((tcoord,) + hdims))
         out[v] = result
     return out
 
