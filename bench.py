@@ -39,6 +39,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from momlevel_amd import core, engine, parallel, synthetic  # noqa: E402
 
+# BASELINE.json's metric string, verbatim
+METRIC = "Mcells/s for fused Wright-EOS+steric at 1440\u00d71080\u00d775; % HBM roofline"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_CELL = 16    # theta 8 + S 8; vol0/p are amortised over the time loop
 GRID = (75, 1080, 1440)
@@ -235,7 +237,7 @@ def main():
     if rank == 0:
         layout = {1: "1x1", 2: "1x2", 4: "2x2", 8: "2x4"}.get(world, f"1x{world}")
         line = {
-            "metric": "Mcells/s for fused Wright-EOS+steric at 1440x1080x75; % HBM roofline",
+            "metric": METRIC,
             "value": round(cells_job * a.steps / elapsed / 1e6, 1),
             "unit": "Mcells/s",
             "n_gpus": world,
