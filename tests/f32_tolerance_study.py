@@ -58,7 +58,8 @@ def main():
     T = core.synth_field(shape, torch.float32, field_id=1, lo=-2.0, scale=34.0, **kw)
     S = core.synth_field(shape, torch.float32, field_id=2, lo=30.0, scale=10.0, **kw)
     cells = nt * nz * ny * nx
-    out = {"grid_xyz": [nx, ny, nz], "nt": nt, "dtype_in": "float32", "timings": {}, "errors": {}}
+    out = {"grid_xyz": [nx, ny, nz], "nt": nt, "dtype_in": "float32", "timings": {}, "errors": {},
+           "product_defaults": {"skip_dry": core.skip_dry_default()}}
 
     for mode in ("faithful", "upcast"):
         for name, Tv, Sv, bpc in (("steric", T, S, 8), ("thermosteric", T, S[0], 4),
