@@ -285,3 +285,27 @@ def test_empty_record_is_rejected_cleanly():
     rc = lib.mlx_steric_global(T.data_ptr(), S.data_ptr(), 0, vol0.data_ptr(), vol0.data_ptr(), 1,
                                0, 0, 3, 32, 96, 96, 0, ws.data_ptr(), ws.data_ptr(), 128, None)
     assert rc == -2  # MLX_E_SHAPE
+
+
+def test_very_long_record_on_a_tiny_grid():
+    """nt = 100 000 (grid.z = 3125 time chunks in K1, 6250 in K2) on a 2x3x4 grid."""
+    nt, nz, ny, nx = 100_000, 2, 3, 4
+    r = np.random.default_rng(9)
+    T = r.uniform(-2, 32, (nt, nz, ny, nx))
+    S = r.uniform(30, 40, (nt, nz, ny, nx))
+    vol = r.uniform(1e9, 1e11, (nz, ny, nx))
+    vol[0, 0, 0] = np.nan
+    pres = np.array([1.2e5, 9.0e6])
+    dT, dS, dvol = (torch.from_numpy(a).cuda() for a in (T, S, vol))
+    rho = o.calc_rho(T, S, pres)
+    masso = core.steric_global_masso(dT, dS, dvol, pres).cpu().numpy()
+    assert_rel(masso, o.calc_masso(rho, vol), 1e-13, "masso")
+    rho0m = core.fold_mask(torch.from_numpy(rho[0]).cuda(), dvol)
+    z_i = np.array([0.0, 12.0, 900.0])
+    dep = r.uniform(0.0, 1000.0, (ny, nx))
+    drho, eta = core.steric_local(dT, dS, rho0m, dvol[0], pres, -1.0 / 1035.0, z_i=z_i, deptho=dep)
+    d = np.where(~np.isnan(vol), rho - rho[0], np.nan)
+    assert_bit_equal(drho.cpu().numpy(), d, "delta_rho")
+    dz = o.calc_dz(0.5 * (z_i[1:] + z_i[:-1]), z_i, dep)
+    e = np.where(~np.isnan(vol[0]), (-1.0 / 1035.0) * np.nansum(dz * d, axis=1), np.nan)
+    assert_bit_equal(eta.cpu().numpy(), e, "eta")
