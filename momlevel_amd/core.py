@@ -269,12 +269,15 @@ def masso(rho, vol):
     else:
         raise ValueError("vol must be (n3,) or (nt, n3)")
     lib = _lib.load()
-    nbytes = lib.mlx_steric_global_workspace_bytes(nt, 1, n3)
-    ws = torch.empty(nbytes // 8, dtype=torch.float64, device=rho.device)
     out = torch.empty(nt, dtype=torch.float64, device=rho.device)
-    rc = lib.mlx_masso(_ptr(rho), _ptr(vol), nt, n3, vstride, _ptr(out), _ptr(ws), nbytes,
-                       _stream())
-    _lib.check(rc, "mlx_masso")
+    step = 32768  # the kernel's grid.y carries the time axis (<= 65535)
+    nbytes = lib.mlx_steric_global_workspace_bytes(min(nt, step), 1, n3)
+    ws = torch.empty(nbytes // 8, dtype=torch.float64, device=rho.device)
+    for t0 in range(0, nt, step):
+        t1 = min(t0 + step, nt)
+        rc = lib.mlx_masso(_ptr(rho[t0:t1]), _ptr(vol[t0:t1] if vstride else vol), t1 - t0, n3,
+                           vstride, _ptr(out[t0:t1]), _ptr(ws), nbytes, _stream())
+        _lib.check(rc, "mlx_masso")
     return out
 
 
