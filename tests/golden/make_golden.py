@@ -89,6 +89,16 @@ def main():
         out[f"f32_{fn}"] = getattr(ref, fn)(T32, S32, out["blk_p"])
         assert out[f"f32_{fn}"].dtype == np.float64
 
+    # (5) float32 with ONE field held at its first time level -- what steric.py:115-125 hands
+    # calc_rho for the thermosteric (S held) and halosteric (theta held) variants: numpy
+    # broadcasts the (nz,ny,nx) slab against the (nt,nz,ny,nx) field
+    out["f32_density_heldS"] = ref.density(T32, S32[0], out["blk_p"])
+    out["f32_density_heldT"] = ref.density(T32[0], S32, out["blk_p"])
+    out["f64_density_heldS"] = ref.density(out["blk_T"], out["blk_S"][0], out["blk_p"])
+    out["f64_density_heldT"] = ref.density(out["blk_T"][0], out["blk_S"], out["blk_p"])
+    for k in ("f32_density_heldS", "f32_density_heldT", "f64_density_heldS", "f64_density_heldT"):
+        assert out[k].dtype == np.float64 and out[k].shape == T32.shape
+
     # scalars of tests/test_wright.py:11-12,30-31,50-51,70-71,120-121
     out["scalar_args"] = np.array([18.0, 35.0, 200000.0])
     out["scalar_out"] = np.array(

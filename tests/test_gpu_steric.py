@@ -208,13 +208,42 @@ def test_land_masked_local_and_global(variant, shape):
     assert_rel(gref["masso"].values, ogref["masso"], RTOL_SUM, "masso0")
 
 
-def test_float32_inputs_match_numpy_mixed_precision():
-    d = _masked_dataset(dtype=np.float32)
-    res, ref = steric(d)
-    ores, oref = _oracle(d)
+@pytest.mark.parametrize("f32_mode", ["faithful", "upcast"])
+@pytest.mark.parametrize("shape", [(6, 9, 14, 20), (5, 4, 7, 9)])
+@pytest.mark.parametrize("variant", ["steric", "thermosteric", "halosteric"])
+def test_float32_inputs_match_numpy_mixed_precision(variant, shape, f32_mode, monkeypatch):
+    """float32 theta/S (the reference's usual input dtype), every variant, local AND global.
+    faithful: numpy's mixed precision on float32 arrays (eos/wright.py:44-48 with weak python-float
+    constants) -- bit for bit; upcast: float64 arithmetic on the float32 values.  The 14x20 plane
+    takes the float4 kernels (held-field hoisting in float32, eos_device.hpp), 7x9 the scalar ones."""
+    monkeypatch.setenv("MOMLEVEL_AMD_F32_MODE", f32_mode)
+    d = _masked_dataset(*shape, dtype=np.float32)
+    od = d
+    if f32_mode == "upcast":
+        od = d.copy()
+        for k in ("thetao", "so"):
+            od[k] = DataArray(d[k].values.astype(np.float64), d[k].dims)
+    res, ref = steric(d, variant=variant)
+    ores, oref = _oracle(od, variant=variant)
     assert_bit_equal(ref["rho"].values, oref["rho"], "rho0 from float32")
     assert_bit_equal(res["delta_rho"].values, ores["delta_rho"], "delta_rho from float32")
-    assert_bit_equal(res["steric"].values, ores["steric"], "eta from float32")
+    assert_bit_equal(res[variant].values, ores[variant], "eta from float32")
+    gres, gref = steric(d, variant=variant, domain="global")
+    ogres, ogref = _oracle(od, variant=variant, domain="global")
+    assert float(gres[variant][0]) == 0.0
+    assert_rel(gref["masso"].values, ogref["masso"], RTOL_SUM, "masso0 from float32")
+    href = float(gres["reference_height"])
+    assert np.allclose(gres[variant].values / href, ogres["expansion_coeff"], rtol=0, atol=1e-12)
+    # masso(t) itself, not only its logarithm
+    from momlevel_amd import core
+
+    T, S = d["thetao"].values, d["so"].values
+    Tv = torch.from_numpy(T if variant != "halosteric" else T[0]).cuda()
+    Sv = torch.from_numpy(S if variant != "thermosteric" else S[0]).cuda()
+    masso = core.steric_global_masso(Tv, Sv, torch.from_numpy(d["volcello"].values[0]).cuda(),
+                                     o.pressure_from_depth(d["z_l"].values),
+                                     f32_mode=f32_mode).cpu().numpy()
+    assert_rel(masso, ogres["masso"], RTOL_SUM, f"masso(t) float32 {variant}")
 
 
 def test_device_resident_inputs_give_device_outputs():

@@ -125,3 +125,56 @@ def test_large_host_arrays_are_chunked(monkeypatch):
     p4 = r.uniform(1e5, 5e7, (7, 5, 6, 10))
     assert_bit_equal(alpha(T, S, p4), o.wright_alpha(T, S, p4))
     assert_bit_equal(density(T, S[0], 2.0e5), o.wright_density(T, S[0], 2.0e5))
+
+
+# ---- held-field (thermosteric / halosteric) kernels vs the reference module's vectors ---------
+@pytest.mark.parametrize("f32_mode", ["faithful", "upcast"])
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("held", ["S", "T"])
+def test_held_field_kernels_match_reference_vectors(wright_vectors, held, prec, f32_mode):
+    """K1 / K2 with HOLD=2 (S held: thermosteric) and HOLD=1 (theta held: halosteric) hoist the
+    held field's share of al0/p0/lam out of the time loop (eos_device.hpp, held-field hoisting).
+    delta_rho + rho0 must reproduce eos/wright.py:44-48 on the broadcast operands bit for bit --
+    float64, and float32 in numpy's mixed precision (faithful); upcast is float64 arithmetic on
+    the float32 values."""
+    from momlevel_amd import core
+
+    if prec == "f64" and f32_mode == "upcast":
+        pytest.skip("f32_mode only matters for float32 inputs")
+    v = wright_vectors
+    T, S = (v["f32_T"], v["f32_S"]) if prec == "f32" else (v["blk_T"], v["blk_S"])
+    p = v["blk_p"]
+    if prec == "f32" and f32_mode == "upcast":
+        Tn, Sn = T.astype(np.float64), S.astype(np.float64)
+        ref = o.wright_density(Tn, Sn[0], p) if held == "S" else o.wright_density(Tn[0], Sn, p)
+        rho0 = o.wright_density(Tn[0], Sn[0], p)
+    else:
+        ref = v[f"{prec}_density_held{held}"]
+        rho0 = o.wright_density(T[0], S[0], p)
+    nt, nz, ny, nx = T.shape
+    dT, dS = torch.from_numpy(T).cuda(), torch.from_numpy(S).cuda()
+    Tv, Sv = (dT, dS[0]) if held == "S" else (dT[0], dS)
+    vol = np.random.default_rng(5).uniform(1e8, 1e12, (nz, ny, nx))
+    dvol = torch.from_numpy(vol).cuda()
+    pz = p.reshape(-1)
+    # K2: delta_rho = rho - rho0, elementwise -> bit-exact
+    rho0m = core.fold_mask(torch.from_numpy(rho0).cuda(), dvol)
+    z_i = np.concatenate([[0.0], np.cumsum(np.full(nz, 10.0))])
+    drho, eta = core.steric_local(Tv, Sv, rho0m, dvol[0], pz, -1.0 / 1035.0, z_i=z_i,
+                                  deptho=np.full((ny, nx), 1e4), f32_mode=f32_mode)
+    assert_bit_equal(drho.cpu().numpy(), ref - rho0, f"K2 held {held} {prec} {f32_mode}")
+    eta_ref = (-1.0 / 1035.0) * np.sum(10.0 * (ref - rho0), axis=1)
+    assert_bit_equal(eta.cpu().numpy(), eta_ref, f"K2 eta held {held} {prec} {f32_mode}")
+    # K1: masso(t) = sum(rho * vol) -- order of summation differs, 1e-12
+    masso = core.steric_global_masso(Tv, Sv, dvol, pz, f32_mode=f32_mode).cpu().numpy()
+    mref = np.sum(ref * vol, axis=(1, 2, 3))
+    assert np.max(np.abs(masso - mref) / mref) < 1e-12
+    # K1 with a ONE-HOT volcello (1.0 in one cell, NaN elsewhere): masso(t) is rho of that cell,
+    # so the hoisted arithmetic of the dwordx4 kernels is seen bit for bit through the reduction
+    for (z, j) in [(0, 0), (3, 17), (nz - 1, ny * nx - 1)]:
+        hot = np.full((nz, ny * nx), np.nan)
+        hot[z, j] = 1.0
+        for skip in (False, True):
+            one = core.steric_global_masso(Tv, Sv, torch.from_numpy(hot.reshape(nz, ny, nx)).cuda(),
+                                           pz, f32_mode=f32_mode, skip_dry=skip).cpu().numpy()
+            assert_bit_equal(one, ref.reshape(nt, nz, -1)[:, z, j], f"K1 one-hot held {held}")
