@@ -6,6 +6,7 @@ Same names, argument meaning and error behaviour as src/momlevel/util.py
 except the area sum of device-resident ``areacello`` (mlx_nansum).
 """
 
+import inspect
 import warnings
 
 import numpy as np
@@ -22,24 +23,37 @@ __all__ = [
 ]
 
 
+_COORD_DEFAULTS = (("t", "time"), ("z", "z_l"), ("zbounds", "z_i"))
+
+
 def default_coords(coord_names=None):
-    """Default coordinate names ``(tcoord, zcoord, zbounds)`` (util.py:199-224)."""
-    coord_names = {} if coord_names is None else coord_names
-    assert isinstance(coord_names, dict), "Coordinate mapping must be a dictionary."
-    zcoord = coord_names["z"] if "z" in coord_names.keys() else "z_l"
-    zbounds = coord_names["zbounds"] if "zbounds" in coord_names.keys() else "z_i"
-    tcoord = coord_names["t"] if "t" in coord_names.keys() else "time"
-    return (tcoord, zcoord, zbounds)
+    """``(tcoord, zcoord, zbounds)``: MOM6's ``("time", "z_l", "z_i")`` unless the mapping
+    overrides them under the keys ``"t"``, ``"z"``, ``"zbounds"`` (behaviour of util.py:199-224;
+    a non-dict mapping is an ``AssertionError`` there, and here)."""
+    mapping = coord_names if coord_names is not None else {}
+    if not isinstance(mapping, dict):
+        raise AssertionError("Coordinate mapping must be a dictionary.")
+    return tuple(mapping.get(key, fallback) for key, fallback in _COORD_DEFAULTS)
 
 
 def eos_func_from_str(eos_str, func_name="density"):
-    """Resolve ``"Wright"`` -> ``momlevel_amd.eos.wright.density`` (util.py:227-249)."""
-    assert isinstance(eos_str, str), "Expecting string for equation of state"
-    eos_str = eos_str.lower()
-    avail_eos = list(eos.__dict__.keys())
-    if eos_str not in avail_eos or eos_str.startswith("_"):
-        raise ValueError(f"Unknown equation of state: {eos_str}")
-    return eos.__dict__[eos_str].__dict__[func_name]
+    """The function ``func_name`` of the equation-of-state module named ``eos_str`` (any case):
+    ``"Wright"`` -> ``momlevel_amd.eos.wright.density``.  Unknown equation of state ->
+    ``ValueError("Unknown equation of state: ...")`` as util.py:227-249; a function the module does
+    not provide (the linear EOS has no alpha / beta here) is a ``ValueError`` too, not the bare
+    ``KeyError`` of the reference's ``__dict__`` lookup."""
+    if not isinstance(eos_str, str):
+        raise AssertionError("Expecting string for equation of state")
+    name = eos_str.lower()
+    module = None if name.startswith("_") else getattr(eos, name, None)
+    if not inspect.ismodule(module):
+        raise ValueError(f"Unknown equation of state: {name}")
+    func = getattr(module, func_name, None)
+    if not callable(func):
+        raise ValueError(
+            f"Equation of state '{name}' does not provide `{func_name}` in momlevel_amd"
+        )
+    return func
 
 
 def _area_sum(areacello):
@@ -52,91 +66,72 @@ def _area_sum(areacello):
 
 
 def validate_areacello(areacello, reference=3.6111092e14, tolerance=0.02):
-    """True if sum(areacello) is within +/-tolerance of the real ocean area (util.py:669-694)."""
-    error = (_area_sum(areacello) - reference) / reference
-    result = bool(np.abs(error) < tolerance)
-    return result
+    """Does ``areacello`` sum to the real ocean's surface (3.6111092e14 m2) within a relative
+    ``tolerance``?  Catches an unmasked field, e.g. the whole globe's area (util.py:669-694)."""
+    relative_error = (_area_sum(areacello) - reference) / reference
+    return bool(abs(relative_error) < tolerance)
+
+
+_FIELDS_4D = ("thetao", "so", "volcello")
+_FIELDS_2D = ("areacello", "deptho")
+_REFERENCE_SCALARS = ("masso", "volo", "rhoga")
+_REQUIRED = ("thetao", "so", "volcello", "areacello")
+_REQUIRED_IN_REFERENCE = ("rho", "volo", "masso", "rhoga")
+
+
+def _dataset_findings(dset, reference, additional_vars):
+    """Yield ``(severity, message)`` for every requirement ``dset`` does not meet, in the order
+    util.py:697-814 reports them.  severity "area" marks the one finding ``strict=False`` turns
+    into a warning."""
+    present = set(dset.variables)
+    extra = [] if additional_vars is None else (
+        list(additional_vars) if isinstance(additional_vars, list) else [additional_vars])
+    wanted = list(_REQUIRED) + extra + (list(_REQUIRED_IN_REFERENCE) if reference else [])
+    missing = [name for name in dict.fromkeys(wanted) if name not in present]
+    if missing:
+        yield "error", f"Reference dataset is missing variables: {missing}"
+
+    # (a reference dataset "cannot contain a time coordinate": the reference's test compares names
+    #  with unbound ``str.lower`` methods and can never fire, util.py:728-733 -- nothing to report)
+
+    nd, layout = (3, "(z,y,x)") if reference else (4, "t,z,y,x")
+    rank_rules = [(name, nd, f"Variable {name} must have exactly {nd} dimensions {layout}")
+                  for name in _FIELDS_4D]
+    rank_rules += [(name, 2, f"Variable {name} must have exactly 2 dimensions (y,x)")
+                   for name in _FIELDS_2D]
+    for name, rank, message in rank_rules:
+        if name in present and len(dset[name].dims) != rank:
+            yield "error", message
+
+    if "areacello" in present and not validate_areacello(dset["areacello"]):
+        yield "area", "Variable `areacello` field is out of range. It may not be masked."
+
+    if reference:
+        # the reference words the `rho` finding with the name `areacello` (util.py:800);
+        # the text is what a user of either package sees, so it is kept
+        if "rho" in present and len(dset["rho"].dims) != 3:
+            yield "error", "Variable areacello must have exactly 3 dimensions (z,y,x)"
+        for name in _REFERENCE_SCALARS:
+            if name in present and len(dset[name].dims) != 0:
+                yield "error", f"Variable {name} must be a scalar"
 
 
 def validate_dataset(dset, reference=False, strict=True, additional_vars=None):
-    """Presence / rank checks of an input or reference dataset (util.py:697-814).
+    """Is ``dset`` a usable input (or, ``reference=True``, reference-state) dataset?
 
-    Errors are collected, printed, and one ``ValueError("Errors found in dataset.")``
-    is raised.  ``strict=False`` only downgrades the areacello range check to a
-    ``UserWarning`` (util.py:783-792).
+    Same observable behaviour as util.py:697-814: required variables present, fields of the right
+    rank, ``areacello`` summing to the real ocean's area.  All findings are printed, then ONE
+    ``ValueError("Errors found in dataset.")`` is raised; ``strict=False`` downgrades only the
+    areacello range finding to a ``UserWarning``.  Returns None.
     """
-    dset_varlist = list(dset.variables)
-    exceptions = []
-
-    # (the reference's "no time coordinate" check compares against unbound methods and
-    #  can never fire -- util.py:728-733; reproduced as a no-op)
-
-    expected_varlist = ["thetao", "so", "volcello", "areacello"]
-    if additional_vars is not None:
-        additional_vars = (
-            [additional_vars] if not isinstance(additional_vars, list) else additional_vars
-        )
-    else:
-        additional_vars = []
-    expected_varlist = expected_varlist + additional_vars
-
-    reference_varlist = ["rho", "volo", "masso", "rhoga"]
-    expected_varlist = expected_varlist + reference_varlist if reference else expected_varlist
-
-    missing = list(set(expected_varlist) - set(dset_varlist))
-    try:
-        assert len(missing) == 0, f"Reference dataset is missing variables: {missing}"
-    except AssertionError as e:
-        exceptions.append(e)
-
-    ranks = (3, "(z,y,x)") if reference else (4, ("t,z,y,x"))
-    for var in ["thetao", "so", "volcello"]:
-        if var in dset.variables:
-            try:
-                assert (
-                    len(dset[var].dims) == ranks[0]
-                ), f"Variable {var} must have exactly {ranks[0]} dimensions {ranks[1]}"
-            except AssertionError as e:
-                exceptions.append(e)
-
-    for var in ["areacello", "deptho"]:
-        if var in dset.variables:
-            try:
-                assert (
-                    len(dset[var].dims) == 2
-                ), f"Variable {var} must have exactly 2 dimensions (y,x)"
-            except AssertionError as e:
-                exceptions.append(e)
-
-    if "areacello" in dset.variables:
-        try:
-            assert validate_areacello(
-                dset["areacello"]
-            ), "Variable `areacello` field is out of range. It may not be masked."
-        except AssertionError as e:
-            if not strict:
-                warnings.warn(str(e))
-            else:
-                exceptions.append(e)
-
-    if reference:
-        if "rho" not in missing:
-            try:
-                assert (
-                    len(dset["rho"].dims) == 3
-                ), "Variable areacello must have exactly 3 dimensions (z,y,x)"
-            except AssertionError as e:
-                exceptions.append(e)
-        for var in ["masso", "volo", "rhoga"]:
-            if var not in missing:
-                try:
-                    assert len(dset[var].dims) == 0, f"Variable {var} must be a scalar"
-                except AssertionError as e:
-                    exceptions.append(e)
-
-    if len(exceptions) > 0:
-        for e in exceptions:
-            print(e)
+    fatal = []
+    for severity, message in _dataset_findings(dset, reference, additional_vars):
+        if severity == "area" and not strict:
+            warnings.warn(message)
+        else:
+            fatal.append(message)
+    if fatal:
+        print("\n".join(fatal))
         raise ValueError("Errors found in dataset.")
 
 
@@ -163,6 +158,12 @@ def _annual_mean_array(values, years, weights):
         den = np.sum(np.where(np.isnan(x), 0.0, 1.0) * w, axis=0)
         out.append(num / np.where(den != 0, den, np.nan))
     return np.stack(out, axis=0)
+
+
+def _np_dtype(var):
+    """numpy dtype of a labelled variable WITHOUT copying device data to the host."""
+    dt = var.data.dtype
+    return np.dtype(str(dt).replace("torch.", "")) if not isinstance(dt, np.dtype) else dt
 
 
 class AnnualPlan:
@@ -216,7 +217,7 @@ def annual_average(xobj, tcoord="time"):
                 result._set(name, c, is_coord=True)
         result._set(tcoord, time_da, is_coord=True)
         for name, var in xobj.data_vars.items():
-            if var.values.dtype.kind not in "fiu":
+            if np.dtype(_np_dtype(var)).kind not in "fiu":
                 continue  # non-numeric variables are skipped (util.py:79-84)
             result[name] = avg(var)
         return result

@@ -66,6 +66,48 @@ def test_validate_dataset_8():
         util.validate_dataset(dset.copy(), additional_vars=["foo", "bar"])
 
 
+def test_eos_func_from_str_errors():
+    """unknown EOS -> ValueError (util.py:247); a function the EOS module lacks (linear alpha/beta,
+    eos/linear.py:61-162 is out of scope here) -> ValueError naming it, not a bare KeyError"""
+    with pytest.raises(ValueError, match="Unknown equation of state: teos10"):
+        util.eos_func_from_str("TEOS10")
+    with pytest.raises(ValueError, match="Unknown equation of state"):
+        util.eos_func_from_str("_dispatch")
+    with pytest.raises(ValueError, match="linear.*alpha"):
+        util.eos_func_from_str("linear", func_name="alpha")
+    with pytest.raises(AssertionError):
+        util.eos_func_from_str(3)
+    with pytest.raises(AssertionError):
+        util.default_coords(["time"])
+
+
+def test_validate_dataset_reports_every_finding(capsys):
+    """all findings are printed, one ValueError raised (util.py:808-814); messages as the reference"""
+    t = dset.copy().drop_vars(["so"])
+    t["areacello"] = t["areacello"] * 1.3
+    t["thetao"] = t["thetao"].isel({"time": 0})
+    with pytest.raises(ValueError, match="Errors found in dataset."):
+        util.validate_dataset(t, additional_vars="deptho_missing")
+    out = capsys.readouterr().out.strip().splitlines()
+    assert out == [
+        "Reference dataset is missing variables: ['so', 'deptho_missing']",
+        "Variable thetao must have exactly 4 dimensions t,z,y,x",
+        "Variable `areacello` field is out of range. It may not be masked.",
+    ]
+    ref = dset.copy()
+    for k in ("thetao", "so", "volcello"):
+        ref[k] = ref[k].isel({"time": 0})
+    ref["rho"] = dset["thetao"]
+    for k in ("volo", "masso"):
+        ref[k] = ref["areacello"].sum()
+    ref["rhoga"] = dset["areacello"]
+    with pytest.raises(ValueError):
+        util.validate_dataset(ref, reference=True)
+    out = capsys.readouterr().out.strip().splitlines()
+    assert out == ["Variable areacello must have exactly 3 dimensions (z,y,x)",
+                   "Variable rhoga must be a scalar"]
+
+
 def test_eos_func_from_str():
     assert util.eos_func_from_str("Wright") is m.eos.wright.density
     assert util.eos_func_from_str("wright", func_name="alpha") is m.eos.wright.alpha
