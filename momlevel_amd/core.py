@@ -2,7 +2,8 @@
 
 torch is used only as the device-array container (allocation, streams); every
 number is produced by libmomlevel_hip.so.  All functions enqueue on torch's
-current stream and return device tensors without synchronising.
+current stream OF THE DEVICE THAT OWNS THE OPERANDS (which need not be torch's current
+device) and return device tensors without synchronising.
 
 Layout: ``(time, z_l, yh, xh)`` C-contiguous, x fastest.  A
 ``(z_l, yh, xh)`` tensor passed where a 4-D field is expected is broadcast over
@@ -37,8 +38,16 @@ def require_device():
         )
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+def _stream(device):
+    """Raw hipStream_t of torch's current stream ON ``device`` (not on the current device: the
+    operands may live on another GPU of the node)."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _on(device):
+    """Context for a launch: kernels are enqueued with ``device`` current, so that the library's
+    hipLaunchKernelGGL targets the GPU that owns the operands whatever torch's current device is."""
+    return torch.cuda.device(device)
 
 
 def _ptr(t):
@@ -80,6 +89,9 @@ def _pair(T, S, f32_mode):
     """Common shape logic of the (thetao, so) pair."""
     if T.dtype != S.dtype:
         raise TypeError("thetao and so must share a dtype")
+    if isinstance(T, torch.Tensor) and isinstance(S, torch.Tensor) and T.device != S.device:
+        raise ValueError(f"thetao is on {T.device} but so on {S.device}: operands of one call "
+                         "must live on one GPU")
     shape3 = tuple(T.shape[-3:])
     nz, ny, nx = shape3
     T, ntT, sT = _field(T, nz, ny, nx, "thetao")
@@ -102,8 +114,10 @@ def _pressure(p, nt, nz, ny, nx, device, allow4d):
     p = _f64(p, device)
     if p.numel() == 1:
         return p.reshape(1), P_SCALAR
+    while p.dim() > 3 and p.shape[0] == 1:  # (1,nz,1,1): calc_rho's 4-D broadcast of a z profile
+        p = p[0]
     shape = tuple(p.shape)
-    if shape in ((nz,), (nz, 1, 1)):
+    if shape in ((nz,), (nz, 1, 1)):  # NB at THIS level a bare (nz,) is a z profile by contract
         return p.reshape(nz), P_ZPROF
     if shape == (nz, ny, nx):
         return p, P_FULL3D
@@ -125,10 +139,11 @@ def eos_map(T, S, p, eos="wright", func="density", f32_mode="faithful"):
     T, S, nt, nz, ny, nx, sT, sS, dt, squeeze = _pair(T, S, f32_mode)
     pt, p_mode = _pressure(p, nt, nz, ny, nx, T.device, allow4d=True)
     out = torch.empty((nt, nz, ny, nx), dtype=torch.float64, device=T.device)
-    rc = _lib.load().mlx_eos_map(
-        _ptr(T), _ptr(S), dt, _ptr(pt), p_mode, EOS_IDS[eos.lower()], FUNC_IDS[func],
-        nt, nz, ny * nx, sT, sS, _ptr(out), _stream(),
-    )
+    with _on(T.device):
+        rc = _lib.load().mlx_eos_map(
+            _ptr(T), _ptr(S), dt, _ptr(pt), p_mode, EOS_IDS[eos.lower()], FUNC_IDS[func],
+            nt, nz, ny * nx, sT, sS, _ptr(out), _stream(T.device),
+        )
     _lib.check(rc, "mlx_eos_map")
     return out[0] if squeeze else out
 
@@ -139,10 +154,11 @@ def inverse_barometer(T, S, p, gravity=9.8, eos="wright", f32_mode="faithful"):
     T, S, nt, nz, ny, nx, sT, sS, dt, squeeze = _pair(T, S, f32_mode)
     pt, p_mode = _pressure(p, nt, nz, ny, nx, T.device, allow4d=True)
     out = torch.empty((nt, nz, ny, nx), dtype=torch.float64, device=T.device)
-    rc = _lib.load().mlx_inverse_barometer(
-        _ptr(T), _ptr(S), dt, _ptr(pt), p_mode, EOS_IDS[eos.lower()], float(gravity),
-        nt, nz, ny * nx, sT, sS, _ptr(out), _stream(),
-    )
+    with _on(T.device):
+        rc = _lib.load().mlx_inverse_barometer(
+            _ptr(T), _ptr(S), dt, _ptr(pt), p_mode, EOS_IDS[eos.lower()], float(gravity),
+            nt, nz, ny * nx, sT, sS, _ptr(out), _stream(T.device),
+        )
     _lib.check(rc, "mlx_inverse_barometer")
     return out[0] if squeeze else out
 
@@ -175,15 +191,17 @@ def steric_global_masso(T, S, vol0, p, eos="wright", f32_mode="faithful", events
     nbytes = lib.mlx_steric_global_workspace_bytes(nt, nz, ny * nx)
     ws = torch.empty(nbytes // 8, dtype=torch.float64, device=T.device)
     out = torch.empty(nt, dtype=torch.float64, device=T.device)
-    if events is not None:
-        events[0].record()
-    rc = lib.mlx_steric_global(
-        _ptr(T), _ptr(S), dt, _ptr(vol0), _ptr(pt), p_mode, EOS_IDS[eos.lower()],
-        nt, nz, ny * nx, sT, sS, _lib.FLAG_SKIP_DRY if skip_dry else 0,
-        _ptr(out), _ptr(ws), nbytes, _stream(),
-    )
-    if events is not None:
-        events[1].record()
+    with _on(T.device):
+        stream = torch.cuda.current_stream(T.device)
+        if events is not None:
+            events[0].record(stream)
+        rc = lib.mlx_steric_global(
+            _ptr(T), _ptr(S), dt, _ptr(vol0), _ptr(pt), p_mode, EOS_IDS[eos.lower()],
+            nt, nz, ny * nx, sT, sS, _lib.FLAG_SKIP_DRY if skip_dry else 0,
+            _ptr(out), _ptr(ws), nbytes, stream.cuda_stream,
+        )
+        if events is not None:
+            events[1].record(stream)
     _lib.check(rc, "mlx_steric_global")
     return out
 
@@ -194,7 +212,9 @@ def fold_mask(rho0, vol0):
     rho0 = _f64(rho0, rho0.device)
     vol0 = _f64(vol0, rho0.device)
     out = torch.empty_like(rho0)
-    rc = _lib.load().mlx_fold_mask(_ptr(rho0), _ptr(vol0), rho0.numel(), _ptr(out), _stream())
+    with _on(rho0.device):
+        rc = _lib.load().mlx_fold_mask(_ptr(rho0), _ptr(vol0), rho0.numel(), _ptr(out),
+                                       _stream(rho0.device))
     _lib.check(rc, "mlx_fold_mask")
     return out
 
@@ -231,12 +251,13 @@ def steric_local(T, S, rho0m, vol0_surface, p, neg_inv_rhozero, dz=None, z_i=Non
     eta = eta_out if eta_out is not None else torch.empty(
         (nt, ny, nx), dtype=torch.float64, device=dev
     )
-    rc = _lib.load().mlx_steric_local(
-        _ptr(T), _ptr(S), dt, _ptr(rho0m), _ptr(vol0_surface), _ptr(dz), _ptr(z_i),
-        _ptr(deptho), _ptr(pt), p_mode, EOS_IDS[eos.lower()], float(neg_inv_rhozero),
-        nt, nz, ny * nx, sT, sS, _lib.FLAG_SKIP_DRY if skip_dry else 0,
-        _ptr(drho), _ptr(eta), _stream(),
-    )
+    with _on(dev):
+        rc = _lib.load().mlx_steric_local(
+            _ptr(T), _ptr(S), dt, _ptr(rho0m), _ptr(vol0_surface), _ptr(dz), _ptr(z_i),
+            _ptr(deptho), _ptr(pt), p_mode, EOS_IDS[eos.lower()], float(neg_inv_rhozero),
+            nt, nz, ny * nx, sT, sS, _lib.FLAG_SKIP_DRY if skip_dry else 0,
+            _ptr(drho), _ptr(eta), _stream(dev),
+        )
     _lib.check(rc, "mlx_steric_local")
     return drho, eta
 
@@ -249,7 +270,8 @@ def nansum(x):
     nbytes = lib.mlx_nansum_workspace_bytes(x.numel())
     ws = torch.empty(max(nbytes // 8, 1), dtype=torch.float64, device=x.device)
     out = torch.empty(1, dtype=torch.float64, device=x.device)
-    rc = lib.mlx_nansum(_ptr(x), x.numel(), _ptr(out), _ptr(ws), nbytes, _stream())
+    with _on(x.device):
+        rc = lib.mlx_nansum(_ptr(x), x.numel(), _ptr(out), _ptr(ws), nbytes, _stream(x.device))
     _lib.check(rc, "mlx_nansum")
     return out[0]
 
@@ -275,8 +297,10 @@ def masso(rho, vol):
     ws = torch.empty(nbytes // 8, dtype=torch.float64, device=rho.device)
     for t0 in range(0, nt, step):
         t1 = min(t0 + step, nt)
-        rc = lib.mlx_masso(_ptr(rho[t0:t1]), _ptr(vol[t0:t1] if vstride else vol), t1 - t0, n3,
-                           vstride, _ptr(out[t0:t1]), _ptr(ws), nbytes, _stream())
+        with _on(rho.device):
+            rc = lib.mlx_masso(_ptr(rho[t0:t1]), _ptr(vol[t0:t1] if vstride else vol), t1 - t0,
+                               n3, vstride, _ptr(out[t0:t1]), _ptr(ws), nbytes,
+                               _stream(rho.device))
         _lib.check(rc, "mlx_masso")
     return out
 
@@ -294,8 +318,9 @@ def group_weighted_mean(x, w, group_len, out=None):
     n = x[0].numel()
     if out is None:
         out = torch.empty((ngroups,) + tuple(x.shape[1:]), dtype=torch.float64, device=x.device)
-    rc = _lib.load().mlx_group_weighted_mean(_ptr(x), _ptr(w), ngroups, group_len, n, _ptr(out),
-                                             _stream())
+    with _on(x.device):
+        rc = _lib.load().mlx_group_weighted_mean(_ptr(x), _ptr(w), ngroups, group_len, n,
+                                                 _ptr(out), _stream(x.device))
     _lib.check(rc, "mlx_group_weighted_mean")
     return out
 
@@ -308,11 +333,12 @@ def calc_dz(z_i, depth, top=0.0, bottom=None, fraction=False):
     nz = z_i.numel() - 1
     ny, nx = depth.shape
     out = torch.empty((nz, ny, nx), dtype=torch.float64, device=depth.device)
-    rc = _lib.load().mlx_calc_dz(
-        _ptr(z_i), _ptr(depth), nz, ny * nx, float(top),
-        float(bottom) if bottom is not None else 0.0, int(bottom is not None),
-        int(bool(fraction)), _ptr(out), _stream(),
-    )
+    with _on(depth.device):
+        rc = _lib.load().mlx_calc_dz(
+            _ptr(z_i), _ptr(depth), nz, ny * nx, float(top),
+            float(bottom) if bottom is not None else 0.0, int(bottom is not None),
+            int(bool(fraction)), _ptr(out), _stream(depth.device),
+        )
     _lib.check(rc, "mlx_calc_dz")
     return out
 
@@ -328,9 +354,10 @@ def synth_field(shape, dtype=torch.float64, *, seed, field_id, lo, scale, mask3d
     code = DTYPE_F64 if out.dtype == torch.float64 else DTYPE_F32
     if mask3d is not None:
         mask3d = _f64(mask3d, out.device)
-    rc = _lib.load().mlx_synth_field(
-        _ptr(out), code, nt, nz, ny, nx, t0, NY, NX, origin[0], origin[1], seed, field_id,
-        float(lo), float(scale), _ptr(mask3d), _stream(),
-    )
+    with _on(out.device):
+        rc = _lib.load().mlx_synth_field(
+            _ptr(out), code, nt, nz, ny, nx, t0, NY, NX, origin[0], origin[1], seed, field_id,
+            float(lo), float(scale), _ptr(mask3d), _stream(out.device),
+        )
     _lib.check(rc, "mlx_synth_field")
     return out

@@ -176,18 +176,21 @@ class TimeChunks:
 # ---------------------------------------------------------------------------------------
 # reference state (src/momlevel/reference.py:48-85)
 # ---------------------------------------------------------------------------------------
-def reference_state(T0, S0, vol0, pres, eos="wright", f32_mode="faithful", with_masso=True):
+def reference_state(T0, S0, vol0, pres, eos="wright", f32_mode="faithful", with_masso=True,
+                    with_rho=True):
     """rho0 (nz,ny,nx), volo, masso0 as device tensors; rhoga is masso0/volo (host).
 
     ``with_masso=False`` skips masso0 (returns None): a caller that is about to run K1 over a
     record whose first step IS this reference slab takes masso0 = masso(t=0) from that launch --
     the same kernel, tiling and operands, hence the same bits -- instead of a second pass.
+    ``with_rho=False`` skips the K0 density pass too (returns None for rho0): the global variants
+    never read rho0, only ``setup_reference_state``'s public result carries it.
     """
     dev = device_of(T0, S0, vol0)
     T0 = to_device(T0, dev, _stream_dtype(T0))
     S0 = to_device(S0, dev, _stream_dtype(S0))
     vol0 = to_device(vol0, dev, torch.float64)
-    rho0 = core.eos_map(T0, S0, pres, eos=eos, f32_mode=f32_mode)
+    rho0 = core.eos_map(T0, S0, pres, eos=eos, f32_mode=f32_mode) if with_rho else None
     volo = core.nansum(vol0)
     if not with_masso:
         return rho0, volo, None

@@ -74,8 +74,13 @@ def evaluate(eos, func, T, S, p, gravity=None):
     out = None
     if pt is not None and len(shape) >= 3 and pt.numel() > 1:
         nz = shape[-3]
-        if tuple(pt.shape) in ((nz,), (nz, 1, 1)) and pt.numel() == nz:
-            # the calc_rho layout: (…, z, y, x) fields with a z-profile pressure
+        pshape = tuple(pt.shape)
+        while len(pshape) > 3 and pshape[0] == 1:
+            pshape = pshape[1:]
+        if pshape == (nz, 1, 1):
+            # the calc_rho layout: (…, z, y, x) fields with a z-profile pressure (nz,1,1) or
+            # (1,…,nz,1,1).  A bare (nz,) is NOT taken here: numpy aligns it with the LAST axis
+            # (x), and so does the general path below (ambiguous only when nx == nz)
             lead = int(np.prod(shape[:-3])) if len(shape) > 3 else 1
             T4 = Tb.reshape((lead,) + tuple(shape[-3:]))
             S4 = Sb.reshape((lead,) + tuple(shape[-3:]))

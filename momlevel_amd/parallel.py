@@ -43,8 +43,8 @@ def init_from_env(backend=None):
             # GPUs than ranks (device tensors are staged through the host for the exchange)
             backend = os.environ.get("MOMLEVEL_AMD_DIST_BACKEND") or (
                 "nccl" if torch.cuda.is_available() else "gloo")
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+        if torch.cuda.is_available():  # every backend: the rank's kernels go to ITS GPU
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
@@ -114,7 +114,7 @@ def steric_global_tile(T, S, vol0, areacello, pres, variant="steric", eos="wrigh
     else:
         raise ValueError(f"Unknown variant '{variant}' passed to `steric`")
     _rho0, volo, _ = engine.reference_state(T[0], S[0], vol0, pres, eos=eos, f32_mode=f32_mode,
-                                            with_masso=False)
+                                            with_masso=False, with_rho=False)
     masso = engine.global_masso(Tv, Sv, vol0, pres, eos=eos, f32_mode=f32_mode)
     masso0 = masso[0]  # the reference slab is step 0 of this record: same launch, same bits
     area = core.nansum(engine.to_device(areacello, masso.device, torch.float64))

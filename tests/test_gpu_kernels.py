@@ -309,3 +309,26 @@ def test_very_long_record_on_a_tiny_grid():
     dz = o.calc_dz(0.5 * (z_i[1:] + z_i[:-1]), z_i, dep)
     e = np.where(~np.isnan(vol[0]), (-1.0 / 1035.0) * np.nansum(dz * d, axis=1), np.nan)
     assert_bit_equal(eta.cpu().numpy(), e, "eta")
+
+
+def test_launch_targets_the_operands_device():
+    """kernels go to the stream of the device that owns the tensors, whatever torch's
+    current device / stream is.  With one GPU the check is on the stream: operands produced on a
+    side stream, launch under that stream, result identical; with >1 GPU also a non-current device."""
+    g, vol0, T, S, pres = make_case(5, 3, 8, 16)
+    base = core.steric_global_masso(T, S, vol0, pres).cpu().numpy()
+    side = torch.cuda.Stream(device=T.device)
+    side.wait_stream(torch.cuda.current_stream(T.device))
+    with torch.cuda.stream(side):
+        got = core.steric_global_masso(T, S, vol0, pres)
+    side.synchronize()
+    assert np.array_equal(got.cpu().numpy(), base)
+    if torch.cuda.device_count() > 1:
+        other = torch.device("cuda", 1)
+        with torch.cuda.device(0):
+            got = core.steric_global_masso(T.to(other), S.to(other), vol0.to(other), pres)
+            assert got.device == other
+            torch.cuda.synchronize(other)
+        assert np.array_equal(got.cpu().numpy(), base)
+        with pytest.raises(ValueError):
+            core.steric_global_masso(T, S.to(other), vol0, pres)

@@ -178,3 +178,30 @@ def test_held_field_kernels_match_reference_vectors(wright_vectors, held, prec, 
             one = core.steric_global_masso(Tv, Sv, torch.from_numpy(hot.reshape(nz, ny, nx)).cuda(),
                                            pz, f32_mode=f32_mode, skip_dry=skip).cpu().numpy()
             assert_bit_equal(one, ref.reshape(nt, nz, -1)[:, z, j], f"K1 one-hot held {held}")
+
+
+def test_bare_1d_pressure_follows_numpy_alignment():
+    """eos.wright.density claims numpy broadcasting: a (n,) pressure against (n,n,n) fields aligns
+    with the LAST axis (x), as in the reference's eos/wright.py; only (nz,1,1) / (1,nz,1,1) is a
+    z profile."""
+    r = np.random.default_rng(11)
+    T, S = r.uniform(0, 30, (5, 5, 5)), r.uniform(30, 40, (5, 5, 5))
+    p = r.uniform(1e5, 5e7, 5)
+    assert_bit_equal(density(T, S, p), o.wright_density(T, S, p), "(n,) -> x")
+    assert_bit_equal(density(T, S, p[:, None, None]), o.wright_density(T, S, p[:, None, None]),
+                     "(n,1,1) -> z")
+    T4, S4 = r.uniform(0, 30, (3, 5, 5, 5)), r.uniform(30, 40, (3, 5, 5, 5))
+    p4 = p.reshape(1, 5, 1, 1)
+    assert_bit_equal(density(T4, S4, p4), o.wright_density(T4, S4, p4), "(1,n,1,1) -> z")
+    with pytest.raises(Exception):
+        density(T[:, :, :4], S[:, :, :4], p)  # numpy would refuse to broadcast (5,) against x=4
+
+
+def test_4d_z_profile_takes_the_profile_kernel(monkeypatch):
+    """calc_rho on 4-D fields hands (1,nz,1,1): it must reach the kernel as MLX_P_ZPROF (nz
+    doubles), not as a materialised 4-D pressure (+8 B/cell)"""
+    from momlevel_amd import core, _lib
+
+    T = torch.rand((2, 3, 4, 8), dtype=torch.float64, device="cuda")
+    pt, mode = core._pressure(np.arange(3.0).reshape(1, 3, 1, 1), 2, 3, 4, 8, T.device, True)
+    assert mode == _lib.P_ZPROF and tuple(pt.shape) == (3,)
