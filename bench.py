@@ -57,22 +57,40 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target seconds of CPU-baseline work (0 disables it)")
     ap.add_argument("--no-extras", action="store_true", help="skip the local-variant timings")
+    ap.add_argument("--cpu-procs", type=int, default=-1,
+                    help="processes of the P-process CPU line (-1: min(16, cores); 0 disables)")
     ap.add_argument("--input-dtype", choices=["f64", "f32"], default="f64",
                     help="storage type of theta/S (f32 = BASELINE.json configs[4]; the headline is f64)")
     return ap.parse_args()
 
 
+def kernel_source_sha():
+    """sha256 of the HIP sources -- a committed counter profile is only quoted while it still
+    describes the kernels that are being timed."""
+    import hashlib
+
+    h = hashlib.sha256()
+    root = os.path.dirname(os.path.abspath(__file__))
+    for rel in ("momlevel_amd/csrc/momlevel_hip.hip", "momlevel_amd/csrc/eos_device.hpp"):
+        with open(os.path.join(root, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(cells_per_launch):
     """HBM bytes per K1 launch from the committed rocprofv3 --pmc passes (profiles/), if they
-    were taken on this workload; bench.py itself cannot read hardware counters."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_summary.json")
-    try:
-        with open(path) as f:
-            s = json.load(f)
-        if s.get("cells_per_launch") == cells_per_launch:
-            return round(s["hbm_traffic_bytes_per_launch"] / 1e9, 2), "profiles/r01_summary.json"
-    except (OSError, KeyError, ValueError):
-        pass
+    were taken on this workload AND on these kernel sources; bench.py itself cannot read
+    hardware counters.  A stale profile (sources changed since) yields null, not an old number."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in ("r02_summary.json",):
+        try:
+            with open(os.path.join(here, "profiles", name)) as f:
+                s = json.load(f)
+            if (s.get("cells_per_launch") == cells_per_launch
+                    and s.get("kernel_source_sha") == kernel_source_sha()):
+                return round(s["hbm_traffic_bytes_per_launch"] / 1e9, 2), f"profiles/{name}"
+        except (OSError, KeyError, ValueError):
+            pass
     return None, None
 
 
@@ -85,6 +103,30 @@ def fit_nt(nt, nz, ny, nx, device, itemsize=8):
     return max(1, min(nt, cap))
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def parity_slabs(nt, t_chunk=32):
+    """Time steps whose GPU masso is checked against the oracle: first and last step of EVERY
+    K1 time chunk that the bounded CPU budget allows, in an order that reaches all chunks first
+    (t = 0, 32, 64, 96, then 31, 63, 95, 119 for nt=120)."""
+    firsts = list(range(0, nt, t_chunk))
+    lasts = [min(t + t_chunk, nt) - 1 for t in firsts]
+    order = []
+    for t in firsts + lasts:
+        if t not in order:
+            order.append(t)
+    return order
+
+
 def cpu_baseline(T, S, g, pres, target_s, gpu_masso):
     """Oracle timed on host cores over whole time slabs of the resident fields."""
     from oracle import momlevel_numpy as o  # the checker / timed baseline, never the product
@@ -92,8 +134,8 @@ def cpu_baseline(T, S, g, pres, target_s, gpu_masso):
     nz, ny, nx = T.shape[1:]
     cells = nz * ny * nx
     vol = g["volcello"]
-    spent, slabs, err = 0.0, 0, 0.0
-    for t in range(min(T.shape[0], 8)):
+    spent, slabs, err, done = 0.0, 0, 0.0, []
+    for t in parity_slabs(T.shape[0])[:8]:
         Tn = T[t].cpu().numpy()
         Sn = S[t].cpu().numpy()
         t0 = time.perf_counter()
@@ -101,19 +143,68 @@ def cpu_baseline(T, S, g, pres, target_s, gpu_masso):
         m = o.calc_masso(rho, vol)
         spent += time.perf_counter() - t0
         slabs += 1
+        done.append(t)
         err = max(err, abs(m - gpu_masso[t]) / abs(m))
         del rho, Tn, Sn
-        if spent >= target_s:
+        if spent >= target_s and slabs >= 4:
             break
     return {
         "value": round(slabs * cells / spent / 1e6, 3),
         "unit": "Mcells/s",
         "cores": 1,
         "kind": "port",
-        "sample": (f"{slabs} of {T.shape[0]} time slabs ({nx}x{ny}x{nz} cells each) of the same "
-                   "synthetic fields: unfused numpy wright density + nansum(rho*volcello_ref), "
-                   f"{spent:.1f} s on 1 thread"),
-    }, {"masso_max_rel_err_vs_oracle": float(err), "slabs_checked": slabs}
+        "cpu": cpu_model(),
+        "sample": (f"{slabs} of {T.shape[0]} time slabs (t = {done}; {nx}x{ny}x{nz} cells each) of "
+                   "the same synthetic fields: unfused numpy wright density + "
+                   f"nansum(rho*volcello_ref), {spent:.1f} s on 1 thread of {cpu_model()}"),
+    }, {"masso_max_rel_err_vs_oracle": float(err), "slabs_checked": slabs,
+        "time_steps_checked": done,
+        "note": "first/last step of K1 time chunks (32 steps each): the whole launch is covered"}
+
+
+def cpu_baseline_processes(g, nz, ny, nx, nt, gpu_masso, procs, reps=2, timeout=420):
+    """The P-process line of BASELINE.md section 4: P independent oracle processes, one time slab
+    each, all timed together (how dask's chunks={"time": 1} spreads momlevel over a host).  Every
+    worker regenerates its slab in numpy (no GPU, no shared memory) -- oracle/cpu_worker.py."""
+    import subprocess
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    steps = [int(round(i * (nt - 1) / max(1, procs - 1))) for i in range(procs)]
+    workers = []
+    try:
+        for t in steps:
+            workers.append(subprocess.Popen(
+                [sys.executable, "-m", "oracle.cpu_worker", str(ny), str(nx), str(nz), str(t),
+                 str(reps)], cwd=here, env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                text=True))
+        deadline = time.time() + timeout
+        for w in workers:
+            if w.stdout.readline().strip() != "ready" or time.time() > deadline:
+                raise RuntimeError("worker failed to start")
+        t0 = time.perf_counter()
+        for w in workers:
+            w.stdin.write("go\n")
+            w.stdin.flush()
+        outs = [w.stdout.readline().split() for w in workers]
+        wall = time.perf_counter() - t0
+        per_slab = [float(o_[0]) for o_ in outs]
+        err = max(abs(float(o_[1]) - gpu_masso[t]) / abs(float(o_[1])) for o_, t in zip(outs, steps))
+    except Exception as exc:  # reported, never fatal for the bench line
+        return {"error": f"{type(exc).__name__}: {exc}"}
+    finally:
+        for w in workers:
+            try:
+                w.kill()
+            except Exception:
+                pass
+    cells = nz * ny * nx * reps * procs
+    return {"value": round(cells / wall / 1e6, 1), "unit": "Mcells/s", "cores": procs,
+            "kind": "port", "cpu": cpu_model(),
+            "sample": (f"{procs} processes x {reps} passes over one time slab each (t = {steps}), "
+                       f"unfused numpy oracle, wall {wall:.1f} s; slowest worker "
+                       f"{max(per_slab):.2f} s/slab, fastest {min(per_slab):.2f}"),
+            "masso_max_rel_err_vs_gpu": float(err)}
 
 
 def cpu_baseline_fused(T, S, g, pres, gpu_masso, slabs=2):
@@ -228,11 +319,14 @@ def main():
     if not a.no_extras and world == 1 and not f32:
         extras = local_variant_timings(T, S, vol0, pres, g, dev)
 
-    cpu, parity, cpu_fused = None, None, None
+    cpu, parity, cpu_fused, cpu_procs = None, None, None, None
     if world == 1 and a.cpu_seconds > 0:
         cpu, parity = cpu_baseline(T, S, g, pres.cpu().numpy(), a.cpu_seconds, out["masso"])
-        if not f32:  # the C restatement is float64 only
+        if not f32:  # the C restatement and the numpy replay of the fields are float64
             cpu_fused = cpu_baseline_fused(T, S, g, pres.cpu().numpy(), out["masso"])
+            procs = min(16, os.cpu_count() or 1) if a.cpu_procs < 0 else a.cpu_procs
+            if procs > 0:
+                cpu_procs = cpu_baseline_processes(g, nz, ny, nx, nt, out["masso"], procs)
 
     if rank == 0:
         layout = {1: "1x1", 2: "1x2", 4: "2x2", 8: "2x4"}.get(world, f"1x{world}")
@@ -285,8 +379,10 @@ def main():
                 "algorithmic_gb_per_launch": round(bytes_per_cell * cells_rank / 1e9, 2),
                 "cells_per_launch": cells_rank,
                 "time_loop_steps_per_block": 32,
+                "kernel_source_sha": kernel_source_sha(),
             },
             "cpu_baseline": cpu,
+            "cpu_baseline_processes": cpu_procs,
             "cpu_baseline_fused_openmp": cpu_fused,
             "parity": parity,
             "eta_t0_is_zero": bool(out["eta"][0] == 0.0),
@@ -317,12 +413,31 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
     nt, nz, ny, nx = T.shape
     cells = nt * nz * ny * nx
     out = {}
-    ms = _time(lambda: core.steric_global_masso(T, S[0], vol0, pres, skip_dry=False))
-    out["thermosteric_global"] = {"Mcells/s": round(cells / ms / 1e3, 1),
-                                  "GB/s_at_8B_per_cell": round(8 * cells / ms / 1e6, 1)}
-    ms = _time(lambda: core.steric_global_masso(T[0], S, vol0, pres, skip_dry=False))
-    out["halosteric_global"] = {"Mcells/s": round(cells / ms / 1e3, 1),
-                                "GB/s_at_8B_per_cell": round(8 * cells / ms / 1e6, 1)}
+
+    def rate(ms, bytes_per_cell, n=cells):
+        return {"Mcells/s": round(n / ms / 1e3, 1), "ms": round(ms, 3),
+                f"GB/s_at_{bytes_per_cell}B_per_cell": round(bytes_per_cell * n / ms / 1e6, 1),
+                "frac_of_8TBs": round(bytes_per_cell * n / ms / 1e6 / HBM_PEAK_GBS, 4)}
+
+    # the 8 B/cell variants: exact (numpy's arithmetic, the default) and MLX_FLAG_FMA (opt-in)
+    for arith in ("exact", "fused"):
+        tag = "" if arith == "exact" else "_fused"
+        ms = _time(lambda: core.steric_global_masso(T, S[0], vol0, pres, skip_dry=False,
+                                                    arith=arith))
+        out["thermosteric_global" + tag] = rate(ms, 8)
+        ms = _time(lambda: core.steric_global_masso(T[0], S, vol0, pres, skip_dry=False,
+                                                    arith=arith))
+        out["halosteric_global" + tag] = rate(ms, 8)
+    ms = _time(lambda: core.steric_global_masso(T, S, vol0, pres, skip_dry=False, arith="fused"))
+    out["steric_global_fused"] = rate(ms, 16)
+    # BASELINE.json configs[4]: steric + thermosteric + halosteric (+ heat content) from ONE pass
+    # over theta/S, against the sum of the three single-variant launches
+    for arith in ("exact", "fused"):
+        ms = _time(lambda: core.steric_global_decomp(T, S, T[0], S[0], vol0, pres, skip_dry=False,
+                                                     arith=arith))
+        r = rate(ms, 16)
+        r["note"] = "all three variants + sum(theta*vol0) per step, theta/S read once"
+        out["decomposition_one_pass" + ("" if arith == "exact" else "_fused")] = r
     # calibration: this box's plain streaming-read rate through the same 16-byte nt loads
     # (skipna sum of the theta record) -- the practical ceiling K1's 16 B/cell runs against
     ms = _time(lambda: core.nansum(T))
@@ -344,31 +459,35 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
     ms = _time(lambda: core.steric_local(T, S, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=zi,
                                          deptho=dep, want_delta_rho=False, eta_out=eta,
                                          skip_dry=False))
-    out["local_eta_only"] = {"Mcells/s": round(cells / ms / 1e3, 1),
-                             "GB/s_at_16B_per_cell": round(16 * cells / ms / 1e6, 1)}
+    out["local_eta_only"] = rate(ms, 16)
     chunk = min(nt, 16)
     free, _ = torch.cuda.mem_get_info(dev)
     if free > chunk * nz * ny * nx * 8 + (2 << 30):
         drho = torch.empty((chunk, nz, ny, nx), dtype=torch.float64, device=dev)
+        starts = range(0, nt - chunk + 1, chunk)
+        done = len(starts) * chunk * nz * ny * nx
 
-        def run():
-            for t0 in range(0, nt - chunk + 1, chunk):
+        def run(skip):
+            for t0 in starts:
                 core.steric_local(T[t0:t0 + chunk], S[t0:t0 + chunk], rho0m, vol0[0], pres,
                                   -1.0 / 1035.0, z_i=zi, deptho=dep, delta_rho_out=drho,
-                                  eta_out=eta[t0:t0 + chunk], skip_dry=False)
+                                  eta_out=eta[t0:t0 + chunk], skip_dry=skip)
 
-        ms = _time(run, reps=2)
-        done = (nt // chunk) * chunk * nz * ny * nx
-        out["local_with_delta_rho"] = {"Mcells/s": round(done / ms / 1e3, 1),
-                                       "GB/s_at_24B_per_cell": round(24 * done / ms / 1e6, 1)}
+        ms = _time(lambda: run(False), reps=2)
+        out["local_with_delta_rho"] = rate(ms, 24, done)
 
-        def run_skip():
-            for t0 in range(0, nt - chunk + 1, chunk):
-                core.steric_local(T[t0:t0 + chunk], S[t0:t0 + chunk], rho0m, vol0[0], pres,
-                                  -1.0 / 1035.0, z_i=zi, deptho=dep, delta_rho_out=drho,
-                                  eta_out=eta[t0:t0 + chunk], skip_dry=True)
+        # the same traffic with no arithmetic: 16 B read + 8 B written per cell through the same
+        # 16-byte nt loads/stores -- this box's ceiling for the pass above
+        def probe():
+            for t0 in starts:
+                core.stream_probe(T[t0:t0 + chunk], S[t0:t0 + chunk], out=drho)
 
-        ms = _time(run_skip, reps=2)
+        pms = _time(probe, reps=2)
+        out["stream_read_write_probe"] = {
+            "GB/s": round(24 * done / pms / 1e6, 1), "ms": round(pms, 3),
+            "note": "mlx_stream_probe: out = a + b, 16 B read + 8 B written per element"}
+        out["local_with_delta_rho"]["frac_of_read_write_probe"] = round(pms / ms, 4)
+        ms = _time(lambda: run(True), reps=2)
         out["land_skipping"]["local_with_delta_rho_Mcells/s"] = round(done / ms / 1e3, 1)
     return out
 

@@ -23,7 +23,8 @@
  *    counts as 0; an all-NaN reduction gives 0.0), as xarray's default .sum().
  *  - Pointwise outputs (rho, its derivatives, delta_rho, dz, local eta) are
  *    bit-identical to the reference's numpy evaluation on finite inputs: the
- *    device code keeps the reference's operator order with FMA contraction off.
+ *    device code keeps the reference's operator order with FMA contraction off
+ *    (unless the caller opts into MLX_FLAG_FMA).
  *    Reductions over (z,y,x) differ from numpy's pairwise order at the 1e-15 level
  *    and are deterministic (fixed order, no float atomics).
  */
@@ -37,7 +38,8 @@
 extern "C" {
 #endif
 
-#define MLX_ABI_VERSION 1
+#define MLX_ABI_VERSION 2 /* 2: mlx_eos_map takes flags; mlx_steric_global_decomp, mlx_stream_probe;
+                             MLX_FLAG_FMA, MLX_FLAG_TCHUNK; MLX_P_FULL4D in K1/K2 */
 
 /* argument-error codes (negative) */
 #define MLX_E_NULL     (-1) /* a required pointer is NULL                      */
@@ -62,7 +64,7 @@ extern "C" {
 #define MLX_P_SCALAR  0 /* p[0] for every cell (calc_pdens, scalar calls)            */
 #define MLX_P_ZPROF   1 /* p[nz]: the steric path, pres = z_l*1e4 + patm              */
 #define MLX_P_FULL3D  2 /* p[nz*plane]: patm given as a (yh,xh) DataArray             */
-#define MLX_P_FULL4D  3 /* p[nt*nz*plane]: same shape as the output (K0 only)         */
+#define MLX_P_FULL4D  3 /* p[nt*nz*plane]: patm given as a (time,yh,xh) DataArray        */
 
 /* dtype of the streamed theta/S fields */
 #define MLX_DTYPE_F64 0
@@ -76,6 +78,18 @@ extern "C" {
                                skipped) resp. are NaN whatever theta/S hold, so the results are
                                bit-identical while whole cache lines of land and sub-bottom cells
                                never leave HBM.  0 = load every cell, wet or dry.               */
+#define MLX_FLAG_FMA 2      /* opt-in fused arithmetic for the Wright DENSITY: the reference's
+                               expression tree with every "c + a*b" contracted into one fma and the
+                               quotient taken by a Newton reciprocal, all in float64 (float32 theta/S
+                               are upcast first).  NOT bit-identical to numpy: rho differs by a few
+                               ulp (parity gate: 1e-10 relative on rho and masso, 1e-10*max|ref| on
+                               delta_rho and eta).  All kernels share one tree, so in this mode too
+                               masso(t=0) == masso0 and delta_rho(t=0) == 0 hold exactly.  About half
+                               the VALU work per cell: lifts the 8 B/cell thermosteric/halosteric
+                               passes and the float32 passes off the fp64-VALU bound.             */
+#define MLX_FLAG_TCHUNK_MASK 0xFF00 /* K1 tuning hint, never changes a result: time steps per
+                               block = 8 * ((flags >> 8) & 0xFF); 0 = the default (32)            */
+#define MLX_FLAG_TCHUNK(steps) ((((steps) / 8) & 0xFF) << 8)
 
 int mlx_version(void);
 /* copies the calling thread's last error text into buf (NUL-terminated); returns its length */
@@ -92,7 +106,7 @@ int mlx_last_error(char *buf, size_t n);
 int mlx_eos_map(const void *T, const void *S, int dtype,
                 const double *p, int p_mode, int eos, int func,
                 int64_t nt, int64_t nz, int64_t plane,
-                int64_t t_stride_T, int64_t t_stride_S,
+                int64_t t_stride_T, int64_t t_stride_S, int flags, /* 0 or MLX_FLAG_FMA (density) */
                 double *out, void *stream);
 
 /* ---------------------------------------------------------------------------------
@@ -112,7 +126,9 @@ int mlx_inverse_barometer(const void *T, const void *S, int dtype,
  * as called from steric() for domain="global" (src/momlevel/steric.py:128,135) and
  * from setup_reference_state (src/momlevel/reference.py:71,77).
  * vol0 is the REFERENCE volcello (z,y,x), used for every time step (steric.py:135).
- * p_mode: MLX_P_SCALAR, MLX_P_ZPROF or MLX_P_FULL3D.
+ * p_mode: any (MLX_P_FULL4D = a time-dependent patm, steric.py:58-60,96).
+ * t_stride_T == 0 (or t_stride_S == 0) holds that field at its (z,y,x) reference slab for every
+ * time step: the halosteric (thermosteric) variant, steric.py:115-125.
  * In a multi-GPU run each rank passes its horizontal tile; the caller all-reduces
  * masso_out (RCCL) -- the library never communicates.
  * ------------------------------------------------------------------------------- */
@@ -123,6 +139,27 @@ int mlx_steric_global(const void *T, const void *S, int dtype,
                       int64_t t_stride_T, int64_t t_stride_S, int flags,
                       double *masso_out, void *workspace, size_t workspace_bytes,
                       void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * K1, all variants in ONE pass over theta/S (BASELINE.json configs[4]): what three calls of
+ * steric(..., domain="global") with variant = "steric", "thermosteric", "halosteric"
+ * (src/momlevel/steric.py:115-147, 187-196) compute, from a single read of the 4-D fields:
+ *   out[0*nt + t] = sum rho(T[t], S[t], p) * vol0      (steric)
+ *   out[1*nt + t] = sum rho(T[t], S0,   p) * vol0      (thermosteric: S held at the reference)
+ *   out[2*nt + t] = sum rho(T0,   S[t], p) * vol0      (halosteric:   theta held)
+ *   out[3*nt + t] = sum T[t] * vol0                    (EXTENSION, not in momlevel: the ocean heat
+ *                   content integrand; OHC(t) = rho0 * c_p * out[3*nt+t], scaled by the caller)
+ * T0, S0: the (z,y,x) reference slabs (same dtype as T, S).  Each of the first three rows is
+ * bit-identical to the corresponding mlx_steric_global call (same tiling, same order of
+ * summation).  out holds 4*nt doubles; workspace: mlx_steric_global_decomp_workspace_bytes().
+ * ------------------------------------------------------------------------------- */
+size_t mlx_steric_global_decomp_workspace_bytes(int64_t nt, int64_t nz, int64_t plane);
+int mlx_steric_global_decomp(const void *T, const void *S, const void *T0, const void *S0,
+                             int dtype, const double *vol0, const double *p, int p_mode, int eos,
+                             int64_t nt, int64_t nz, int64_t plane,
+                             int64_t t_stride_T, int64_t t_stride_S, int flags,
+                             double *out, void *workspace, size_t workspace_bytes,
+                             void *stream);
 
 /* ---------------------------------------------------------------------------------
  * K2  fused EOS + delta_rho + dz-weighted column integral.
@@ -187,6 +224,14 @@ int mlx_group_weighted_mean(const double *x, const double *w, int64_t ngroups, i
 int mlx_calc_dz(const double *z_i, const double *depth, int64_t nz, int64_t plane,
                 double top, double bottom, int has_bottom, int fraction,
                 double *dz_out, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * Measurement aid (not a reference function): out[i] = a[i] + b[i] over n doubles (n even, all
+ * pointers 16-byte aligned) with the 16-byte non-temporal loads and stores of the fused local
+ * kernel -- 16 B read + 8 B written per element and no arithmetic to speak of.  bench.py reports
+ * mlx_steric_local with delta_rho (24 B/cell) as a fraction of this box-specific ceiling.
+ * ------------------------------------------------------------------------------- */
+int mlx_stream_probe(const double *a, const double *b, int64_t n, double *out, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * Synthetic MOM6-shaped fields for bench.py and the full-size tests (not a

@@ -12,12 +12,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmomlevel_hip.so")
 
 # ---- constants mirrored from include/momlevel_hip.h --------------------------------
-ABI_VERSION = 1
+ABI_VERSION = 2
 EOS_WRIGHT, EOS_LINEAR = 0, 1
 FUNC_DENSITY, FUNC_DRHO_DTEMP, FUNC_DRHO_DSAL, FUNC_ALPHA, FUNC_BETA = 0, 1, 2, 3, 4
 P_SCALAR, P_ZPROF, P_FULL3D, P_FULL4D = 0, 1, 2, 3
 DTYPE_F64, DTYPE_F32, DTYPE_F32_UPCAST = 0, 1, 2
 FLAG_SKIP_DRY = 1
+FLAG_FMA = 2
+
+
+def flag_tchunk(steps):
+    """MLX_FLAG_TCHUNK(steps): K1 tuning hint (time steps per block, multiple of 8; 0 = default)."""
+    return ((int(steps) // 8) & 0xFF) << 8
+
 
 EOS_IDS = {"wright": EOS_WRIGHT, "linear": EOS_LINEAR}
 FUNC_IDS = {
@@ -41,7 +48,7 @@ SIGNATURES = {
     "mlx_last_error": (_int, [ctypes.c_char_p, _sz]),
     "mlx_eos_map": (
         _int,
-        [_vp, _vp, _int, _vp, _int, _int, _int, _i64, _i64, _i64, _i64, _i64, _vp, _vp],
+        [_vp, _vp, _int, _vp, _int, _int, _int, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp],
     ),
     "mlx_inverse_barometer": (
         _int,
@@ -53,6 +60,12 @@ SIGNATURES = {
         [_vp, _vp, _int, _vp, _vp, _int, _int, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp, _sz,
          _vp],
     ),
+    "mlx_steric_global_decomp_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "mlx_steric_global_decomp": (
+        _int,
+        [_vp, _vp, _vp, _vp, _int, _vp, _vp, _int, _int, _i64, _i64, _i64, _i64, _i64, _int, _vp,
+         _vp, _sz, _vp],
+    ),
     "mlx_fold_mask": (_int, [_vp, _vp, _i64, _vp, _vp]),
     "mlx_steric_local": (
         _int,
@@ -63,6 +76,7 @@ SIGNATURES = {
     "mlx_nansum": (_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
     "mlx_masso": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "mlx_group_weighted_mean": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "mlx_stream_probe": (_int, [_vp, _vp, _i64, _vp, _vp]),
     "mlx_calc_dz": (_int, [_vp, _vp, _i64, _i64, _dbl, _dbl, _int, _int, _vp, _vp]),
     "mlx_synth_field": (
         _int,

@@ -27,6 +27,29 @@ from ._lib import (
 )
 
 F32_MODES = {"faithful": DTYPE_F32, "upcast": DTYPE_F32_UPCAST}
+ARITH_FLAGS = {"exact": 0, "fused": _lib.FLAG_FMA}
+
+
+def arith_default():
+    """Arithmetic of the Wright density.  "exact" (default): numpy's operator-for-operator
+    evaluation, bit-identical to the reference.  "fused" (opt-in, MOMLEVEL_AMD_ARITH=fused):
+    MLX_FLAG_FMA -- contracted multiply-adds and a Newton reciprocal, a few ulp from numpy
+    (<= 1e-10 relative), about half the VALU work per cell."""
+    import os
+
+    mode = os.environ.get("MOMLEVEL_AMD_ARITH", "exact")
+    if mode not in ARITH_FLAGS:
+        raise ValueError(f"MOMLEVEL_AMD_ARITH must be 'exact' or 'fused', got '{mode}'")
+    return mode
+
+
+def _arith_flag(arith):
+    if arith is None:
+        arith = arith_default()
+    try:
+        return ARITH_FLAGS[arith]
+    except KeyError:
+        raise ValueError(f"arith must be 'exact' or 'fused', got '{arith}'") from None
 
 
 def require_device():
@@ -89,7 +112,8 @@ def _pair(T, S, f32_mode):
     """Common shape logic of the (thetao, so) pair."""
     if T.dtype != S.dtype:
         raise TypeError("thetao and so must share a dtype")
-    if isinstance(T, torch.Tensor) and isinstance(S, torch.Tensor) and T.device != S.device:
+    if (isinstance(T, torch.Tensor) and isinstance(S, torch.Tensor) and T.is_cuda and S.is_cuda
+            and T.device != S.device):
         raise ValueError(f"thetao is on {T.device} but so on {S.device}: operands of one call "
                          "must live on one GPU")
     shape3 = tuple(T.shape[-3:])
@@ -133,16 +157,18 @@ def _pressure(p, nt, nz, ny, nx, device, allow4d):
     raise ValueError(f"pressure of shape {shape} does not broadcast to {(nz, ny, nx)}")
 
 
-def eos_map(T, S, p, eos="wright", func="density", f32_mode="faithful"):
-    """K0: pointwise EOS function over a (nt,nz,ny,nx) or (nz,ny,nx) grid -> float64."""
+def eos_map(T, S, p, eos="wright", func="density", f32_mode="faithful", arith=None):
+    """K0: pointwise EOS function over a (nt,nz,ny,nx) or (nz,ny,nx) grid -> float64.
+    ``arith``: "exact" | "fused" | None = arith_default(); applies to the Wright density only."""
     require_device()
+    flags = _arith_flag(arith) if (func == "density" and eos.lower() == "wright") else 0
     T, S, nt, nz, ny, nx, sT, sS, dt, squeeze = _pair(T, S, f32_mode)
     pt, p_mode = _pressure(p, nt, nz, ny, nx, T.device, allow4d=True)
     out = torch.empty((nt, nz, ny, nx), dtype=torch.float64, device=T.device)
     with _on(T.device):
         rc = _lib.load().mlx_eos_map(
             _ptr(T), _ptr(S), dt, _ptr(pt), p_mode, EOS_IDS[eos.lower()], FUNC_IDS[func],
-            nt, nz, ny * nx, sT, sS, _ptr(out), _stream(T.device),
+            nt, nz, ny * nx, sT, sS, flags, _ptr(out), _stream(T.device),
         )
     _lib.check(rc, "mlx_eos_map")
     return out[0] if squeeze else out
@@ -170,23 +196,33 @@ def skip_dry_default():
     return os.environ.get("MOMLEVEL_AMD_SKIP_DRY", "1") != "0"
 
 
+def _k1_flags(skip_dry, arith, t_chunk):
+    if skip_dry is None:
+        skip_dry = skip_dry_default()
+    flags = (_lib.FLAG_SKIP_DRY if skip_dry else 0) | _arith_flag(arith)
+    if t_chunk:
+        flags |= _lib.flag_tchunk(t_chunk)
+    return flags
+
+
 def steric_global_masso(T, S, vol0, p, eos="wright", f32_mode="faithful", events=None,
-                        skip_dry=None):
+                        skip_dry=None, arith=None, t_chunk=0):
     """K1: masso[t] = sum_{z,y,x} rho(T,S,p) * vol0  (skipna) -> (nt,) float64.
 
     ``events=(start, end)``: two ``torch.cuda.Event(enable_timing=True)`` recorded on the
     launch stream immediately around the kernel launches (bench.py's per-launch timing).
     ``skip_dry``: MLX_FLAG_SKIP_DRY (None = the default policy, on); results are bit-identical
-    either way.
+    either way.  ``arith``: "exact" | "fused" (None = arith_default()).  ``t_chunk``: tuning
+    hint, time steps per block (multiple of 8; 0 = library default); never changes a result.
+    ``p`` may be time dependent, (nt,nz,ny,nx)-broadcastable (a DataArray ``patm``).
     """
-    if skip_dry is None:
-        skip_dry = skip_dry_default()
     require_device()
+    flags = _k1_flags(skip_dry, arith, t_chunk)
     T, S, nt, nz, ny, nx, sT, sS, dt, _ = _pair(T, S, f32_mode)
     vol0 = _f64(vol0, T.device)
     if tuple(vol0.shape) != (nz, ny, nx):
         raise ValueError(f"vol0 has shape {tuple(vol0.shape)}, expected {(nz, ny, nx)}")
-    pt, p_mode = _pressure(p, nt, nz, ny, nx, T.device, allow4d=False)
+    pt, p_mode = _pressure(p, nt, nz, ny, nx, T.device, allow4d=True)
     lib = _lib.load()
     nbytes = lib.mlx_steric_global_workspace_bytes(nt, nz, ny * nx)
     ws = torch.empty(nbytes // 8, dtype=torch.float64, device=T.device)
@@ -197,12 +233,67 @@ def steric_global_masso(T, S, vol0, p, eos="wright", f32_mode="faithful", events
             events[0].record(stream)
         rc = lib.mlx_steric_global(
             _ptr(T), _ptr(S), dt, _ptr(vol0), _ptr(pt), p_mode, EOS_IDS[eos.lower()],
-            nt, nz, ny * nx, sT, sS, _lib.FLAG_SKIP_DRY if skip_dry else 0,
+            nt, nz, ny * nx, sT, sS, flags,
             _ptr(out), _ptr(ws), nbytes, stream.cuda_stream,
         )
         if events is not None:
             events[1].record(stream)
     _lib.check(rc, "mlx_steric_global")
+    return out
+
+
+DECOMP_ROWS = ("steric", "thermosteric", "halosteric", "heat")
+
+
+def steric_global_decomp(T, S, T0, S0, vol0, p, eos="wright", f32_mode="faithful", events=None,
+                         skip_dry=None, arith=None, t_chunk=0):
+    """K1, all variants in one pass over theta/S: (4, nt) float64, rows DECOMP_ROWS =
+    masso of steric / thermosteric (S held at S0) / halosteric (theta held at T0), and
+    sum(theta*vol0) (the heat-content integrand; an extension, not in momlevel).  Rows 0-2 are
+    bit-identical to three steric_global_masso calls."""
+    require_device()
+    flags = _k1_flags(skip_dry, arith, t_chunk)
+    T, S, nt, nz, ny, nx, sT, sS, dt, _ = _pair(T, S, f32_mode)
+    if T.dim() != 4 or S.dim() != 4:
+        raise ValueError("steric_global_decomp streams both fields: thetao and so must be 4-D")
+    dev = T.device
+    T0 = T0.to(device=dev, dtype=T.dtype).contiguous()
+    S0 = S0.to(device=dev, dtype=S.dtype).contiguous()
+    if tuple(T0.shape) != (nz, ny, nx) or tuple(S0.shape) != (nz, ny, nx):
+        raise ValueError(f"T0 and S0 must be {(nz, ny, nx)}")
+    vol0 = _f64(vol0, dev)
+    if tuple(vol0.shape) != (nz, ny, nx):
+        raise ValueError(f"vol0 has shape {tuple(vol0.shape)}, expected {(nz, ny, nx)}")
+    pt, p_mode = _pressure(p, nt, nz, ny, nx, dev, allow4d=True)
+    lib = _lib.load()
+    nbytes = lib.mlx_steric_global_decomp_workspace_bytes(nt, nz, ny * nx)
+    ws = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
+    out = torch.empty((4, nt), dtype=torch.float64, device=dev)
+    with _on(dev):
+        stream = torch.cuda.current_stream(dev)
+        if events is not None:
+            events[0].record(stream)
+        rc = lib.mlx_steric_global_decomp(
+            _ptr(T), _ptr(S), _ptr(T0), _ptr(S0), dt, _ptr(vol0), _ptr(pt), p_mode,
+            EOS_IDS[eos.lower()], nt, nz, ny * nx, sT, sS, flags, _ptr(out), _ptr(ws), nbytes,
+            stream.cuda_stream,
+        )
+        if events is not None:
+            events[1].record(stream)
+    _lib.check(rc, "mlx_steric_global_decomp")
+    return out
+
+
+def stream_probe(a, b, out=None):
+    """Measurement aid: out = a + b with K2's 16-byte nt loads/stores (16 B read + 8 B written per
+    element); see mlx_stream_probe."""
+    require_device()
+    if out is None:
+        out = torch.empty_like(a)
+    with _on(a.device):
+        rc = _lib.load().mlx_stream_probe(_ptr(a), _ptr(b), a.numel(), _ptr(out),
+                                          _stream(a.device))
+    _lib.check(rc, "mlx_stream_probe")
     return out
 
 
@@ -233,7 +324,7 @@ def steric_local(T, S, rho0m, vol0_surface, p, neg_inv_rhozero, dz=None, z_i=Non
     vol0_surface = _f64(vol0_surface, dev)
     if tuple(rho0m.shape) != (nz, ny, nx) or tuple(vol0_surface.shape) != (ny, nx):
         raise ValueError("rho0m must be (nz,ny,nx) and vol0_surface (ny,nx)")
-    pt, p_mode = _pressure(p, nt, nz, ny, nx, dev, allow4d=False)
+    pt, p_mode = _pressure(p, nt, nz, ny, nx, dev, allow4d=True)
     if dz is not None:
         dz = _f64(dz, dev)
         if tuple(dz.shape) != (nz, ny, nx):
@@ -255,7 +346,7 @@ def steric_local(T, S, rho0m, vol0_surface, p, neg_inv_rhozero, dz=None, z_i=Non
         rc = _lib.load().mlx_steric_local(
             _ptr(T), _ptr(S), dt, _ptr(rho0m), _ptr(vol0_surface), _ptr(dz), _ptr(z_i),
             _ptr(deptho), _ptr(pt), p_mode, EOS_IDS[eos.lower()], float(neg_inv_rhozero),
-            nt, nz, ny * nx, sT, sS, _lib.FLAG_SKIP_DRY if skip_dry else 0,
+            nt, nz, ny * nx, sT, sS, flags,
             _ptr(drho), _ptr(eta), _stream(dev),
         )
     _lib.check(rc, "mlx_steric_local")

@@ -53,75 +53,109 @@ struct WrightC {
   static constexpr R C5 = R(-3.079464);
 };
 
-// al0, p0, lam in precision R (double, or float for numpy's float32 inputs: the
-// python-float constants are weak scalars and are rounded to float32 first)
+// ---- arithmetic policies -----------------------------------------------------------------------
+// ExactOps: numpy's evaluation -- every + - * / is ONE correctly rounded IEEE operation, in the
+//   reference's operator order; results are bit-identical to eos/wright.py on the host.
+// FusedOps (opt-in, MLX_FLAG_FMA): the same expression tree with each "c + a*b" node contracted
+//   into one fma and the quotient taken by a Newton reciprocal (v_rcp_f64 + 1 refinement + exact
+//   residual correction; the Wright denominator lives near 2^19, far from over/underflow).  Not
+//   bit-identical to numpy: |rho_fused - rho_numpy| <= a few ulp (parity gate 1e-10 relative).
+//   Always float64, also for float32 theta/S (upcast first).
+struct ExactOps {
+  static constexpr bool fused = false;
+  template <typename R>
+  static __device__ __forceinline__ R mad(R a, R b, R c) {
+    return a * b + c;  // two roundings: this file is compiled with contraction off
+  }
+  // eos/wright.py:47-48: I_denom = 1.0 / den; return (p + p0) * I_denom
+  static __device__ __forceinline__ double quotient(double num, double den) {
+    const double I_denom = 1.0 / den;
+    return num * I_denom;
+  }
+};
+
+struct FusedOps {
+  static constexpr bool fused = true;
+  template <typename R>
+  static __device__ __forceinline__ R mad(R a, R b, R c) {
+    return __builtin_fma(a, b, c);
+  }
+  static __device__ __forceinline__ double quotient(double num, double den) {
+    double r = __builtin_amdgcn_rcp(den);           // ~2^-23 relative
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);  // ~2^-45
+    const double q = num * r;
+    return __builtin_fma(__builtin_fma(-den, q, num), r, q);  // exact residual: <= 1 ulp
+  }
+};
+
+// ---- the Wright polynomial, split into the part that depends on T only, the part that depends
+// on S only, and the combination.  This is eos/wright.py:44-46 regrouped along its own
+// parentheses:
+//     al0 = (A0 + A1*T) + A2*S
+//     p0  = (B0 + B4*S) + T*((B1 + T*(B2 + B3*T)) + B5*S)
+//     lam = (C0 + C4*S) + T*((C1 + T*(C2 + C3*T)) + C5*S)
+// Every sub-expression below is one of the reference's own sub-expressions, rounded the same
+// way, so ExactOps stays bit-identical to numpy.  The split is what lets the kernels evaluate a
+// part ONCE when its field is held at the reference state (thermosteric: S, halosteric: T) and
+// share parts between the three variants in the one-pass decomposition kernel.  FusedOps uses
+// the same tree, so all kernels agree bit for bit with each other in that mode too.
 template <typename R>
-__device__ __forceinline__ void wright_terms(R T, R S, R& al0, R& p0, R& lam) {
+struct TPart {  // functions of T
+  R t, a01, tb, tc;
+};
+template <typename R>
+struct SPart {  // functions of S (and, FusedOps only, of the pressure folded into b04)
+  R a2s, b04, b5s, c04, c5s;
+};
+
+template <typename Ops, typename R>
+__device__ __forceinline__ TPart<R> t_part(R T) {
   using K = WrightC<R>;
-  al0 = (K::A0 + K::A1 * T) + K::A2 * S;
-  p0 = (K::B0 + K::B4 * S) + T * ((K::B1 + T * (K::B2 + K::B3 * T)) + K::B5 * S);
-  lam = (K::C0 + K::C4 * S) + T * ((K::C1 + T * (K::C2 + K::C3 * T)) + K::C5 * S);
+  TPart<R> h;
+  h.t = T;
+  h.a01 = Ops::mad(K::A1, T, K::A0);                        // A0 + A1*T
+  h.tb = Ops::mad(T, Ops::mad(K::B3, T, K::B2), K::B1);     // B1 + T*(B2 + B3*T)
+  h.tc = Ops::mad(T, Ops::mad(K::C3, T, K::C2), K::C1);     // C1 + T*(C2 + C3*T)
+  return h;
 }
 
-// ---- held-field hoisting (thermosteric: S fixed in time; halosteric: T fixed) --------------
-// The sub-expressions of al0, p0, lam that depend only on the held field are evaluated once
-// per cell, outside the time loop.  They are the SAME sub-expressions, rounded the same way,
-// so the result stays bit-identical to wright_terms(); only 7 (S held) or 10 (T held) of the
-// ~26 polynomial operations per cell and time step disappear.
-template <typename R>
-struct HeldS {  // terms of S only
-  R a2s, b04s, b5s, c04s, c5s;
-};
-template <typename R>
-struct HeldT {  // terms of T only
-  R t, a01t, bpoly, cpoly;
-};
-
-template <typename R>
-__device__ __forceinline__ HeldS<R> hold_S(R S) {
+// p_fold: FusedOps folds the pressure into the constant term (B0 + p, rounded once per z level
+// or cell) so that p + p0 costs nothing; ExactOps must keep numpy's (p + p0) and passes 0.
+template <typename Ops, typename R>
+__device__ __forceinline__ SPart<R> s_part(R S, R p_fold) {
   using K = WrightC<R>;
-  HeldS<R> h;
+  SPart<R> h;
   h.a2s = K::A2 * S;
-  h.b04s = K::B0 + K::B4 * S;
+  if constexpr (Ops::fused) h.b04 = Ops::mad(K::B4, S, K::B0 + p_fold);
+  else h.b04 = Ops::mad(K::B4, S, K::B0);                   // B0 + B4*S
   h.b5s = K::B5 * S;
-  h.c04s = K::C0 + K::C4 * S;
+  h.c04 = Ops::mad(K::C4, S, K::C0);                        // C0 + C4*S
   h.c5s = K::C5 * S;
   return h;
 }
 
-template <typename R>
-__device__ __forceinline__ HeldT<R> hold_T(R T) {
-  using K = WrightC<R>;
-  HeldT<R> h;
-  h.t = T;
-  h.a01t = K::A0 + K::A1 * T;
-  h.bpoly = K::B1 + T * (K::B2 + K::B3 * T);
-  h.cpoly = K::C1 + T * (K::C2 + K::C3 * T);
-  return h;
+// rho from the two parts: eos/wright.py:44-48
+template <typename Ops, typename R>
+__device__ __forceinline__ double wright_combine(const TPart<R>& a, const SPart<R>& b, double p) {
+  const R al0 = a.a01 + b.a2s;
+  const R p0 = Ops::mad(a.t, a.tb + b.b5s, b.b04);
+  const R lam = Ops::mad(a.t, a.tc + b.c5s, b.c04);
+  double pp0;
+  if constexpr (Ops::fused) pp0 = (double)p0;  // p is inside b04
+  else pp0 = p + (double)p0;
+  const double den = Ops::mad((double)al0, pp0, (double)lam);  // lam + al0*(p + p0)
+  return Ops::quotient(pp0, den);
 }
 
+// al0, p0, lam in precision R (double, or float for numpy's float32 inputs: the python-float
+// constants are weak scalars and are rounded to float32 first) -- used by the derivatives
 template <typename R>
-__device__ __forceinline__ void wright_terms_heldS(R T, const HeldS<R>& h, R& al0, R& p0, R& lam) {
-  using K = WrightC<R>;
-  al0 = (K::A0 + K::A1 * T) + h.a2s;
-  p0 = h.b04s + T * ((K::B1 + T * (K::B2 + K::B3 * T)) + h.b5s);
-  lam = h.c04s + T * ((K::C1 + T * (K::C2 + K::C3 * T)) + h.c5s);
-}
-
-template <typename R>
-__device__ __forceinline__ void wright_terms_heldT(const HeldT<R>& h, R S, R& al0, R& p0, R& lam) {
-  using K = WrightC<R>;
-  al0 = h.a01t + K::A2 * S;
-  p0 = (K::B0 + K::B4 * S) + h.t * (h.bpoly + K::B5 * S);
-  lam = (K::C0 + K::C4 * S) + h.t * (h.cpoly + K::C5 * S);
-}
-
-// rho from (al0, p0, lam) already widened to float64: eos/wright.py:47-48
-__device__ __forceinline__ double wright_density_from_terms(double al0, double p0, double lam,
-                                                            double p) {
-  const double pp0 = p + p0;
-  const double I_denom = 1.0 / (lam + al0 * pp0);
-  return pp0 * I_denom;
+__device__ __forceinline__ void wright_terms(R T, R S, R& al0, R& p0, R& lam) {
+  const TPart<R> a = t_part<ExactOps, R>(T);
+  const SPart<R> b = s_part<ExactOps, R>(S, R(0));
+  al0 = a.a01 + b.a2s;
+  p0 = b.b04 + a.t * (a.tb + b.b5s);
+  lam = b.c04 + a.t * (a.tc + b.c5s);
 }
 
 // arithmetic type of the polynomial part for a dtype mode
@@ -135,21 +169,13 @@ struct PolyType<kF32Faithful> {
 };
 
 // in-situ density, eos/wright.py:44-48.  MODE selects how float32 inputs are treated.
-template <int MODE, typename TIn>
+template <int MODE, typename TIn, typename Ops = ExactOps>
 __device__ __forceinline__ double wright_density(TIn Tin, TIn Sin, double p) {
-  double al0, p0, lam;
-  if constexpr (MODE == kF32Faithful) {
-    float a, b, c;
-    wright_terms<float>(Tin, Sin, a, b, c);
-    al0 = (double)a;
-    p0 = (double)b;
-    lam = (double)c;
-  } else {
-    wright_terms<double>((double)Tin, (double)Sin, al0, p0, lam);
-  }
-  const double pp0 = p + p0;
-  const double I_denom = 1.0 / (lam + al0 * pp0);
-  return pp0 * I_denom;
+  typedef typename PolyType<MODE>::type R;
+  static_assert(!(Ops::fused && MODE == kF32Faithful), "FusedOps computes in float64");
+  const TPart<R> a = t_part<Ops, R>((R)Tin);
+  const SPart<R> b = s_part<Ops, R>((R)Sin, Ops::fused ? (R)p : R(0));
+  return wright_combine<Ops, R>(a, b, p);
 }
 
 // eos/wright.py:74-83 (float64 only)
@@ -225,7 +251,9 @@ __device__ __forceinline__ double linear_density(TIn Tin, TIn Sin) {
 }
 
 // runtime-dispatched EOS function (generic kernels; eos/func are wave-uniform)
-template <int MODE, typename TIn>
+// Ops applies to the Wright DENSITY only (the one function on the steric path); the derivatives
+// and the linear EOS are always evaluated exactly.
+template <int MODE, typename TIn, typename Ops = ExactOps>
 __device__ __forceinline__ double eos_eval(int eos, int func, TIn T, TIn S, double p,
                                            double aux = 0.0) {
   if (func == kIbh) {  // pso * (-1.0 / (rho_conv * gravity))
@@ -238,7 +266,7 @@ __device__ __forceinline__ double eos_eval(int eos, int func, TIn T, TIn S, doub
   }
   switch (func) {
     case kDensity:
-      return wright_density<MODE, TIn>(T, S, p);
+      return wright_density<MODE, TIn, Ops>(T, S, p);
     case kDrhoDtemp:
       if constexpr (MODE == kF32Faithful) return wright_drho_dtemp_f32(T, S, p);
       else return wright_drho_dtemp((double)T, (double)S, p);

@@ -27,6 +27,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <initializer_list>
+#include <type_traits>
+
 #include "../../include/momlevel_hip.h"
 #include "eos_device.hpp"
 
@@ -112,26 +115,47 @@ __device__ __forceinline__ double wave_sum(double v) {
 // grid = (ceil(plane / (kBlock*VEC*U)), nz, ceil(nt/t_chunk)); each thread owns U packs of
 // VEC adjacent cells of ONE z level, keeps their vol0 (and p, if FULL3D) in registers and
 // loops over the time steps of its chunk.  Per time step it parks its partial in LDS row
-// (t - chunk start) % kNTC; every kNTC steps the block reduces the parked rows (fixed order) and
+// (t - chunk start) % NTC; every NTC steps the block reduces the parked rows (fixed order) and
 // writes partials[t][block].  A second kernel (k_reduce_rows) sums partials[t][:] in a fixed
 // order -> masso[t].
 //
-// HOLD: 0 = both fields stream, 1 = T is time-invariant (halosteric), 2 = S is
-// (thermosteric); the held field is loaded once.  GENERIC (VEC==1 instantiation)
-// takes eos/p_mode at run time and honours any stride, incl. 0, by reloading.
+// VAR (steric.py:115-125): 0 = steric, both fields stream; 1 = halosteric, theta is held at the
+// reference state T0; 2 = thermosteric, S is held at S0; 3 = ALL THREE in one pass over theta/S
+// (+ the heat-content integrand sum(theta*vol0), an extension) -- 4 partials per step,
+// partials[(o*nt + t)][block], o = 0 steric, 1 thermosteric, 2 halosteric, 3 heat.  The held
+// field is read once and its part of the polynomial (eos_device.hpp TPart/SPart) is evaluated
+// once, outside the time loop; VAR 3 also shares the streamed fields' parts between the
+// variants.  Every variant adds the same terms in the same order from the same tiling, so each
+// output of VAR 3 is bit-identical to the corresponding single-variant launch, and masso(t=0)
+// of all of them to the reference state's masso0.
+// GENERIC (VEC==1 instantiation) takes eos/p_mode at run time, incl. a time-dependent
+// pressure (MLX_P_FULL4D), and evaluates every density from scratch.
 // SKIP (MLX_FLAG_SKIP_DRY): a pack whose vol0 is NaN in every cell contributes exactly 0
 // whatever theta/S hold (rho*NaN is skipped), so its lanes neither load nor compute; whole
 // 64/128-byte lines of land or sub-bottom cells then never leave HBM.  Same bits out.
+// FMA (MLX_FLAG_FMA): FusedOps arithmetic (eos_device.hpp), float64, not bit-identical to numpy.
 // ------------------------------------------------------------------------------------
-template <typename TIn, int VEC, int U, int HOLD, int MODE, bool GENERIC, bool SKIP = false>
+constexpr int kVarSteric = 0, kVarHalo = 1, kVarThermo = 2, kVarAll = 3;
+
+template <typename TIn, int VEC, int U, int VAR, int MODE, bool GENERIC, bool SKIP, bool FMA>
 __global__ __launch_bounds__(kBlock) void k_steric_global(
-    const TIn* __restrict__ T, const TIn* __restrict__ S, const double* __restrict__ vol0,
-    const double* __restrict__ p, int p_mode, int eos, int nt, int t_chunk, int64_t plane,
-    int64_t t_stride_T, int64_t t_stride_S, double* __restrict__ partials, int64_t nblk_total) {
-  __shared__ double red[kNTC][kBlock];
+    const TIn* __restrict__ T, const TIn* __restrict__ S, const TIn* __restrict__ T0,
+    const TIn* __restrict__ S0, const double* __restrict__ vol0, const double* __restrict__ p,
+    int p_mode, int eos, int nt, int t_chunk, int64_t plane, int64_t t_stride_T,
+    int64_t t_stride_S, double* __restrict__ partials, int64_t nblk_total) {
+  constexpr int NOUT = (VAR == kVarAll) ? 4 : 1;
+  constexpr int NTC = (VAR == kVarAll) ? kNTC / 2 : kNTC;  // LDS: NOUT*NTC*kBlock doubles
+  constexpr bool STREAM_T = (VAR != kVarHalo), STREAM_S = (VAR != kVarThermo);
+  constexpr bool HELD_T = (VAR == kVarHalo || VAR == kVarAll);
+  constexpr bool HELD_S = (VAR == kVarThermo || VAR == kVarAll);
+  typedef typename PolyType<MODE>::type R;
+  typedef typename std::conditional<FMA, FusedOps, ExactOps>::type Ops;
+  static_assert(!FMA || MODE != kF32Faithful, "fused arithmetic is float64");
+  __shared__ double red[NOUT][NTC][kBlock];
 
   const int tid = threadIdx.x;
   const int z = blockIdx.y;
+  const int nz = gridDim.y;
   // blockIdx.z = time chunk (slowest grid dimension): the resident blocks all work inside one
   // window of t_chunk time steps instead of drifting over the whole record (+3.7 % measured
   // at nt=120, scripts/tune_k1.hip), at the price of re-reading vol0 once per chunk.
@@ -169,90 +193,138 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
   double pz = 0.0;
   if (!GENERIC || p_mode == MLX_P_ZPROF) pz = p[z];
   if (GENERIC && p_mode == MLX_P_SCALAR) pz = p[0];
+  const R pfold = FMA ? (R)pz : R(0);  // FusedOps folds the level's pressure into B0
 
-  // HOLD != 0: the held field is read once and its share of the polynomial is hoisted out of
-  // the time loop (eos_device.hpp, "held-field hoisting"); only the other field streams.
-  typedef typename PolyType<MODE>::type R;
-  HeldS<R> hs[HOLD == 2 ? U : 1][VEC];
-  HeldT<R> ht[HOLD == 1 ? U : 1][VEC];
-  if constexpr (HOLD == 2) {
+  // held fields: read once; fast path keeps their PART of the polynomial, generic the values
+  TPart<R> t0p[(HELD_T && !GENERIC) ? U : 1][VEC];
+  SPart<R> s0p[(HELD_S && !GENERIC) ? U : 1][VEC];
+  TIn t0v[(HELD_T && GENERIC) ? U : 1][VEC], s0v[(HELD_S && GENERIC) ? U : 1][VEC];
+  if constexpr (HELD_T) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      Pack<TIn, VEC> s0 = {};
-      if (alive[u]) s0 = load_pack<TIn, VEC, true>(S + off[u]);
+      Pack<TIn, VEC> h = {};
+      if (alive[u]) h = load_pack<TIn, VEC, true>(T0 + off[u]);
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) hs[u][k] = hold_S<R>((R)s0.v[k]);
+      for (int k = 0; k < VEC; ++k) {
+        if constexpr (GENERIC) t0v[u][k] = h.v[k];
+        else t0p[u][k] = t_part<Ops, R>((R)h.v[k]);
+      }
     }
   }
-  if constexpr (HOLD == 1) {
+  if constexpr (HELD_S) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      Pack<TIn, VEC> t0 = {};
-      if (alive[u]) t0 = load_pack<TIn, VEC, true>(T + off[u]);
+      Pack<TIn, VEC> h = {};
+      if (alive[u]) h = load_pack<TIn, VEC, true>(S0 + off[u]);
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) ht[u][k] = hold_T<R>((R)t0.v[k]);
+      for (int k = 0; k < VEC; ++k) {
+        if constexpr (GENERIC) s0v[u][k] = h.v[k];
+        else s0p[u][k] = s_part<Ops, R>((R)h.v[k], pfold);
+      }
     }
   }
 
-  Pack<TIn, VEC> curT[U], curS[U], nxtT[U], nxtS[U];
+  // Register double buffering of the streams -- except in the float64 all-variants kernel, whose
+  // 9 held doubles per cell leave no room for a second set of packs: it would drop to one wave
+  // per SIMD.  That kernel is VALU-bound (~100 ops per cell), two waves per SIMD cover each
+  // other's load latency.
+  constexpr bool PREFETCH = !(VAR == kVarAll && sizeof(TIn) == 8 && !GENERIC);
+  Pack<TIn, VEC> curT[U], curS[U], nxtT[PREFETCH ? U : 1], nxtS[PREFETCH ? U : 1];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
+  for (int u = 0; u < (PREFETCH ? U : 0); ++u) {
     nxtT[u] = {};
     nxtS[u] = {};
     if (alive[u]) {
-      if (HOLD != 1) nxtT[u] = load_pack<TIn, VEC, true>(T + (int64_t)tb * t_stride_T + off[u]);
-      if (HOLD != 2) nxtS[u] = load_pack<TIn, VEC, true>(S + (int64_t)tb * t_stride_S + off[u]);
+      if (STREAM_T) nxtT[u] = load_pack<TIn, VEC, true>(T + (int64_t)tb * t_stride_T + off[u]);
+      if (STREAM_S) nxtS[u] = load_pack<TIn, VEC, true>(S + (int64_t)tb * t_stride_S + off[u]);
     }
   }
 
   for (int t = tb; t < te; ++t) {
+    if constexpr (!PREFETCH) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (HOLD != 1) curT[u] = nxtT[u];
-      if (HOLD != 2) curS[u] = nxtS[u];
+      for (int u = 0; u < U; ++u) {
+        curT[u] = {};
+        curS[u] = {};
+        if (alive[u]) {
+          if (STREAM_T) curT[u] = load_pack<TIn, VEC, true>(T + (int64_t)t * t_stride_T + off[u]);
+          if (STREAM_S) curS[u] = load_pack<TIn, VEC, true>(S + (int64_t)t * t_stride_S + off[u]);
+        }
+      }
     }
-    if (t + 1 < te) {  // issue the next step's loads before this step's arithmetic
+#pragma unroll
+    for (int u = 0; u < (PREFETCH ? U : 0); ++u) {
+      if (STREAM_T) curT[u] = nxtT[u];
+      if (STREAM_S) curS[u] = nxtS[u];
+    }
+    if (PREFETCH && t + 1 < te) {  // issue the next step's loads before this step's arithmetic
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (alive[u]) {
-          if (HOLD != 1)
+          if (STREAM_T)
             nxtT[u] = load_pack<TIn, VEC, true>(T + (int64_t)(t + 1) * t_stride_T + off[u]);
-          if (HOLD != 2)
+          if (STREAM_S)
             nxtS[u] = load_pack<TIn, VEC, true>(S + (int64_t)(t + 1) * t_stride_S + off[u]);
         }
       }
     }
-    double c = 0.0;
+    double c[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) c[o] = 0.0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (SKIP && !alive[u]) continue;  // adds exactly nothing: c + 0.0 == c
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
-        double rho;
+        double rho[NOUT > 1 ? 3 : 1];
         if constexpr (GENERIC) {
-          const double pp = (p_mode == MLX_P_FULL3D) ? pc[u][k] : pz;
-          rho = eos_eval<MODE, TIn>(eos, kDensity, curT[u].v[k], curS[u].v[k], pp);
-        } else if constexpr (HOLD == 0) {
-          rho = wright_density<MODE, TIn>(curT[u].v[k], curS[u].v[k], pz);
+          double pp = pz;
+          if (p_mode == MLX_P_FULL3D) pp = pc[u][k];
+          if (p_mode == MLX_P_FULL4D) pp = p[((int64_t)t * nz) * plane + off[u] + k];
+          const TIn tv = STREAM_T ? curT[u].v[k] : t0v[u][k];
+          const TIn sv = STREAM_S ? curS[u].v[k] : s0v[u][k];
+          rho[0] = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, sv, pp);
+          if constexpr (VAR == kVarAll) {
+            rho[1] = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, s0v[u][k], pp);
+            rho[2] = eos_eval<MODE, TIn, Ops>(eos, kDensity, t0v[u][k], sv, pp);
+          }
         } else {
-          R al0, p0, lam;
-          if constexpr (HOLD == 2) wright_terms_heldS<R>((R)curT[u].v[k], hs[u][k], al0, p0, lam);
-          else wright_terms_heldT<R>(ht[u][k], (R)curS[u].v[k], al0, p0, lam);
-          rho = wright_density_from_terms((double)al0, (double)p0, (double)lam, pz);
+          TPart<R> a;
+          SPart<R> b;
+          if constexpr (STREAM_T) a = t_part<Ops, R>((R)curT[u].v[k]);
+          if constexpr (STREAM_S) b = s_part<Ops, R>((R)curS[u].v[k], pfold);
+          if constexpr (VAR == kVarSteric) rho[0] = wright_combine<Ops, R>(a, b, pz);
+          if constexpr (VAR == kVarHalo) rho[0] = wright_combine<Ops, R>(t0p[u][k], b, pz);
+          if constexpr (VAR == kVarThermo) rho[0] = wright_combine<Ops, R>(a, s0p[u][k], pz);
+          if constexpr (VAR == kVarAll) {
+            rho[0] = wright_combine<Ops, R>(a, b, pz);
+            rho[1] = wright_combine<Ops, R>(a, s0p[u][k], pz);
+            rho[2] = wright_combine<Ops, R>(t0p[u][k], b, pz);
+          }
         }
-        const double term = rho * vol[u][k];  // derived.py:435
-        c += is_nan(term) ? 0.0 : term;       // skipna
+#pragma unroll
+        for (int o = 0; o < (NOUT > 1 ? 3 : 1); ++o) {
+          const double term = rho[o] * vol[u][k];  // derived.py:435
+          c[o] += is_nan(term) ? 0.0 : term;       // skipna
+        }
+        if constexpr (VAR == kVarAll) {  // extension: heat-content integrand theta*vol0
+          const double term = (double)curT[u].v[k] * vol[u][k];
+          c[3] += is_nan(term) ? 0.0 : term;
+        }
       }
     }
-    const int row = (t - tb) % kNTC;
-    red[row][tid] = c;
-    if (row == kNTC - 1 || t == te - 1) {
+    const int row = (t - tb) % NTC;
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) red[o][row][tid] = c[o];
+    if (row == NTC - 1 || t == te - 1) {
       __syncthreads();
       const int wave = tid >> 6, lane = tid & 63;
-      for (int r = wave; r <= row; r += kBlock / 64) {
-        double v = ((red[r][lane] + red[r][lane + 64]) + red[r][lane + 128]) + red[r][lane + 192];
+      for (int q = wave; q < NOUT * (row + 1); q += kBlock / 64) {
+        const int o = q / (row + 1), r = q % (row + 1);
+        double v = ((red[o][r][lane] + red[o][r][lane + 64]) + red[o][r][lane + 128]) +
+                   red[o][r][lane + 192];
         v = wave_sum(v);
-        if (lane == 0) partials[(int64_t)(t - row + r) * nblk_total + blk] = v;
+        if (lane == 0) partials[((int64_t)o * nt + (t - row + r)) * nblk_total + blk] = v;
       }
       __syncthreads();
     }
@@ -332,10 +404,27 @@ __global__ __launch_bounds__(kBlock) void k_nansum_partial(const double* __restr
   if (threadIdx.x == 0) partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
+// Streaming probe for K2: reads 16 B and writes 8 B per element with the same 16-byte nt loads
+// and stores as the fused local kernel, and no arithmetic to speak of (out = a + b) -- the box's
+// read+write ceiling that `local_with_delta_rho` runs against (bench.py).
+__global__ __launch_bounds__(kBlock) void k_stream_probe(const double* __restrict__ a,
+                                                         const double* __restrict__ b, int64_t n2,
+                                                         double* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
+       i += (int64_t)gridDim.x * kBlock) {
+    const Pack<double, 2> x = load_pack<double, 2, true>(a + 2 * i);
+    const Pack<double, 2> y = load_pack<double, 2, true>(b + 2 * i);
+    Pack<double, 2> r;
+    r.v[0] = x.v[0] + y.v[0];
+    r.v[1] = x.v[1] + y.v[1];
+    store_pack<2, true>(out + 2 * i, r);
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // K0: pointwise EOS map.  grid = (ceil(plane/(kBlock*VEC*U)), nz, nt)
 // ------------------------------------------------------------------------------------
-template <typename TIn, int VEC, int U, int MODE, int FUNC, bool GENERIC>
+template <typename TIn, int VEC, int U, int MODE, int FUNC, bool GENERIC, bool FMA = false>
 __global__ __launch_bounds__(kBlock) void k_eos_map(const TIn* __restrict__ T,
                                                     const TIn* __restrict__ S,
                                                     const double* __restrict__ p, int p_mode,
@@ -343,6 +432,7 @@ __global__ __launch_bounds__(kBlock) void k_eos_map(const TIn* __restrict__ T,
                                                     int64_t t_stride_T, int64_t t_stride_S,
                                                     int64_t t_base, double aux,
                                                     double* __restrict__ out) {
+  typedef typename std::conditional<FMA, FusedOps, ExactOps>::type Ops;
   const int z = blockIdx.y;
   const int64_t t = t_base + blockIdx.z;
   const int64_t tile0 = (int64_t)blockIdx.x * (kBlock * VEC * U);
@@ -370,9 +460,9 @@ __global__ __launch_bounds__(kBlock) void k_eos_map(const TIn* __restrict__ T,
         double pp = pz;
         if (p_mode == MLX_P_FULL3D) pp = p[off[u] + k];
         if (p_mode == MLX_P_FULL4D) pp = p[t * nz * plane + off[u] + k];
-        r.v[k] = eos_eval<MODE, TIn>(eos, func, a[u].v[k], b[u].v[k], pp, aux);
+        r.v[k] = eos_eval<MODE, TIn, Ops>(eos, func, a[u].v[k], b[u].v[k], pp, aux);
       } else {
-        r.v[k] = eos_eval<MODE, TIn>(kWright, FUNC, a[u].v[k], b[u].v[k], pz);
+        r.v[k] = eos_eval<MODE, TIn, Ops>(kWright, FUNC, a[u].v[k], b[u].v[k], pz);
       }
     }
     if (valid[u]) store_pack<VEC, true>(out + t * nz * plane + off[u], r);
@@ -412,7 +502,7 @@ __device__ __forceinline__ double dz_default(double depth, double ztop, double z
 // (scripts/tune_k2.hip) than NTI=8 at 4 waves/SIMD: half the rho0m re-reads and twice the
 // bytes in flight per wave.  theta/S loads and the delta_rho stores use the nt policy.
 // ------------------------------------------------------------------------------------
-template <typename TIn, int VEC, int NTI, int HOLD, int MODE, bool GENERIC, bool SKIP = false>
+template <typename TIn, int VEC, int NTI, int HOLD, int MODE, bool GENERIC, bool SKIP, bool FMA>
 __global__ __launch_bounds__(kBlock) void k_steric_local(
     const TIn* __restrict__ T, const TIn* __restrict__ S, const double* __restrict__ rho0m,
     const double* __restrict__ vol0_surface, const double* __restrict__ dz,
@@ -420,6 +510,9 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
     const double* __restrict__ p, int p_mode, int eos, double neg_inv_rhozero, int nt, int nz,
     int64_t plane, int64_t t_stride_T, int64_t t_stride_S, double* __restrict__ drho_out,
     double* __restrict__ eta_out) {
+  typedef typename PolyType<MODE>::type R;
+  typedef typename std::conditional<FMA, FusedOps, ExactOps>::type Ops;
+  static_assert(!FMA || MODE != kF32Faithful, "fused arithmetic is float64");
   const int64_t col = (xcd_remap(blockIdx.x, gridDim.x) * kBlock + threadIdx.x) * VEC;
   if (col + VEC > plane) return;  // whole packs only; no barrier below
   const int t0 = blockIdx.y * NTI;
@@ -464,10 +557,23 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
       for (int k = 0; k < VEC; ++k) alive = alive || !is_nan(r0.v[k]);
     }
 
+    // the held field (HOLD 1: theta, 2: S) is read once per level and -- fast path -- its part
+    // of the polynomial evaluated once for the NTI time steps (eos_device.hpp TPart/SPart)
     Pack<TIn, VEC> hT = {}, hS = {};
     if (alive) {
       if (HOLD == 1) hT = load_pack<TIn, VEC>(T + off);
       if (HOLD == 2) hS = load_pack<TIn, VEC>(S + off);
+    }
+    const R pfold = FMA ? (R)pz : R(0);
+    TPart<R> hTp[VEC];
+    SPart<R> hSp[VEC];
+    if constexpr (!GENERIC && HOLD == 1) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) hTp[k] = t_part<Ops, R>((R)hT.v[k]);
+    }
+    if constexpr (!GENERIC && HOLD == 2) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) hSp[k] = s_part<Ops, R>((R)hS.v[k], pfold);
     }
 
     Pack<TIn, VEC> a[NTI], b[NTI];
@@ -494,10 +600,15 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
           const TIn sv = (HOLD == 2) ? hS.v[k] : b[j].v[k];
           double rho;
           if constexpr (GENERIC) {
-            const double pp = (p_mode == MLX_P_FULL3D) ? pfull.v[k] : pz;
-            rho = eos_eval<MODE, TIn>(eos, kDensity, tv, sv, pp);
+            double pp = (p_mode == MLX_P_FULL3D) ? pfull.v[k] : pz;
+            if (p_mode == MLX_P_FULL4D) pp = p[(int64_t)(t0 + j) * n3 + off + k];
+            rho = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, sv, pp);
+          } else if constexpr (HOLD == 1) {
+            rho = wright_combine<Ops, R>(hTp[k], s_part<Ops, R>((R)sv, pfold), pz);
+          } else if constexpr (HOLD == 2) {
+            rho = wright_combine<Ops, R>(t_part<Ops, R>((R)tv), hSp[k], pz);
           } else {
-            rho = wright_density<MODE, TIn>(tv, sv, pz);
+            rho = wright_density<MODE, TIn, Ops>(tv, sv, pz);
           }
           double dr = rho - r0.v[k];               // steric.py:152 (NaN where vol0 is NaN)
           dr = is_nan(dr) ? canonical_nan() : dr;  // canonical payload
@@ -615,6 +726,8 @@ __global__ __launch_bounds__(kBlock) void k_synth(TOut* __restrict__ out, int64_
 // =====================================================================================
 namespace {
 
+using namespace mlx;
+
 thread_local char g_err[512] = "";
 
 int fail(int code, const char* msg) {
@@ -635,34 +748,16 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // cells a K1 block covers within one z level
 constexpr int kU64 = 4, kVec64 = 2;  // 8 cells/thread, 2048 cells/block (fast f64)
 constexpr int kU32 = 2, kVec32 = 4;  // 8 cells/thread (fast f32)
-// NB: every variant of a dtype (steric / thermosteric / halosteric, any nt) must share ONE tiling:
-// the reference state's masso0 (HOLD=0, nt=1) has to equal masso(t=0) of the held-field launches
-// bit for bit, and the partial-sum order is a function of the tiling.
+// NB: every variant of a dtype (steric / thermosteric / halosteric / all-in-one, any nt) must
+// share ONE tiling: the reference state's masso0 (VAR 0, nt=1) has to equal masso(t=0) of the
+// held-field launches bit for bit, and the partial-sum order is a function of the tiling.
 constexpr int kUGen = 4;             // generic: 4 scalar cells/thread, 1024 cells/block
-constexpr int kTChunk = 32;          // K1 time steps per block (grid.z = ceil(nt / kTChunk))
+constexpr int kTChunk = 32;          // K1 time steps per block (grid.z = ceil(nt / t_chunk))
 constexpr int kNTI64 = 16;           // time steps per K2 thread, f64 (2 columns/thread)
 constexpr int kNTI32 = 8;            // f32 (4 columns/thread)
 constexpr int kNTIGen = 8;           // generic scalar path
 
-struct GlobalPlan {
-  bool fast;
-  int64_t grid_x;
-  int64_t nblk_total;
-};
-
-GlobalPlan plan_global(const void* T, const void* S, const double* vol0, int dtype, int p_mode,
-                       int eos, int64_t nz, int64_t plane, int64_t sT, int64_t sS) {
-  const int vec = (dtype == MLX_DTYPE_F64) ? kVec64 : kVec32;
-  const int u = (dtype == MLX_DTYPE_F64) ? kU64 : kU32;
-  GlobalPlan pl;
-  pl.fast = (eos == MLX_EOS_WRIGHT) && (p_mode == MLX_P_ZPROF) && (plane % vec == 0) &&
-            (sT % vec == 0) && (sS % vec == 0) && !(sT == 0 && sS == 0) && aligned(T, 16) &&
-            aligned(S, 16) && aligned(vol0, 16);
-  const int64_t cells = pl.fast ? (int64_t)mlx::kBlock * vec * u : (int64_t)mlx::kBlock * kUGen;
-  pl.grid_x = ceil_div(plane, cells);
-  pl.nblk_total = pl.grid_x * nz;
-  return pl;
-}
+constexpr int kKnownFlags = MLX_FLAG_SKIP_DRY | MLX_FLAG_FMA | MLX_FLAG_TCHUNK_MASK;
 
 int check_dtype(int dtype) {
   if (dtype != MLX_DTYPE_F64 && dtype != MLX_DTYPE_F32 && dtype != MLX_DTYPE_F32_UPCAST)
@@ -671,20 +766,198 @@ int check_dtype(int dtype) {
 }
 
 int check_common(const void* T, const void* S, int dtype, const double* p, int p_mode, int eos,
-                 int64_t nt, int64_t nz, int64_t plane, int64_t sT, int64_t sS, bool allow4d) {
+                 int64_t nt, int64_t nz, int64_t plane, int64_t sT, int64_t sS) {
   if (!T || !S) return fail(MLX_E_NULL, "T and S must not be NULL");
   if (int rc = check_dtype(dtype)) return rc;
   if (eos != MLX_EOS_WRIGHT && eos != MLX_EOS_LINEAR) return fail(MLX_E_ENUM, "unknown eos");
-  if (p_mode < MLX_P_SCALAR || p_mode > (allow4d ? MLX_P_FULL4D : MLX_P_FULL3D))
-    return fail(MLX_E_ENUM, "p_mode not supported by this entry point");
+  if (p_mode < MLX_P_SCALAR || p_mode > MLX_P_FULL4D) return fail(MLX_E_ENUM, "unknown p_mode");
   if (!p && eos == MLX_EOS_WRIGHT) return fail(MLX_E_NULL, "p must not be NULL for the Wright EOS");
   if (nt <= 0 || nz <= 0 || plane <= 0) return fail(MLX_E_SHAPE, "nt, nz, plane must be > 0");
   if (nz > 65535) return fail(MLX_E_SHAPE, "nz must be <= 65535");
   if (nt > 2147483647LL) return fail(MLX_E_SHAPE, "nt too large");
+  if (plane > (int64_t)1 << 40) return fail(MLX_E_SHAPE, "plane too large");
   if (sT < 0 || sS < 0) return fail(MLX_E_SHAPE, "time strides must be >= 0");
   const size_t es = (dtype == MLX_DTYPE_F64) ? 8 : 4;
   if (!aligned(T, es) || !aligned(S, es)) return fail(MLX_E_ALIGN, "T/S not element-aligned");
+  if (p && !aligned(p, 8)) return fail(MLX_E_ALIGN, "p not 8-byte aligned");
   return 0;
+}
+
+inline int vec_of(int dtype) { return (dtype == MLX_DTYPE_F64) ? kVec64 : kVec32; }
+
+// the dwordx4 kernels need: Wright EOS, z-profile pressure, whole packs per plane and per time
+// stride, 16-byte aligned operands; everything else takes the generic (scalar) twin
+bool fast_layout(int dtype, int p_mode, int eos, int64_t plane, int64_t sT, int64_t sS,
+                 std::initializer_list<const void*> ptrs) {
+  const int vec = vec_of(dtype);
+  if (eos != MLX_EOS_WRIGHT || p_mode != MLX_P_ZPROF) return false;
+  if (plane % vec || sT % vec || sS % vec) return false;
+  for (const void* q : ptrs)
+    if (q && !aligned(q, 16)) return false;
+  return true;
+}
+
+// ---- K1 dispatch -------------------------------------------------------------------------
+struct K1Args {
+  dim3 grid;
+  hipStream_t st;
+  const void *T, *S, *T0, *S0;
+  const double *vol0, *p;
+  int p_mode, eos, nt, t_chunk;
+  int64_t plane, sT, sS;
+  double* partials;
+  int64_t nblk;
+};
+
+template <typename TIn, int VEC, int U, int VAR, int MODE, bool GEN, bool SKIP, bool FMA>
+void k1_go(const K1Args& a) {
+  hipLaunchKernelGGL((k_steric_global<TIn, VEC, U, VAR, MODE, GEN, SKIP, FMA>), a.grid,
+                     dim3(kBlock), 0, a.st, (const TIn*)a.T, (const TIn*)a.S, (const TIn*)a.T0,
+                     (const TIn*)a.S0, a.vol0, a.p, a.p_mode, a.eos, a.nt, a.t_chunk, a.plane,
+                     a.sT, a.sS, a.partials, a.nblk);
+}
+
+template <typename TIn, int VEC, int U, int VAR, int MODE, bool GEN>
+void k1_flags(const K1Args& a, bool skip, bool fma) {
+  constexpr int FM = (MODE == kF32Faithful) ? kF32Upcast : MODE;  // fused arithmetic is float64
+  constexpr bool S1 = !GEN;  // the generic twin has no skipping instantiation
+  if (fma) {
+    if (skip && S1) k1_go<TIn, VEC, U, VAR, FM, GEN, S1, true>(a);
+    else k1_go<TIn, VEC, U, VAR, FM, GEN, false, true>(a);
+  } else {
+    if (skip && S1) k1_go<TIn, VEC, U, VAR, MODE, GEN, S1, false>(a);
+    else k1_go<TIn, VEC, U, VAR, MODE, GEN, false, false>(a);
+  }
+}
+
+template <typename TIn, int VEC, int U, int MODE, bool GEN>
+void k1_var(const K1Args& a, int var, bool skip, bool fma) {
+  if constexpr (GEN) {  // held fields reach the generic twin as stride-0 streams (VAR 0)
+    if (var == kVarAll) k1_flags<TIn, VEC, U, kVarAll, MODE, GEN>(a, skip, fma);
+    else k1_flags<TIn, VEC, U, kVarSteric, MODE, GEN>(a, skip, fma);
+  } else {
+    switch (var) {
+      case kVarSteric: k1_flags<TIn, VEC, U, kVarSteric, MODE, GEN>(a, skip, fma); break;
+      case kVarHalo: k1_flags<TIn, VEC, U, kVarHalo, MODE, GEN>(a, skip, fma); break;
+      case kVarThermo: k1_flags<TIn, VEC, U, kVarThermo, MODE, GEN>(a, skip, fma); break;
+      default: k1_flags<TIn, VEC, U, kVarAll, MODE, GEN>(a, skip, fma); break;
+    }
+  }
+}
+
+void k1_dispatch(const K1Args& a, int dtype, bool fast, int var, bool skip, bool fma) {
+  if (fast) {
+    if (dtype == MLX_DTYPE_F64) k1_var<double, kVec64, kU64, kF64, false>(a, var, skip, fma);
+    else if (dtype == MLX_DTYPE_F32) k1_var<float, kVec32, kU32, kF32Faithful, false>(a, var, skip, fma);
+    else k1_var<float, kVec32, kU32, kF32Upcast, false>(a, var, skip, fma);
+  } else {
+    if (dtype == MLX_DTYPE_F64) k1_var<double, 1, kUGen, kF64, true>(a, var, skip, fma);
+    else if (dtype == MLX_DTYPE_F32) k1_var<float, 1, kUGen, kF32Faithful, true>(a, var, skip, fma);
+    else k1_var<float, 1, kUGen, kF32Upcast, true>(a, var, skip, fma);
+  }
+}
+
+int64_t k1_blocks(bool fast, int dtype, int64_t plane) {
+  const int64_t cells = fast ? (int64_t)kBlock * 8 : (int64_t)kBlock * kUGen;
+  (void)dtype;  // 8 cells per thread for both fast dtypes
+  return ceil_div(plane, cells);
+}
+
+int k1_time_chunk(int flags, int64_t nt) {
+  const int hint = (flags & MLX_FLAG_TCHUNK_MASK) >> 8;
+  int64_t tc = hint ? (int64_t)hint * 8 : kTChunk;
+  if (tc > nt) tc = nt;
+  return (int)tc;
+}
+
+// shared body of mlx_steric_global (nout 1) and mlx_steric_global_decomp (nout 4)
+int steric_global_impl(const void* T, const void* S, const void* T0, const void* S0, int var,
+                       int dtype, const double* vol0, const double* p, int p_mode, int eos,
+                       int64_t nt, int64_t nz, int64_t plane, int64_t sT, int64_t sS, int flags,
+                       double* out, void* workspace, size_t workspace_bytes, void* stream,
+                       const char* name) {
+  const int nout = (var == kVarAll) ? 4 : 1;
+  if (flags & ~kKnownFlags) return fail(MLX_E_ENUM, "unknown flag bits");
+  if (int rc = check_common(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS)) return rc;
+  if (!vol0 || !out) return fail(MLX_E_NULL, "vol0 and the output must not be NULL");
+  if (!aligned(vol0, 8) || !aligned(out, 8)) return fail(MLX_E_ALIGN, "vol0/out not 8-byte aligned");
+  if (var == kVarAll) {
+    if (!T0 || !S0) return fail(MLX_E_NULL, "T0 and S0 must not be NULL");
+    const size_t es = (dtype == MLX_DTYPE_F64) ? 8 : 4;
+    if (!aligned(T0, es) || !aligned(S0, es)) return fail(MLX_E_ALIGN, "T0/S0 not element-aligned");
+  }
+  if (!workspace) return fail(MLX_E_NULL, "workspace must not be NULL");
+  const size_t need = (size_t)nout * mlx_steric_global_workspace_bytes(nt, nz, plane);
+  if (!aligned(workspace, 8) || workspace_bytes < need)
+    return fail(MLX_E_WORKSPACE, "workspace smaller than the *_workspace_bytes() query");
+  const bool skip = (flags & MLX_FLAG_SKIP_DRY) != 0, fma = (flags & MLX_FLAG_FMA) != 0;
+  bool fast = fast_layout(dtype, p_mode, eos, plane, sT, sS, {T, S, T0, S0, vol0});
+  if (var != kVarAll) {
+    if (sT == 0 && sS == 0) fast = false;  // both held: nothing streams; the generic twin reloads
+    else if (sT == 0) { var = kVarHalo; T0 = T; }
+    else if (sS == 0) { var = kVarThermo; S0 = S; }
+  }
+  K1Args a;
+  const int64_t gx = k1_blocks(fast, dtype, plane);
+  a.t_chunk = k1_time_chunk(flags, nt);
+  if (ceil_div(nt, a.t_chunk) > 65535) return fail(MLX_E_SHAPE, "nt too large for one call: chunk it");
+  if (gx > 2147483647LL) return fail(MLX_E_SHAPE, "plane too large");
+  a.grid = dim3((unsigned)gx, (unsigned)nz, (unsigned)ceil_div(nt, a.t_chunk));
+  a.st = (hipStream_t)stream;
+  a.T = T; a.S = S; a.T0 = T0 ? T0 : T; a.S0 = S0 ? S0 : S;
+  a.vol0 = vol0; a.p = p ? p : vol0;  // p is never dereferenced for the linear EOS
+  a.p_mode = p_mode; a.eos = eos; a.nt = (int)nt;
+  a.plane = plane; a.sT = sT; a.sS = sS;
+  a.partials = (double*)workspace; a.nblk = gx * nz;
+  k1_dispatch(a, dtype, fast, var, skip, fma);
+  if (int rc = hip_status(hipGetLastError(), name)) return rc;
+  hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)(nout * nt)), dim3(kBlock), 0, a.st,
+                     a.partials, a.nblk, out);
+  return hip_status(hipGetLastError(), "k_reduce_rows launch");
+}
+
+// ---- K2 dispatch -------------------------------------------------------------------------
+struct K2Args {
+  dim3 grid;
+  hipStream_t st;
+  const void *T, *S;
+  const double *rho0m, *surf, *dz, *z_i, *deptho, *p;
+  int p_mode, eos, nt, nz;
+  double neg_inv_rhozero;
+  int64_t plane, sT, sS;
+  double *drho, *eta;
+};
+
+template <typename TIn, int VEC, int NTI, int HOLD, int MODE, bool GEN, bool SKIP, bool FMA>
+void k2_go(const K2Args& a) {
+  hipLaunchKernelGGL((k_steric_local<TIn, VEC, NTI, HOLD, MODE, GEN, SKIP, FMA>), a.grid,
+                     dim3(kBlock), 0, a.st, (const TIn*)a.T, (const TIn*)a.S, a.rho0m, a.surf,
+                     a.dz, a.z_i, a.deptho, a.p, a.p_mode, a.eos, a.neg_inv_rhozero, a.nt, a.nz,
+                     a.plane, a.sT, a.sS, a.drho, a.eta);
+}
+
+template <typename TIn, int VEC, int NTI, int HOLD, int MODE, bool GEN>
+void k2_flags(const K2Args& a, bool skip, bool fma) {
+  constexpr int FM = (MODE == kF32Faithful) ? kF32Upcast : MODE;
+  constexpr bool S1 = !GEN;
+  if (fma) {
+    if (skip && S1) k2_go<TIn, VEC, NTI, HOLD, FM, GEN, S1, true>(a);
+    else k2_go<TIn, VEC, NTI, HOLD, FM, GEN, false, true>(a);
+  } else {
+    if (skip && S1) k2_go<TIn, VEC, NTI, HOLD, MODE, GEN, S1, false>(a);
+    else k2_go<TIn, VEC, NTI, HOLD, MODE, GEN, false, false>(a);
+  }
+}
+
+template <typename TIn, int VEC, int NTI, int MODE, bool GEN>
+void k2_hold(const K2Args& a, int hold, bool skip, bool fma) {
+  if constexpr (GEN) {
+    k2_flags<TIn, VEC, NTI, 0, MODE, GEN>(a, skip, fma);
+  } else {
+    if (hold == 0) k2_flags<TIn, VEC, NTI, 0, MODE, GEN>(a, skip, fma);
+    else if (hold == 1) k2_flags<TIn, VEC, NTI, 1, MODE, GEN>(a, skip, fma);
+    else k2_flags<TIn, VEC, NTI, 2, MODE, GEN>(a, skip, fma);
+  }
 }
 
 }  // namespace
@@ -704,55 +977,65 @@ int mlx_last_error(char* buf, size_t n) {
 // ---------------------------------------------------------------------------- K0
 static int eos_map_impl(const void* T, const void* S, int dtype, const double* p, int p_mode,
                         int eos, int func, double aux, int64_t nt, int64_t nz, int64_t plane,
-                        int64_t sT, int64_t sS, double* out, void* stream) {
-  using namespace mlx;
-  if (int rc = check_common(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS, true)) return rc;
+                        int64_t sT, int64_t sS, int flags, double* out, void* stream) {
+  if (flags & ~MLX_FLAG_FMA) return fail(MLX_E_ENUM, "mlx_eos_map takes MLX_FLAG_FMA only");
+  if (int rc = check_common(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS)) return rc;
   if (!out) return fail(MLX_E_NULL, "out must not be NULL");
+  if (!aligned(out, 8)) return fail(MLX_E_ALIGN, "out not 8-byte aligned");
   if (func < MLX_FUNC_DENSITY || func > MLX_FUNC_IBH) return fail(MLX_E_ENUM, "unknown func");
   if (eos == MLX_EOS_LINEAR && func != MLX_FUNC_DENSITY && func != MLX_FUNC_IBH)
     return fail(MLX_E_ENUM, "the linear EOS kernel provides density only");
   if (func == MLX_FUNC_IBH && !p) return fail(MLX_E_NULL, "p must not be NULL");
+  const bool fma = (flags & MLX_FLAG_FMA) != 0;
+  if (fma && func != MLX_FUNC_DENSITY)
+    return fail(MLX_E_ENUM, "MLX_FLAG_FMA applies to the density only");
   hipStream_t st = (hipStream_t)stream;
   const bool f64 = (dtype == MLX_DTYPE_F64);
-  const int vec = f64 ? kVec64 : kVec32;
-  const bool fast = (eos == MLX_EOS_WRIGHT) && (p_mode == MLX_P_ZPROF) && (plane % vec == 0) &&
-                    (sT % vec == 0) && (sS % vec == 0) && aligned(T, 16) && aligned(S, 16) &&
-                    aligned(out, 16) && (f64 || func == MLX_FUNC_DENSITY) &&
-                    func != MLX_FUNC_IBH;
+  const int vec = vec_of(dtype);
+  const bool fast = fast_layout(dtype, p_mode, eos, plane, sT, sS, {T, S, out}) &&
+                    (f64 || func == MLX_FUNC_DENSITY) && func != MLX_FUNC_IBH;
   const double* pp = p ? p : out;  // never dereferenced for the linear EOS
   for (int64_t tb = 0; tb < nt; tb += 32768) {
     const int64_t ntc = (nt - tb < 32768) ? (nt - tb) : 32768;
     if (fast) {
       constexpr int U = 2;
       dim3 grid((unsigned)ceil_div(plane, (int64_t)kBlock * vec * U), (unsigned)nz, (unsigned)ntc);
-#define MLX_LAUNCH_K0(TIN, VEC, MODE, FUNC)                                                     \
-  hipLaunchKernelGGL((k_eos_map<TIN, VEC, U, MODE, FUNC, false>), grid, dim3(kBlock), 0, st,     \
-                     (const TIN*)T, (const TIN*)S, pp, p_mode, eos, func, nz, plane, sT, sS, tb, \
-                     aux, out)
+#define MLX_LAUNCH_K0(TIN, VEC, MODE, FUNC, FMA)                                                 \
+  hipLaunchKernelGGL((k_eos_map<TIN, VEC, U, MODE, FUNC, false, FMA>), grid, dim3(kBlock), 0,    \
+                     st, (const TIN*)T, (const TIN*)S, pp, p_mode, eos, func, nz, plane, sT, sS, \
+                     tb, aux, out)
       if (f64) {
         switch (func) {
-          case MLX_FUNC_DENSITY: MLX_LAUNCH_K0(double, 2, kF64, kDensity); break;
-          case MLX_FUNC_DRHO_DTEMP: MLX_LAUNCH_K0(double, 2, kF64, kDrhoDtemp); break;
-          case MLX_FUNC_DRHO_DSAL: MLX_LAUNCH_K0(double, 2, kF64, kDrhoDsal); break;
-          case MLX_FUNC_ALPHA: MLX_LAUNCH_K0(double, 2, kF64, kAlpha); break;
-          default: MLX_LAUNCH_K0(double, 2, kF64, kBeta); break;
+          case MLX_FUNC_DENSITY:
+            if (fma) MLX_LAUNCH_K0(double, 2, kF64, kDensity, true);
+            else MLX_LAUNCH_K0(double, 2, kF64, kDensity, false);
+            break;
+          case MLX_FUNC_DRHO_DTEMP: MLX_LAUNCH_K0(double, 2, kF64, kDrhoDtemp, false); break;
+          case MLX_FUNC_DRHO_DSAL: MLX_LAUNCH_K0(double, 2, kF64, kDrhoDsal, false); break;
+          case MLX_FUNC_ALPHA: MLX_LAUNCH_K0(double, 2, kF64, kAlpha, false); break;
+          default: MLX_LAUNCH_K0(double, 2, kF64, kBeta, false); break;
         }
+      } else if (fma) {
+        MLX_LAUNCH_K0(float, 4, kF32Upcast, kDensity, true);
       } else if (dtype == MLX_DTYPE_F32) {
-        MLX_LAUNCH_K0(float, 4, kF32Faithful, kDensity);
+        MLX_LAUNCH_K0(float, 4, kF32Faithful, kDensity, false);
       } else {
-        MLX_LAUNCH_K0(float, 4, kF32Upcast, kDensity);
+        MLX_LAUNCH_K0(float, 4, kF32Upcast, kDensity, false);
       }
 #undef MLX_LAUNCH_K0
     } else {
       constexpr int U = 4;
       dim3 grid((unsigned)ceil_div(plane, (int64_t)kBlock * U), (unsigned)nz, (unsigned)ntc);
-#define MLX_LAUNCH_K0G(TIN, MODE)                                                               \
-  hipLaunchKernelGGL((k_eos_map<TIN, 1, U, MODE, 0, true>), grid, dim3(kBlock), 0, st,           \
+#define MLX_LAUNCH_K0G(TIN, MODE, FMA)                                                           \
+  hipLaunchKernelGGL((k_eos_map<TIN, 1, U, MODE, 0, true, FMA>), grid, dim3(kBlock), 0, st,      \
                      (const TIN*)T, (const TIN*)S, pp, p_mode, eos, func, nz, plane, sT, sS, tb, \
                      aux, out)
-      if (f64) MLX_LAUNCH_K0G(double, kF64);
-      else if (dtype == MLX_DTYPE_F32) MLX_LAUNCH_K0G(float, kF32Faithful);
-      else MLX_LAUNCH_K0G(float, kF32Upcast);
+      if (fma) {
+        if (f64) MLX_LAUNCH_K0G(double, kF64, true);
+        else MLX_LAUNCH_K0G(float, kF32Upcast, true);
+      } else if (f64) MLX_LAUNCH_K0G(double, kF64, false);
+      else if (dtype == MLX_DTYPE_F32) MLX_LAUNCH_K0G(float, kF32Faithful, false);
+      else MLX_LAUNCH_K0G(float, kF32Upcast, false);
 #undef MLX_LAUNCH_K0G
     }
   }
@@ -761,79 +1044,50 @@ static int eos_map_impl(const void* T, const void* S, int dtype, const double* p
 
 int mlx_eos_map(const void* T, const void* S, int dtype, const double* p, int p_mode, int eos,
                 int func, int64_t nt, int64_t nz, int64_t plane, int64_t sT, int64_t sS,
-                double* out, void* stream) {
+                int flags, double* out, void* stream) {
   if (func == MLX_FUNC_IBH) return fail(MLX_E_ENUM, "use mlx_inverse_barometer for MLX_FUNC_IBH");
-  return eos_map_impl(T, S, dtype, p, p_mode, eos, func, 0.0, nt, nz, plane, sT, sS, out, stream);
+  return eos_map_impl(T, S, dtype, p, p_mode, eos, func, 0.0, nt, nz, plane, sT, sS, flags, out,
+                      stream);
 }
 
 int mlx_inverse_barometer(const void* T, const void* S, int dtype, const double* p, int p_mode,
                           int eos, double gravity, int64_t nt, int64_t nz, int64_t plane,
                           int64_t sT, int64_t sS, double* out, void* stream) {
   return eos_map_impl(T, S, dtype, p, p_mode, eos, MLX_FUNC_IBH, gravity, nt, nz, plane, sT, sS,
-                      out, stream);
+                      0, out, stream);
 }
 
 // ---------------------------------------------------------------------------- K1
 size_t mlx_steric_global_workspace_bytes(int64_t nt, int64_t nz, int64_t plane) {
   if (nt <= 0 || nz <= 0 || plane <= 0) return 0;
   // the generic path has the smaller tile, hence the larger block count: size for it
-  const int64_t nblk = ceil_div(plane, (int64_t)mlx::kBlock * kUGen) * nz;
+  const int64_t nblk = ceil_div(plane, (int64_t)kBlock * kUGen) * nz;
   return (size_t)(nt * nblk) * sizeof(double);
+}
+
+size_t mlx_steric_global_decomp_workspace_bytes(int64_t nt, int64_t nz, int64_t plane) {
+  return 4 * mlx_steric_global_workspace_bytes(nt, nz, plane);
 }
 
 int mlx_steric_global(const void* T, const void* S, int dtype, const double* vol0, const double* p,
                       int p_mode, int eos, int64_t nt, int64_t nz, int64_t plane, int64_t sT,
                       int64_t sS, int flags, double* masso_out, void* workspace,
                       size_t workspace_bytes, void* stream) {
-  using namespace mlx;
-  if (flags & ~MLX_FLAG_SKIP_DRY) return fail(MLX_E_ENUM, "unknown flag bits");
-  const bool skip_dry = (flags & MLX_FLAG_SKIP_DRY) != 0;
-  if (int rc = check_common(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS, false)) return rc;
-  if (!vol0 || !masso_out) return fail(MLX_E_NULL, "vol0 and masso_out must not be NULL");
-  if (!workspace) return fail(MLX_E_NULL, "workspace must not be NULL");
-  if (!aligned(workspace, 8) || workspace_bytes < mlx_steric_global_workspace_bytes(nt, nz, plane))
-    return fail(MLX_E_WORKSPACE, "workspace smaller than mlx_steric_global_workspace_bytes()");
-  hipStream_t st = (hipStream_t)stream;
-  const GlobalPlan pl = plan_global(T, S, vol0, dtype, p_mode, eos, nz, plane, sT, sS);
-  double* partials = (double*)workspace;
-  if (ceil_div(nt, kTChunk) > 65535) return fail(MLX_E_SHAPE, "nt too large for one call: chunk it");
-  dim3 grid((unsigned)pl.grid_x, (unsigned)nz, (unsigned)ceil_div(nt, kTChunk));
-  const double* pp = p ? p : vol0;
-  const int hold = (sT == 0) ? 1 : ((sS == 0) ? 2 : 0);
-#define MLX_LAUNCH_K1S(TIN, VEC, U, HOLD, MODE, GEN, SKIP)                                        \
-  hipLaunchKernelGGL((k_steric_global<TIN, VEC, U, HOLD, MODE, GEN, SKIP>), grid, dim3(kBlock), 0, \
-                     st, (const TIN*)T, (const TIN*)S, vol0, pp, p_mode, eos, (int)nt, kTChunk,    \
-                     plane, sT, sS, partials, pl.nblk_total)
-#define MLX_LAUNCH_K1(TIN, VEC, U, HOLD, MODE, GEN)                 \
-  do {                                                              \
-    if (!GEN && skip_dry) MLX_LAUNCH_K1S(TIN, VEC, U, HOLD, MODE, GEN, (!GEN)); \
-    else MLX_LAUNCH_K1S(TIN, VEC, U, HOLD, MODE, GEN, false);       \
-  } while (0)
-  if (pl.fast) {
-    if (dtype == MLX_DTYPE_F64) {
-      if (hold == 0) MLX_LAUNCH_K1(double, kVec64, kU64, 0, kF64, false);
-      else if (hold == 1) MLX_LAUNCH_K1(double, kVec64, kU64, 1, kF64, false);
-      else MLX_LAUNCH_K1(double, kVec64, kU64, 2, kF64, false);
-    } else if (dtype == MLX_DTYPE_F32) {
-      if (hold == 0) MLX_LAUNCH_K1(float, kVec32, kU32, 0, kF32Faithful, false);
-      else if (hold == 1) MLX_LAUNCH_K1(float, kVec32, kU32, 1, kF32Faithful, false);
-      else MLX_LAUNCH_K1(float, kVec32, kU32, 2, kF32Faithful, false);
-    } else {
-      if (hold == 0) MLX_LAUNCH_K1(float, kVec32, kU32, 0, kF32Upcast, false);
-      else if (hold == 1) MLX_LAUNCH_K1(float, kVec32, kU32, 1, kF32Upcast, false);
-      else MLX_LAUNCH_K1(float, kVec32, kU32, 2, kF32Upcast, false);
-    }
-  } else {
-    if (dtype == MLX_DTYPE_F64) MLX_LAUNCH_K1(double, 1, kUGen, 0, kF64, true);
-    else if (dtype == MLX_DTYPE_F32) MLX_LAUNCH_K1(float, 1, kUGen, 0, kF32Faithful, true);
-    else MLX_LAUNCH_K1(float, 1, kUGen, 0, kF32Upcast, true);
-  }
-#undef MLX_LAUNCH_K1
-#undef MLX_LAUNCH_K1S
-  if (int rc = hip_status(hipGetLastError(), "k_steric_global launch")) return rc;
-  hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)nt), dim3(kBlock), 0, st, partials,
-                     pl.nblk_total, masso_out);
-  return hip_status(hipGetLastError(), "k_reduce_rows launch");
+  return steric_global_impl(T, S, nullptr, nullptr, kVarSteric, dtype, vol0, p, p_mode, eos, nt,
+                            nz, plane, sT, sS, flags, masso_out, workspace, workspace_bytes,
+                            stream, "k_steric_global launch");
+}
+
+int mlx_steric_global_decomp(const void* T, const void* S, const void* T0, const void* S0,
+                             int dtype, const double* vol0, const double* p, int p_mode, int eos,
+                             int64_t nt, int64_t nz, int64_t plane, int64_t sT, int64_t sS,
+                             int flags, double* out, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  if (sT == 0 || sS == 0)
+    return fail(MLX_E_SHAPE, "mlx_steric_global_decomp streams both fields: time strides must be > 0");
+  return steric_global_impl(T, S, T0, S0, kVarAll, dtype, vol0, p, p_mode, eos, nt, nz, plane, sT,
+                            sS, flags, out, workspace, workspace_bytes, stream,
+                            "k_steric_global (decomposition) launch");
 }
 
 // ---------------------------------------------------------------------------- K2
@@ -841,9 +1095,11 @@ int mlx_fold_mask(const double* rho0, const double* vol0, int64_t n, double* rho
                   void* stream) {
   if (!rho0 || !vol0 || !rho0m_out) return fail(MLX_E_NULL, "rho0, vol0, rho0m_out must not be NULL");
   if (n <= 0) return fail(MLX_E_SHAPE, "n must be > 0");
-  const int64_t blocks = ceil_div(n, mlx::kBlock);
-  hipLaunchKernelGGL(mlx::k_fold_mask, dim3((unsigned)(blocks < 8192 ? blocks : 8192)),
-                     dim3(mlx::kBlock), 0, (hipStream_t)stream, rho0, vol0, n, rho0m_out);
+  if (!aligned(rho0, 8) || !aligned(vol0, 8) || !aligned(rho0m_out, 8))
+    return fail(MLX_E_ALIGN, "operands not 8-byte aligned");
+  const int64_t blocks = ceil_div(n, kBlock);
+  hipLaunchKernelGGL(k_fold_mask, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(kBlock), 0,
+                     (hipStream_t)stream, rho0, vol0, n, rho0m_out);
   return hip_status(hipGetLastError(), "k_fold_mask launch");
 }
 
@@ -852,66 +1108,50 @@ int mlx_steric_local(const void* T, const void* S, int dtype, const double* rho0
                      const double* deptho, const double* p, int p_mode, int eos,
                      double neg_inv_rhozero, int64_t nt, int64_t nz, int64_t plane, int64_t sT,
                      int64_t sS, int flags, double* delta_rho_out, double* eta_out, void* stream) {
-  using namespace mlx;
-  if (flags & ~MLX_FLAG_SKIP_DRY) return fail(MLX_E_ENUM, "unknown flag bits");
-  const bool skip_dry = (flags & MLX_FLAG_SKIP_DRY) != 0;
-  if (int rc = check_common(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS, false)) return rc;
+  if (flags & ~(MLX_FLAG_SKIP_DRY | MLX_FLAG_FMA)) return fail(MLX_E_ENUM, "unknown flag bits");
+  const bool skip = (flags & MLX_FLAG_SKIP_DRY) != 0, fma = (flags & MLX_FLAG_FMA) != 0;
+  if (int rc = check_common(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS)) return rc;
   if (!rho0m || !vol0_surface || !eta_out)
     return fail(MLX_E_NULL, "rho0m, vol0_surface and eta_out must not be NULL");
   if (!dz && (!z_i || !deptho))
     return fail(MLX_E_NULL, "either dz or both z_i and deptho must be given");
+  for (const void* q : {(const void*)rho0m, (const void*)vol0_surface, (const void*)dz,
+                        (const void*)z_i, (const void*)deptho, (const void*)delta_rho_out,
+                        (const void*)eta_out})
+    if (q && !aligned(q, 8)) return fail(MLX_E_ALIGN, "operands not 8-byte aligned");
   if (ceil_div(nt, kNTIGen) > 65535) return fail(MLX_E_SHAPE, "nt too large for one call: chunk it");
-  hipStream_t st = (hipStream_t)stream;
   const bool f64 = (dtype == MLX_DTYPE_F64);
-  const int vec = f64 ? kVec64 : kVec32;
-  const bool fast = (eos == MLX_EOS_WRIGHT) && (p_mode == MLX_P_ZPROF) && (plane % vec == 0) &&
-                    (sT % vec == 0) && (sS % vec == 0) && !(sT == 0 && sS == 0) &&
-                    aligned(T, 16) && aligned(S, 16) && aligned(rho0m, 16) &&
-                    aligned(vol0_surface, 16) && aligned(eta_out, 16) &&
-                    (!dz || aligned(dz, 16)) && (dz || aligned(deptho, 16)) &&
-                    (!delta_rho_out || aligned(delta_rho_out, 16));
-  const double* pp = p ? p : rho0m;
+  const bool fast = fast_layout(dtype, p_mode, eos, plane, sT, sS,
+                                {T, S, rho0m, vol0_surface, eta_out, dz, dz ? nullptr : deptho,
+                                 delta_rho_out}) &&
+                    !(sT == 0 && sS == 0);
   const int hold = (sT == 0) ? 1 : ((sS == 0) ? 2 : 0);
-  const int v = fast ? vec : 1;
+  const int v = fast ? vec_of(dtype) : 1;
   const int nti = fast ? (f64 ? kNTI64 : kNTI32) : kNTIGen;
-  dim3 grid((unsigned)ceil_div(plane, (int64_t)kBlock * v), (unsigned)ceil_div(nt, nti));
-#define MLX_LAUNCH_K2S(TIN, VEC, NTI, HOLD, MODE, GEN, SKIP)                                      \
-  hipLaunchKernelGGL((k_steric_local<TIN, VEC, NTI, HOLD, MODE, GEN, SKIP>), grid, dim3(kBlock),  \
-                     0, st, (const TIN*)T, (const TIN*)S, rho0m, vol0_surface, dz, z_i, deptho,  \
-                     pp, p_mode, eos, neg_inv_rhozero, (int)nt, (int)nz, plane, sT, sS,          \
-                     delta_rho_out, eta_out)
-#define MLX_LAUNCH_K2(TIN, VEC, NTI, HOLD, MODE, GEN)                               \
-  do {                                                                              \
-    if (!GEN && skip_dry) MLX_LAUNCH_K2S(TIN, VEC, NTI, HOLD, MODE, GEN, (!GEN));   \
-    else MLX_LAUNCH_K2S(TIN, VEC, NTI, HOLD, MODE, GEN, false);                     \
-  } while (0)
+  const int64_t gx = ceil_div(plane, (int64_t)kBlock * v);
+  if (gx > 2147483647LL) return fail(MLX_E_SHAPE, "plane too large");
+  K2Args a;
+  a.grid = dim3((unsigned)gx, (unsigned)ceil_div(nt, nti));
+  a.st = (hipStream_t)stream;
+  a.T = T; a.S = S; a.rho0m = rho0m; a.surf = vol0_surface; a.dz = dz; a.z_i = z_i;
+  a.deptho = deptho; a.p = p ? p : rho0m; a.p_mode = p_mode; a.eos = eos; a.nt = (int)nt;
+  a.nz = (int)nz; a.neg_inv_rhozero = neg_inv_rhozero; a.plane = plane; a.sT = sT; a.sS = sS;
+  a.drho = delta_rho_out; a.eta = eta_out;
   if (fast) {
-    if (f64) {
-      if (hold == 0) MLX_LAUNCH_K2(double, kVec64, kNTI64, 0, kF64, false);
-      else if (hold == 1) MLX_LAUNCH_K2(double, kVec64, kNTI64, 1, kF64, false);
-      else MLX_LAUNCH_K2(double, kVec64, kNTI64, 2, kF64, false);
-    } else if (dtype == MLX_DTYPE_F32) {
-      if (hold == 0) MLX_LAUNCH_K2(float, kVec32, kNTI32, 0, kF32Faithful, false);
-      else if (hold == 1) MLX_LAUNCH_K2(float, kVec32, kNTI32, 1, kF32Faithful, false);
-      else MLX_LAUNCH_K2(float, kVec32, kNTI32, 2, kF32Faithful, false);
-    } else {
-      if (hold == 0) MLX_LAUNCH_K2(float, kVec32, kNTI32, 0, kF32Upcast, false);
-      else if (hold == 1) MLX_LAUNCH_K2(float, kVec32, kNTI32, 1, kF32Upcast, false);
-      else MLX_LAUNCH_K2(float, kVec32, kNTI32, 2, kF32Upcast, false);
-    }
+    if (f64) k2_hold<double, kVec64, kNTI64, kF64, false>(a, hold, skip, fma);
+    else if (dtype == MLX_DTYPE_F32) k2_hold<float, kVec32, kNTI32, kF32Faithful, false>(a, hold, skip, fma);
+    else k2_hold<float, kVec32, kNTI32, kF32Upcast, false>(a, hold, skip, fma);
   } else {
-    if (f64) MLX_LAUNCH_K2(double, 1, kNTIGen, 0, kF64, true);
-    else if (dtype == MLX_DTYPE_F32) MLX_LAUNCH_K2(float, 1, kNTIGen, 0, kF32Faithful, true);
-    else MLX_LAUNCH_K2(float, 1, kNTIGen, 0, kF32Upcast, true);
+    if (f64) k2_hold<double, 1, kNTIGen, kF64, true>(a, hold, skip, fma);
+    else if (dtype == MLX_DTYPE_F32) k2_hold<float, 1, kNTIGen, kF32Faithful, true>(a, hold, skip, fma);
+    else k2_hold<float, 1, kNTIGen, kF32Upcast, true>(a, hold, skip, fma);
   }
-#undef MLX_LAUNCH_K2
-#undef MLX_LAUNCH_K2S
   return hip_status(hipGetLastError(), "k_steric_local launch");
 }
 
 // ---------------------------------------------------------------------------- sums
 static int64_t nansum_blocks(int64_t n) {
-  const int64_t b = ceil_div(n, (int64_t)mlx::kBlock * 8);
+  const int64_t b = ceil_div(n, (int64_t)kBlock * 8);
   return b < 1 ? 1 : (b > 8192 ? 8192 : b);
 }
 
@@ -924,18 +1164,18 @@ int mlx_nansum(const double* x, int64_t n, double* out, void* workspace, size_t 
                void* stream) {
   if (!x || !out || !workspace) return fail(MLX_E_NULL, "x, out, workspace must not be NULL");
   if (n <= 0) return fail(MLX_E_SHAPE, "n must be > 0");
-  if (workspace_bytes < mlx_nansum_workspace_bytes(n))
+  if (!aligned(x, 8) || !aligned(out, 8)) return fail(MLX_E_ALIGN, "x/out not 8-byte aligned");
+  if (!aligned(workspace, 8) || workspace_bytes < mlx_nansum_workspace_bytes(n))
     return fail(MLX_E_WORKSPACE, "workspace smaller than mlx_nansum_workspace_bytes()");
   const int64_t nb = nansum_blocks(n);
   hipStream_t st = (hipStream_t)stream;
   if (n % 2 == 0 && aligned(x, 16))
-    hipLaunchKernelGGL(mlx::k_nansum_partial<true>, dim3((unsigned)nb), dim3(mlx::kBlock), 0, st, x,
-                       n, (double*)workspace);
+    hipLaunchKernelGGL(k_nansum_partial<true>, dim3((unsigned)nb), dim3(kBlock), 0, st, x, n,
+                       (double*)workspace);
   else
-    hipLaunchKernelGGL(mlx::k_nansum_partial<false>, dim3((unsigned)nb), dim3(mlx::kBlock), 0, st, x,
-                       n, (double*)workspace);
-  hipLaunchKernelGGL(mlx::k_reduce_rows, dim3(1), dim3(mlx::kBlock), 0, st,
-                     (const double*)workspace, nb, out);
+    hipLaunchKernelGGL(k_nansum_partial<false>, dim3((unsigned)nb), dim3(kBlock), 0, st, x, n,
+                       (double*)workspace);
+  hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(kBlock), 0, st, (const double*)workspace, nb, out);
   return hip_status(hipGetLastError(), "mlx_nansum launch");
 }
 
@@ -946,14 +1186,16 @@ int mlx_masso(const double* rho, const double* vol, int64_t nt, int64_t n3, int6
   if (nt <= 0 || n3 <= 0 || nt > 65535) return fail(MLX_E_SHAPE, "need 0 < nt <= 65535, n3 > 0");
   if (vol_t_stride != 0 && vol_t_stride != n3)
     return fail(MLX_E_SHAPE, "vol_t_stride must be 0 or n3");
+  if (!aligned(rho, 8) || !aligned(vol, 8) || !aligned(masso_out, 8))
+    return fail(MLX_E_ALIGN, "operands not 8-byte aligned");
   const int64_t nb = nansum_blocks(n3);
-  if (workspace_bytes < (size_t)(nt * nb) * sizeof(double) ||
+  if (!aligned(workspace, 8) || workspace_bytes < (size_t)(nt * nb) * sizeof(double) ||
       workspace_bytes < mlx_steric_global_workspace_bytes(nt, 1, n3))
     return fail(MLX_E_WORKSPACE, "workspace smaller than mlx_steric_global_workspace_bytes(nt,1,n3)");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(mlx::k_masso_partial, dim3((unsigned)nb, (unsigned)nt), dim3(mlx::kBlock), 0,
-                     st, rho, vol, n3, vol_t_stride, (double*)workspace);
-  hipLaunchKernelGGL(mlx::k_reduce_rows, dim3((unsigned)nt), dim3(mlx::kBlock), 0, st,
+  hipLaunchKernelGGL(k_masso_partial, dim3((unsigned)nb, (unsigned)nt), dim3(kBlock), 0, st, rho,
+                     vol, n3, vol_t_stride, (double*)workspace);
+  hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)nt), dim3(kBlock), 0, st,
                      (const double*)workspace, nb, masso_out);
   return hip_status(hipGetLastError(), "mlx_masso launch");
 }
@@ -963,15 +1205,15 @@ int mlx_group_weighted_mean(const double* x, const double* w, int64_t ngroups, i
   if (!x || !w || !out) return fail(MLX_E_NULL, "x, w, out must not be NULL");
   if (ngroups <= 0 || group_len <= 0 || n <= 0 || ngroups > 65535)
     return fail(MLX_E_SHAPE, "need 0 < ngroups <= 65535, group_len > 0, n > 0");
+  if (!aligned(x, 8) || !aligned(w, 8) || !aligned(out, 8))
+    return fail(MLX_E_ALIGN, "operands not 8-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   if (n % 2 == 0 && aligned(x, 16) && aligned(out, 16)) {
-    dim3 grid((unsigned)ceil_div(n, (int64_t)mlx::kBlock * 2), (unsigned)ngroups);
-    hipLaunchKernelGGL(mlx::k_group_weighted_mean<2>, grid, dim3(mlx::kBlock), 0, st, x, w,
-                       group_len, n, out);
+    dim3 grid((unsigned)ceil_div(n, (int64_t)kBlock * 2), (unsigned)ngroups);
+    hipLaunchKernelGGL(k_group_weighted_mean<2>, grid, dim3(kBlock), 0, st, x, w, group_len, n, out);
   } else {
-    dim3 grid((unsigned)ceil_div(n, (int64_t)mlx::kBlock), (unsigned)ngroups);
-    hipLaunchKernelGGL(mlx::k_group_weighted_mean<1>, grid, dim3(mlx::kBlock), 0, st, x, w,
-                       group_len, n, out);
+    dim3 grid((unsigned)ceil_div(n, (int64_t)kBlock), (unsigned)ngroups);
+    hipLaunchKernelGGL(k_group_weighted_mean<1>, grid, dim3(kBlock), 0, st, x, w, group_len, n, out);
   }
   return hip_status(hipGetLastError(), "k_group_weighted_mean launch");
 }
@@ -980,10 +1222,24 @@ int mlx_calc_dz(const double* z_i, const double* depth, int64_t nz, int64_t plan
                 double bottom, int has_bottom, int fraction, double* dz_out, void* stream) {
   if (!z_i || !depth || !dz_out) return fail(MLX_E_NULL, "z_i, depth, dz_out must not be NULL");
   if (nz <= 0 || plane <= 0) return fail(MLX_E_SHAPE, "nz and plane must be > 0");
-  hipLaunchKernelGGL(mlx::k_calc_dz, dim3((unsigned)ceil_div(plane, mlx::kBlock)),
-                     dim3(mlx::kBlock), 0, (hipStream_t)stream, z_i, depth, nz, plane, top, bottom,
-                     has_bottom, fraction, dz_out);
+  if (!aligned(z_i, 8) || !aligned(depth, 8) || !aligned(dz_out, 8))
+    return fail(MLX_E_ALIGN, "operands not 8-byte aligned");
+  const int64_t gx = ceil_div(plane, kBlock);
+  if (gx > 2147483647LL) return fail(MLX_E_SHAPE, "plane too large");
+  hipLaunchKernelGGL(k_calc_dz, dim3((unsigned)gx), dim3(kBlock), 0, (hipStream_t)stream, z_i,
+                     depth, nz, plane, top, bottom, has_bottom, fraction, dz_out);
   return hip_status(hipGetLastError(), "k_calc_dz launch");
+}
+
+int mlx_stream_probe(const double* a, const double* b, int64_t n, double* out, void* stream) {
+  if (!a || !b || !out) return fail(MLX_E_NULL, "a, b, out must not be NULL");
+  if (n <= 0 || n % 2) return fail(MLX_E_SHAPE, "n must be > 0 and even");
+  if (!aligned(a, 16) || !aligned(b, 16) || !aligned(out, 16))
+    return fail(MLX_E_ALIGN, "operands must be 16-byte aligned");
+  const int64_t want = ceil_div(n / 2, kBlock);
+  hipLaunchKernelGGL(k_stream_probe, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(kBlock), 0,
+                     (hipStream_t)stream, a, b, n / 2, out);
+  return hip_status(hipGetLastError(), "k_stream_probe launch");
 }
 
 int mlx_synth_field(void* out, int dtype, int64_t nt, int64_t nz, int64_t ny, int64_t nx,
@@ -991,23 +1247,22 @@ int mlx_synth_field(void* out, int dtype, int64_t nt, int64_t nz, int64_t ny, in
                     int field_id, double lo, double scale, const double* mask3d, void* stream) {
   if (!out) return fail(MLX_E_NULL, "out must not be NULL");
   if (nt <= 0 || nz <= 0 || ny <= 0 || nx <= 0) return fail(MLX_E_SHAPE, "dims must be > 0");
-  if (y0 < 0 || x0 < 0 || y0 + ny > NY || x0 + nx > NX)
+  if (y0 < 0 || x0 < 0 || t0 < 0 || y0 + ny > NY || x0 + nx > NX)
     return fail(MLX_E_SHAPE, "tile does not fit the global grid");
   if (field_id < 0 || field_id > 15) return fail(MLX_E_ENUM, "field_id must be 0..15");
+  if (int rc = check_dtype(dtype)) return rc;
+  if (!aligned(out, dtype == MLX_DTYPE_F64 ? 8 : 4) || (mask3d && !aligned(mask3d, 8)))
+    return fail(MLX_E_ALIGN, "out/mask3d not element-aligned");
   const int64_t n = nt * nz * ny * nx;
-  const int64_t want = ceil_div(n, mlx::kBlock);
+  const int64_t want = ceil_div(n, kBlock);
   dim3 grid((unsigned)(want < 16384 ? want : 16384));
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MLX_DTYPE_F64)
-    hipLaunchKernelGGL(mlx::k_synth<double>, grid, dim3(mlx::kBlock), 0, st, (double*)out, nt, nz,
-                       ny, nx, t0, NY, NX, y0, x0, (unsigned long long)seed, field_id, lo, scale,
-                       mask3d);
-  else if (dtype == MLX_DTYPE_F32 || dtype == MLX_DTYPE_F32_UPCAST)
-    hipLaunchKernelGGL(mlx::k_synth<float>, grid, dim3(mlx::kBlock), 0, st, (float*)out, nt, nz,
-                       ny, nx, t0, NY, NX, y0, x0, (unsigned long long)seed, field_id, lo, scale,
-                       mask3d);
+    hipLaunchKernelGGL(k_synth<double>, grid, dim3(kBlock), 0, st, (double*)out, nt, nz, ny, nx,
+                       t0, NY, NX, y0, x0, (unsigned long long)seed, field_id, lo, scale, mask3d);
   else
-    return fail(MLX_E_ENUM, "dtype must be MLX_DTYPE_F64 or MLX_DTYPE_F32");
+    hipLaunchKernelGGL(k_synth<float>, grid, dim3(kBlock), 0, st, (float*)out, nt, nz, ny, nx, t0,
+                       NY, NX, y0, x0, (unsigned long long)seed, field_id, lo, scale, mask3d);
   return hip_status(hipGetLastError(), "k_synth launch");
 }
 

@@ -173,6 +173,26 @@ class TimeChunks:
             self._release(wait=True)
 
 
+def time_dependent(pres):
+    """True for a pressure that carries the time axis: (nt, nz|1, ny|1, nx|1) -- ``patm`` given as
+    a DataArray with a time dimension (steric.py:58-60,96)."""
+    return getattr(pres, "ndim", 0) == 4
+
+
+def pressure_chunk(pres, t0, t1, device):
+    """The pressure operand of time steps [t0, t1): a time-dependent pressure is cut (and moved)
+    chunk by chunk like theta/S, anything else is passed through."""
+    if time_dependent(pres):
+        return to_device(pres[t0:t1], device, torch.float64)
+    return pres
+
+
+def _pressure_bytes_per_step(pres):
+    if time_dependent(pres) and not _is_device(pres):
+        return int(np.prod(pres.shape[1:])) * 8
+    return 0
+
+
 # ---------------------------------------------------------------------------------------
 # reference state (src/momlevel/reference.py:48-85)
 # ---------------------------------------------------------------------------------------
@@ -202,6 +222,24 @@ def reference_state(T0, S0, vol0, pres, eos="wright", f32_mode="faithful", with_
     return rho0, volo, masso0
 
 
+def reference_state_time_dependent(T0, S0, vol0, pres4, eos="wright", f32_mode="faithful"):
+    """The reference state momlevel builds when ``patm`` carries the time dimension
+    (reference.py:54,71-77 broadcast by name): rho0 (nt,nz,ny,nx) = rho(theta0, S0, pres(t)),
+    volo, masso (nt,).  theta0/S0 are broadcast over time by stride 0 -- never copied."""
+    dev = device_of(T0, S0, vol0)
+    T0 = to_device(T0, dev, _stream_dtype(T0))
+    S0 = to_device(S0, dev, _stream_dtype(S0))
+    vol0 = to_device(vol0, dev, torch.float64)
+    pres4 = to_device(pres4, dev, torch.float64)
+    nt = pres4.shape[0]
+    shape = (nt,) + tuple(T0.shape)
+    rho0 = core.eos_map(T0.unsqueeze(0).expand(shape), S0.unsqueeze(0).expand(shape), pres4,
+                        eos=eos, f32_mode=f32_mode)
+    volo = core.nansum(vol0)
+    masso = core.masso(rho0.reshape(nt, -1), vol0.reshape(-1))
+    return rho0, volo, masso
+
+
 # ---------------------------------------------------------------------------------------
 # global variant (src/momlevel/steric.py:134-147)
 # ---------------------------------------------------------------------------------------
@@ -214,16 +252,19 @@ def global_masso(T, S, vol0, pres, eos="wright", f32_mode="faithful", steps=None
     """
     dev = device_of(T, S, vol0)
     vol0 = to_device(vol0, dev, torch.float64)
-    pres = to_device(pres, dev, torch.float64)
-    chunks = TimeChunks(T, S, dev, steps=steps)
+    if not time_dependent(pres):
+        pres = to_device(pres, dev, torch.float64)
+    chunks = TimeChunks(T, S, dev, steps=steps,
+                        extra_bytes_per_step=_pressure_bytes_per_step(pres))
     if chunks.steps >= chunks.nt:
-        for _t0, _t1, Tc, Sc in chunks:
-            return core.steric_global_masso(Tc, Sc, vol0, pres, eos=eos, f32_mode=f32_mode,
-                                            events=events, skip_dry=skip_dry)
+        for t0, t1, Tc, Sc in chunks:
+            return core.steric_global_masso(Tc, Sc, vol0, pressure_chunk(pres, t0, t1, dev),
+                                            eos=eos, f32_mode=f32_mode, events=events,
+                                            skip_dry=skip_dry)
     out = torch.empty(chunks.nt, dtype=torch.float64, device=dev)
     for t0, t1, Tc, Sc in chunks:
-        out[t0:t1] = core.steric_global_masso(Tc, Sc, vol0, pres, eos=eos, f32_mode=f32_mode,
-                                              skip_dry=skip_dry)
+        out[t0:t1] = core.steric_global_masso(Tc, Sc, vol0, pressure_chunk(pres, t0, t1, dev),
+                                              eos=eos, f32_mode=f32_mode, skip_dry=skip_dry)
     return out
 
 
@@ -265,7 +306,8 @@ def local_steric(T, S, rho0, vol0, pres, rhozero, z_i=None, deptho=None, dz=None
     dev = device_of(T, S, rho0, vol0)
     vol0 = to_device(vol0, dev, torch.float64)
     rho0 = to_device(rho0, dev, torch.float64)
-    pres = to_device(pres, dev, torch.float64)
+    if not time_dependent(pres):
+        pres = to_device(pres, dev, torch.float64)
     rho0m = core.fold_mask(rho0, vol0)
     surface = vol0[0].contiguous()
     if dz is not None:
@@ -278,7 +320,7 @@ def local_steric(T, S, rho0, vol0, pres, rhozero, z_i=None, deptho=None, dz=None
     n3 = nz * ny * nx
     if out_host is None:
         out_host = not (_is_device(T) or _is_device(S))
-    extra = n3 * 8 if (want_delta_rho and out_host) else 0
+    extra = (n3 * 8 if (want_delta_rho and out_host) else 0) + _pressure_bytes_per_step(pres)
     chunks = TimeChunks(T, S, dev, steps=steps, extra_bytes_per_step=extra)
     nt = chunks.nt
     if out_host:
@@ -295,8 +337,9 @@ def local_steric(T, S, rho0, vol0, pres, rhozero, z_i=None, deptho=None, dz=None
     d2h = torch.cuda.Stream(device=dev) if out_host else None
     main = torch.cuda.current_stream(dev)
     for t0, t1, Tc, Sc in chunks:
+        pc = pressure_chunk(pres, t0, t1, dev)
         if out_host:
-            d, e = core.steric_local(Tc, Sc, rho0m, surface, pres, neg_inv, dz=dz, z_i=z_i,
+            d, e = core.steric_local(Tc, Sc, rho0m, surface, pc, neg_inv, dz=dz, z_i=z_i,
                                      deptho=deptho, eos=eos, f32_mode=f32_mode,
                                      want_delta_rho=want_delta_rho)
             d2h.wait_stream(main)
@@ -308,7 +351,7 @@ def local_steric(T, S, rho0, vol0, pres, rhozero, z_i=None, deptho=None, dz=None
                     torch.from_numpy(drho[t0:t1]).copy_(d, non_blocking=True)
                     d.record_stream(d2h)
         else:
-            core.steric_local(Tc, Sc, rho0m, surface, pres, neg_inv, dz=dz, z_i=z_i,
+            core.steric_local(Tc, Sc, rho0m, surface, pc, neg_inv, dz=dz, z_i=z_i,
                               deptho=deptho, eos=eos, f32_mode=f32_mode,
                               want_delta_rho=want_delta_rho,
                               delta_rho_out=drho[t0:t1] if want_delta_rho else None,
@@ -337,21 +380,38 @@ def _variant_operands(variant, Tc, Sc, T0, S0):
 
 
 def global_masso_variants(T, S, T0, S0, vol0, pres, variants, eos="wright", f32_mode="faithful",
-                          steps=None, skip_dry=None):
-    """masso(t) of every requested variant; theta/S chunks are uploaded once and reused."""
+                          steps=None, skip_dry=None, with_heat=False):
+    """masso(t) of every requested variant -> {variant: (nt,) device tensor}; with ``with_heat``
+    also ``"heat"``: sum(theta*vol0) per step (the heat-content integrand, an extension).
+
+    Two or more variants (or the heat row) are computed by ONE pass of the all-variants kernel
+    (core.steric_global_decomp: theta/S read once, 16 B/cell instead of 16+8+8); a single variant
+    by its own launch.  Either way every row is bit-identical to the single-variant call, and
+    theta/S chunks of host inputs are uploaded once."""
     dev = device_of(T, S, vol0)
     vol0 = to_device(vol0, dev, torch.float64)
-    pres = to_device(pres, dev, torch.float64)
+    if not time_dependent(pres):
+        pres = to_device(pres, dev, torch.float64)
     T0 = to_device(T0, dev, _stream_dtype(T0))
     S0 = to_device(S0, dev, _stream_dtype(S0))
-    Ts, Ss = _streamed_pair(variants, T, S, T0, S0)
-    chunks = TimeChunks(Ts, Ss, dev, steps=steps)
+    one_pass = len(variants) >= 2 or with_heat
+    Ts, Ss = (T, S) if one_pass else _streamed_pair(variants, T, S, T0, S0)
+    chunks = TimeChunks(Ts, Ss, dev, steps=steps,
+                        extra_bytes_per_step=_pressure_bytes_per_step(pres))
     nt = T.shape[0]
-    out = {v: torch.empty(nt, dtype=torch.float64, device=dev) for v in variants}
+    names = list(variants) + (["heat"] if with_heat else [])
+    out = {v: torch.empty(nt, dtype=torch.float64, device=dev) for v in names}
     for t0, t1, Tc, Sc in chunks:
+        pc = pressure_chunk(pres, t0, t1, dev)
+        if one_pass:
+            rows = core.steric_global_decomp(Tc, Sc, T0.to(Tc.dtype), S0.to(Sc.dtype), vol0, pc,
+                                             eos=eos, f32_mode=f32_mode, skip_dry=skip_dry)
+            for v in names:
+                out[v][t0:t1] = rows[core.DECOMP_ROWS.index(v)]
+            continue
         for v in variants:
             Tv, Sv = _variant_operands(v, Tc, Sc, T0, S0)
-            out[v][t0:t1] = core.steric_global_masso(Tv, Sv, vol0, pres, eos=eos,
+            out[v][t0:t1] = core.steric_global_masso(Tv, Sv, vol0, pc, eos=eos,
                                                      f32_mode=f32_mode, skip_dry=skip_dry)
     return out
 
@@ -368,7 +428,8 @@ def local_steric_variants(T, S, T0, S0, rho0, vol0, pres, rhozero, variants, z_i
     dev = device_of(T, S, rho0, vol0)
     vol0 = to_device(vol0, dev, torch.float64)
     rho0 = to_device(rho0, dev, torch.float64)
-    pres = to_device(pres, dev, torch.float64)
+    if not time_dependent(pres):
+        pres = to_device(pres, dev, torch.float64)
     T0 = to_device(T0, dev, _stream_dtype(T0))
     S0 = to_device(S0, dev, _stream_dtype(S0))
     rho0m = core.fold_mask(rho0, vol0)
@@ -386,6 +447,7 @@ def local_steric_variants(T, S, T0, S0, rho0, vol0, pres, rhozero, variants, z_i
     n_out = len(variants)
     annual = annual_weights is not None
     extra = n_out * nz * ny * nx * 8 if (want_delta_rho and (out_host or annual)) else 0
+    extra += _pressure_bytes_per_step(pres)
     Ts, Ss = _streamed_pair(variants, T, S, T0, S0)
     if annual:
         if nt % 12:
@@ -410,12 +472,13 @@ def local_steric_variants(T, S, T0, S0, rho0, vol0, pres, rhozero, variants, z_i
     main = torch.cuda.current_stream(dev)
     for t0, t1, Tc, Sc in chunks:
         o0, o1 = (t0 // 12, t1 // 12) if annual else (t0, t1)
+        pc = pressure_chunk(pres, t0, t1, dev)
         for v in variants:
             Tv, Sv = _variant_operands(v, Tc, Sc, T0, S0)
             kw = dict(dz=dz, z_i=z_i, deptho=deptho, eos=eos, f32_mode=f32_mode,
                       want_delta_rho=want_delta_rho)
             if annual:  # K2 on the chunk, then the fused annual-mean epilogue on the device
-                d, e = core.steric_local(Tv, Sv, rho0m, surface, pres, neg_inv, **kw)
+                d, e = core.steric_local(Tv, Sv, rho0m, surface, pc, neg_inv, **kw)
                 e = core.group_weighted_mean(e, w_dev[t0:t1], 12,
                                              out=None if out_host else eta[v][o0:o1])
                 if want_delta_rho:
@@ -425,7 +488,7 @@ def local_steric_variants(T, S, T0, S0, rho0, vol0, pres, rhozero, variants, z_i
                     continue
             if out_host:
                 if not annual:
-                    d, e = core.steric_local(Tv, Sv, rho0m, surface, pres, neg_inv, **kw)
+                    d, e = core.steric_local(Tv, Sv, rho0m, surface, pc, neg_inv, **kw)
                 d2h.wait_stream(main)
                 with torch.cuda.stream(d2h):
                     torch.from_numpy(eta[v][o0:o1]).copy_(e, non_blocking=True)
@@ -434,7 +497,7 @@ def local_steric_variants(T, S, T0, S0, rho0, vol0, pres, rhozero, variants, z_i
                         torch.from_numpy(drho[v][o0:o1]).copy_(d, non_blocking=True)
                         d.record_stream(d2h)
             else:
-                core.steric_local(Tv, Sv, rho0m, surface, pres, neg_inv,
+                core.steric_local(Tv, Sv, rho0m, surface, pc, neg_inv,
                                   delta_rho_out=drho[v][t0:t1] if want_delta_rho else None,
                                   eta_out=eta[v][t0:t1], **kw)
     if d2h is not None:

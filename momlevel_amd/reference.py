@@ -28,15 +28,16 @@ def pressure_field(dset, zcoord, patm):
 
 
 def pressure_operand(pres, tcoord, cdims):
-    """Raw pressure for the kernels: scalar, z-profile, or a (z,y,x)-broadcastable array
-    in canonical dim order (patm given as a DataArray, steric.py:58-60)."""
-    if tcoord in pres.dims:
-        raise ValueError("a time-dependent `patm` is not supported by the fused steric path")
-    if pres.ndim <= 1:
+    """Raw pressure for the kernels in canonical dim order: a scalar, the z profile, a
+    (z,y,x)-broadcastable array (``patm`` given as a (yh,xh) DataArray, steric.py:58-60), or --
+    when ``patm`` carries the time dimension -- a 4-D (time,z,y,x)-broadcastable array, which the
+    engine cuts into the same time chunks as theta/S (MLX_P_FULL4D)."""
+    if pres.ndim <= 1 and tcoord not in pres.dims:
         return pres.data
-    sub = tuple(d for d in cdims if d in pres.dims)
+    order = ((tcoord,) if tcoord in pres.dims else ()) + tuple(cdims)
+    sub = tuple(d for d in order if d in pres.dims)
     vals = pres.transpose(*sub).values
-    return vals.reshape([pres.sizes.get(d, 1) for d in cdims])
+    return vals.reshape([pres.sizes.get(d, 1) for d in order])
 
 
 def _f32_mode():
@@ -67,34 +68,52 @@ def _setup(dset, patm, eos, coord_names, time_index, defer_masso):
     S0 = reference["so"].transpose(*cdims)
     V0 = reference["volcello"].transpose(*cdims)
     p = pressure_operand(pres, tcoord, cdims)
-
     on_device = T0.is_device or S0.is_device or V0.is_device
-    rho0, volo, masso0 = engine.reference_state(
-        T0.data, S0.data, V0.data, p, eos=eos.lower(), f32_mode=_f32_mode(),
-        with_masso=not defer_masso,
-    )
 
-    rho = DataArray(rho0 if on_device else rho0.cpu().numpy(), cdims, T0.coords)
-    rho.attrs = {
+    rho_attrs = {
         "standard_name": "sea_water_density",
         "long_name": "In situ sea water density",
         "comment": f"calculated with the {eos} equation of state",
         "units": "kg m-3",
     }
-    reference["rho"] = rho.transpose(*reference["thetao"].dims)
+    if tcoord in pres.dims:
+        # A `patm` with a time dimension makes the reference's rho0 = calc_rho(theta0, S0, pres)
+        # time dependent too (reference.py:71 broadcasts by name), and with it masso and rhoga
+        # (derived.py:435-438 sums every dim except time).  Reproduced as is: steric() then refuses
+        # such a self-made reference in validate_dataset, exactly like momlevel.
+        rho0, volo, masso_t = engine.reference_state_time_dependent(
+            T0.data, S0.data, V0.data, p, eos=eos.lower(), f32_mode=_f32_mode())
+        tdim = (tcoord,)
+        rho = DataArray(rho0 if on_device else rho0.cpu().numpy(), tdim + cdims,
+                        dict(T0.coords, **({tcoord: dset[tcoord]} if tcoord in dset.variables
+                                           else {})), rho_attrs)
+        reference["rho"] = rho
+        volo_h = float(volo.item())
+        masso_h = masso_t.cpu().numpy()
+        masso_dims, masso_val = tdim, masso_h
+        rhoga_val = masso_h / np.float64(volo_h)
+    else:
+        rho0, volo, masso0 = engine.reference_state(
+            T0.data, S0.data, V0.data, p, eos=eos.lower(), f32_mode=_f32_mode(),
+            with_masso=not defer_masso,
+        )
+        rho = DataArray(rho0 if on_device else rho0.cpu().numpy(), cdims, T0.coords, rho_attrs)
+        reference["rho"] = rho.transpose(*reference["thetao"].dims)
+        volo_h = float(volo.item())
+        masso_h = float("nan") if masso0 is None else float(masso0.item())
+        masso_dims, masso_val = (), np.array(masso_h)
+        rhoga_val = np.array(np.float64(masso_h) / np.float64(volo_h))
 
-    volo_h = float(volo.item())
-    masso_h = float("nan") if masso0 is None else float(masso0.item())
     reference["volo"] = DataArray(
         np.array(volo_h), (), None,
         {"standard_name": "sea_water_volume", "long_name": "Sea Water Volume", "units": "m3"},
     )
     reference["masso"] = DataArray(
-        np.array(masso_h), (), None,
+        masso_val, masso_dims, None,
         {"standard_name": "sea_water_mass", "long_name": "Sea Water Mass", "units": "kg"},
     )
     reference["rhoga"] = DataArray(
-        np.array(np.float64(masso_h) / np.float64(volo_h)), (), None,
+        rhoga_val, masso_dims, None,
         {"long_name": "Global Average Sea Water Density", "units": "kg m-3"},
     )
     reference["areacello"] = dset["areacello"]

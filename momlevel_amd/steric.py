@@ -61,11 +61,19 @@ def _check_dz_inputs(levels, interfaces, depth):
     )
 
 
-def _global_results(ops, reference, variants, dtype, tcoord, coords_for, deferred):
-    """steric.py:134-147 -- masso(t) from K1, then the Boussinesq offline approximation."""
+# EXTENSION (not in momlevel): ocean heat content beside the steric decomposition
+# (BASELINE.json configs[4]).  OHC(t) = rhozero * cp * sum(theta * volcello_ref) over the ocean,
+# relative to 0 degC, with MOM6's Boussinesq constants.
+OHC_CP = 3992.0  # J kg-1 K-1
+
+
+def _global_results(ops, reference, variants, dtype, tcoord, coords_for, deferred,
+                    heat=None):
+    """steric.py:134-147 -- masso(t) from K1, then the Boussinesq offline approximation.
+    ``heat=(rhozero, cp)``: also the ocean-heat-content extension (key "heat")."""
     T, S, T0, S0, vol0, p, eos = ops
     masso = engine.global_masso_variants(T, S, T0, S0, vol0, p, variants, eos=eos,
-                                         f32_mode=_f32_mode())
+                                         f32_mode=_f32_mode(), with_heat=heat is not None)
     masso = {v: m.cpu().numpy() for v, m in masso.items()}
     if deferred:  # the self-generated reference is time index 0 of this very record: every
         # variant sees (theta0, S0) there, so any of them carries masso0 (same kernel, same bits)
@@ -86,6 +94,17 @@ def _global_results(ops, reference, variants, dtype, tcoord, coords_for, deferre
         result["reference_height"].encoding["dtype"] = dtype
         result[v] = DataArray(sealevel, (tcoord,), coords_for((tcoord,)))
         out[v] = result
+    if heat is not None:
+        rhozero, cp = heat
+        result = Dataset()
+        result["ohc"] = DataArray(
+            (np.float64(rhozero) * np.float64(cp)) * masso["heat"], (tcoord,),
+            coords_for((tcoord,)),
+            {"long_name": "Global ocean heat content relative to 0 degC (momlevel_amd extension)",
+             "units": "J",
+             "comment": f"rhozero={rhozero} kg m-3 * cp={cp} J kg-1 K-1 * sum(thetao*volcello_ref)"},
+        )
+        out["heat"] = result
     return out
 
 
@@ -130,7 +149,7 @@ def _local_results(ops, dset, reference, variants, dtype, rhozero, names, cdims3
 
 
 def _steric_many(dset, variants, reference, coord_names, varname_map, rhozero, patm,
-                 equation_of_state, domain, dtype, strict, annual, verbose):
+                 equation_of_state, domain, dtype, strict, annual, verbose, heat_cp=None):
     """The body of steric() for one or several variants sharing one reference state and one
     pass of theta/S through the device.  Returns ({variant: result}, reference)."""
     dset = dset.rename(varname_map)
@@ -142,7 +161,9 @@ def _steric_many(dset, variants, reference, coord_names, varname_map, rhozero, p
     )
     pres = pressure_field(dset, zcoord, patm)  # 1 m of depth ~ 1 dbar = 1e4 Pa, plus patm
 
-    deferred = reference is None and domain == "global"
+    # (not with a time-dependent patm: that reference state is time dependent itself and is
+    #  rejected by the validation below, as in momlevel)
+    deferred = reference is None and domain == "global" and tcoord not in pres.dims
     if reference is None:
         # domain="global": masso0 is masso(t=0) of the K1 launch below (same kernel, same bits)
         reference = _setup(dset, patm, equation_of_state, coord_names, 0, defer_masso=deferred)
@@ -179,12 +200,19 @@ def _steric_many(dset, variants, reference, coord_names, varname_map, rhozero, p
         if not plan.contiguous:
             plan = None  # unusual time axis: average on the host afterwards
     if domain == "global":
-        results = _global_results(ops, reference, variants, dtype, tcoord, coords_for, deferred)
+        results = _global_results(ops, reference, variants, dtype, tcoord, coords_for, deferred,
+                                  heat=None if heat_cp is None else (rhozero, heat_cp))
     else:
+        if heat_cp is not None:
+            raise ValueError("heat_content is a global integral: use domain='global'")
         results = _local_results(ops, dset, reference, variants, dtype, rhozero, names, cdims3,
                                  coords_for, plan)
 
     for variant, result in results.items():
+        if variant == "heat":
+            if annual:
+                results[variant] = annual_average(result)
+            continue
         result[variant].attrs.update(
             {"long_name": f"{variant.capitalize()} height adjustment", "units": "m"}
         )
@@ -261,6 +289,8 @@ def steric_variants(
     strict=True,
     annual=False,
     verbose=False,
+    heat_content=False,
+    cp=OHC_CP,
 ):
     """EXTENSION (not in momlevel): several variants in one call.
 
@@ -268,6 +298,10 @@ def steric_variants(
     together, and with host-resident inputs each call is bound by moving theta/S over PCIe.
     This entry point uploads every time chunk once and runs the requested variants on it, with
     one shared reference state.  Each result is bit-identical to the corresponding single call.
+    With ``domain="global"`` two or more variants come out of ONE pass of the all-variants kernel
+    (theta/S read once).  ``heat_content=True`` (global only) adds ``results["heat"]["ohc"]``, the
+    ocean heat content ``rhozero * cp * sum(thetao * volcello_ref)`` per time step from the same
+    pass -- an extension with no counterpart in momlevel.
 
     Returns
     -------
@@ -276,6 +310,7 @@ def steric_variants(
     results, reference = _steric_many(
         dset, tuple(variants), reference, coord_names, varname_map, rhozero, patm,
         equation_of_state, domain, dtype, strict, annual, verbose,
+        heat_cp=cp if heat_content else None,
     )
     return (results, reference)
 

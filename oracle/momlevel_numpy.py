@@ -462,3 +462,16 @@ def generate_test_data_time(start_year=1981, nyears=5, calendar="noleap", seed=1
         "var_a": np.random.default_rng(seed).normal(100, 20, (nt, 5, 5)),
         "var_b": np.random.default_rng(seed * 2).normal(100, 20, (nt, 5, 5)),
     }
+
+
+# ----------------------------------------------------------------------------
+# EXTENSION -- NOT a momlevel function.  PARITY UNPINNED: the reference has no ocean-heat-content
+# code (grep heat|ohc over /root/reference/src is empty), so there is nothing to pin this against;
+# it is the build's own definition (BASELINE.json configs[4] names the quantity), restated in numpy
+# for the GPU tests of momlevel_amd.steric_variants(..., heat_content=True).
+# ----------------------------------------------------------------------------
+def ocean_heat_content(thetao, volcello_ref, rhozero=1035.0, cp=3992.0):
+    """OHC(t) = rhozero * cp * sum_{z,y,x} thetao(t) * volcello_ref  [J, relative to 0 degC];
+    skipna sum, float64 product (float32 theta is promoted by numpy)."""
+    heat = nansum(thetao * volcello_ref, axis=(1, 2, 3))
+    return (np.float64(rhozero) * np.float64(cp)) * heat

@@ -107,7 +107,7 @@ def test_abi_error_codes():
     with pytest.raises(_lib.MomlevelHipError, match="argument error -3"):
         lib = _lib.load()
         rc = lib.mlx_eos_map(T.data_ptr(), S.data_ptr(), 0, vol0.data_ptr(), 1, 7, 0,
-                             2, 3, 32, 96, 96, T.data_ptr(), None)
+                             2, 3, 32, 96, 96, 0, T.data_ptr(), None)
         _lib.check(rc, "mlx_eos_map")
     lib = _lib.load()
     ws = torch.empty(1, dtype=torch.float64, device="cuda")
@@ -332,3 +332,167 @@ def test_launch_targets_the_operands_device():
         assert np.array_equal(got.cpu().numpy(), base)
         with pytest.raises(ValueError):
             core.steric_global_masso(T, S.to(other), vol0, pres)
+
+
+# ---------------------------------------------------------------------------------------------
+# round 2: one-pass decomposition (all variants + heat), fused arithmetic, time-dependent pressure
+# ---------------------------------------------------------------------------------------------
+def _case_fields(shape, dtype, seed=3):
+    nt, nz, ny, nx = shape
+    g = synthetic.make_grid(ny, nx, nz)
+    r = np.random.default_rng(seed)
+    mask = np.isnan(g["volcello"])
+    T = np.where(mask[None], np.nan, r.uniform(-2, 32, shape)).astype(dtype)
+    S = np.where(mask[None], np.nan, r.uniform(30, 40, shape)).astype(dtype)
+    return g, T, S
+
+
+@pytest.mark.parametrize("skip_dry", [False, True])
+@pytest.mark.parametrize("dtype,f32_mode", [(np.float64, "faithful"), (np.float32, "faithful"),
+                                            (np.float32, "upcast")])
+@pytest.mark.parametrize("shape", [(37, 5, 12, 40), (9, 3, 7, 9), (3, 4, 2, 1024)])
+def test_decomposition_rows_equal_single_variant_launches(shape, dtype, f32_mode, skip_dry):
+    """mlx_steric_global_decomp: rows 0-2 bit-identical to three mlx_steric_global calls (same
+    tiling, same order), row 3 = sum(theta*vol0) vs numpy; 12x40 / 2x1024 planes take the dwordx4
+    kernel, 7x9 the scalar twin; nt=37 spans two 32-step time chunks."""
+    g, T, S = _case_fields(shape, dtype)
+    dT, dS = torch.from_numpy(T).cuda(), torch.from_numpy(S).cuda()
+    vol0 = torch.from_numpy(g["volcello"]).cuda()
+    pres = o.pressure_from_depth(g["z_l"])
+    kw = dict(f32_mode=f32_mode, skip_dry=skip_dry)
+    rows = core.steric_global_decomp(dT, dS, dT[0], dS[0], vol0, pres, **kw).cpu().numpy()
+    assert rows.shape == (4, shape[0])
+    assert np.array_equal(rows[0], core.steric_global_masso(dT, dS, vol0, pres, **kw).cpu().numpy())
+    assert np.array_equal(rows[1], core.steric_global_masso(dT, dS[0], vol0, pres, **kw).cpu().numpy())
+    assert np.array_equal(rows[2], core.steric_global_masso(dT[0], dS, vol0, pres, **kw).cpu().numpy())
+    assert rows[0][0] == rows[1][0] == rows[2][0]  # t=0: every variant sees (theta0, S0)
+    heat = np.nansum(T.astype(np.float64) * g["volcello"], axis=(1, 2, 3))
+    assert_rel(rows[3], heat, 1e-12, "heat integrand")
+    # and against the oracle (the single launches are checked elsewhere; this closes the loop)
+    Tn, Sn = (T.astype(np.float64), S.astype(np.float64)) if f32_mode == "upcast" else (T, S)
+    pb = pres[:, None, None]
+    for row, (a, b) in zip(rows[:3], [(Tn, Sn), (Tn, Sn[0]), (Tn[0], Sn)]):
+        ref = np.nansum(np.broadcast_to(o.wright_density(a, b, pb), T.shape) * g["volcello"],
+                        axis=(1, 2, 3))
+        assert_rel(row, ref, 1e-12, "masso vs oracle")
+
+
+def test_decomposition_with_a_separate_reference_state():
+    """T0/S0 need not be time level 0 of the record (a reference read from an earlier run)"""
+    g, T, S = _case_fields((6, 4, 8, 16), np.float64)
+    _, T0, S0 = _case_fields((1, 4, 8, 16), np.float64, seed=99)
+    dT, dS = torch.from_numpy(T).cuda(), torch.from_numpy(S).cuda()
+    dT0, dS0 = torch.from_numpy(T0[0]).cuda(), torch.from_numpy(S0[0]).cuda()
+    vol0 = torch.from_numpy(g["volcello"]).cuda()
+    pres = o.pressure_from_depth(g["z_l"])
+    rows = core.steric_global_decomp(dT, dS, dT0, dS0, vol0, pres).cpu().numpy()
+    assert np.array_equal(rows[1], core.steric_global_masso(dT, dS0, vol0, pres).cpu().numpy())
+    assert np.array_equal(rows[2], core.steric_global_masso(dT0, dS, vol0, pres).cpu().numpy())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(19, 6, 12, 40), (5, 3, 7, 9)])
+def test_fused_arithmetic_meets_the_parity_gate(shape, dtype):
+    """MLX_FLAG_FMA (opt-in): rho and masso within 1e-10 relative of the oracle (north_star's fp64
+    tolerance), delta_rho / eta within 1e-10 * max|ref|; and the fused kernels agree with EACH
+    OTHER bit for bit: masso(t=0) identical across variants and equal to the reference state's,
+    delta_rho(t=0) exactly 0, K0 == K2 + rho0."""
+    g, T, S = _case_fields(shape, dtype)
+    Tn, Sn = T.astype(np.float64), S.astype(np.float64)  # fused arithmetic is float64 on the values
+    dT, dS = torch.from_numpy(T).cuda(), torch.from_numpy(S).cuda()
+    vol0 = torch.from_numpy(g["volcello"]).cuda()
+    pres = o.pressure_from_depth(g["z_l"])
+    pb = pres[:, None, None]
+    rho_ref = o.wright_density(Tn, Sn, pb)
+    rho = core.eos_map(dT, dS, pres, arith="fused").cpu().numpy()
+    assert_rel(rho, rho_ref, 1e-10, "fused rho")
+    m = ~np.isnan(rho_ref)
+    assert np.max(np.abs(rho[m] - rho_ref[m]) / rho_ref[m]) < 2e-15  # in fact a few ulp
+    assert not np.array_equal(rho[m], core.eos_map(dT, dS, pres, arith="exact").cpu().numpy()[m])
+    kw = dict(arith="fused")
+    rows = core.steric_global_decomp(dT, dS, dT[0], dS[0], vol0, pres, **kw).cpu().numpy()
+    singles = [core.steric_global_masso(dT, dS, vol0, pres, **kw),
+               core.steric_global_masso(dT, dS[0], vol0, pres, **kw),
+               core.steric_global_masso(dT[0], dS, vol0, pres, **kw)]
+    for row, single, (a, b) in zip(rows, singles, [(Tn, Sn), (Tn, Sn[0]), (Tn[0], Sn)]):
+        assert np.array_equal(row, single.cpu().numpy())
+        ref = np.nansum(np.broadcast_to(o.wright_density(a, b, pb), T.shape) * g["volcello"],
+                        axis=(1, 2, 3))
+        assert_rel(row, ref, 1e-10, "fused masso")
+    masso0 = core.steric_global_masso(dT[:1], dS[:1], vol0, pres, **kw).cpu().numpy()[0]
+    assert rows[0][0] == rows[1][0] == rows[2][0] == masso0
+    # local: rho0 from the fused K0, so delta_rho(t=0) == 0 exactly, for every variant
+    rho0 = core.eos_map(dT[0], dS[0], pres, arith="fused")
+    rho0m = core.fold_mask(rho0, vol0)
+    drho_ref = np.where(~np.isnan(g["volcello"]), rho_ref - rho_ref[0], np.nan)
+    dz = o.calc_dz(g["z_l"], g["z_i"], g["deptho"])
+    for (a, b, an, bn) in [(dT, dS, Tn, Sn), (dT, dS[0], Tn, Sn[0]), (dT[0], dS, Tn[0], Sn)]:
+        drho, eta = core.steric_local(a, b, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=g["z_i"],
+                                      deptho=g["deptho"], **kw)
+        drho, eta = drho.cpu().numpy(), eta.cpu().numpy()
+        wet = ~np.isnan(g["volcello"])
+        assert np.all(drho[0][wet] == 0.0)
+        r = np.broadcast_to(o.wright_density(an, bn, pb), T.shape)
+        dref = np.where(wet, r - rho_ref[0], np.nan)
+        eref = np.where(wet[0], (-1.0 / 1035.0) * np.nansum(dz * dref, axis=1), np.nan)
+        assert np.array_equal(np.isnan(drho), np.isnan(dref))
+        assert np.nanmax(np.abs(drho - dref)) <= 1e-10 * np.nanmax(np.abs(dref))
+        assert np.array_equal(np.isnan(eta), np.isnan(eref))
+        assert np.nanmax(np.abs(eta - eref)) <= 1e-10 * np.nanmax(np.abs(eref))
+
+
+def test_fused_mode_is_opt_in(monkeypatch):
+    g, vol0, T, S, pres = make_case(4, 3, 8, 16)
+    exact = core.steric_global_masso(T, S, vol0, pres, arith="exact").cpu().numpy()
+    assert np.array_equal(core.steric_global_masso(T, S, vol0, pres).cpu().numpy(), exact)
+    monkeypatch.setenv("MOMLEVEL_AMD_ARITH", "fused")
+    fused = core.steric_global_masso(T, S, vol0, pres).cpu().numpy()
+    assert np.array_equal(fused, core.steric_global_masso(T, S, vol0, pres, arith="fused").cpu().numpy())
+    assert_rel(fused, exact, 1e-12)
+    monkeypatch.setenv("MOMLEVEL_AMD_ARITH", "sloppy")
+    with pytest.raises(ValueError):
+        core.steric_global_masso(T, S, vol0, pres)
+
+
+@pytest.mark.parametrize("t_chunk", [8, 16, 64, 2040])
+def test_time_chunk_hint_never_changes_a_result(t_chunk):
+    g, vol0, T, S, pres = make_case(70, 3, 8, 32)
+    base = core.steric_global_masso(T, S, vol0, pres).cpu().numpy()
+    assert np.array_equal(core.steric_global_masso(T, S, vol0, pres, t_chunk=t_chunk).cpu().numpy(), base)
+    assert np.array_equal(core.steric_global_masso(T, S[0], vol0, pres, t_chunk=t_chunk).cpu().numpy(),
+                          core.steric_global_masso(T, S[0], vol0, pres).cpu().numpy())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_time_dependent_pressure_in_the_fused_kernels(dtype):
+    """MLX_P_FULL4D in K1 / K2 (a patm DataArray with a time dimension, steric.py:58-60,96)"""
+    shape = (5, 4, 6, 10)
+    g, T, S = _case_fields(shape, dtype)
+    r = np.random.default_rng(8)
+    patm = 101325.0 + r.normal(0.0, 800.0, (shape[0], 1, shape[2], shape[3]))
+    pres = (g["z_l"] * 1.0e4)[None, :, None, None] + patm
+    dT, dS = torch.from_numpy(T).cuda(), torch.from_numpy(S).cuda()
+    vol0 = torch.from_numpy(g["volcello"]).cuda()
+    rho = o.wright_density(T, S, pres)
+    assert_bit_equal(core.eos_map(dT, dS, pres).cpu().numpy(), rho, "K0 4-D pressure")
+    masso = core.steric_global_masso(dT, dS, vol0, pres).cpu().numpy()
+    assert_rel(masso, np.nansum(rho * g["volcello"], axis=(1, 2, 3)), 1e-12, "K1 4-D pressure")
+    rho0 = o.wright_density(T[0], S[0], (g["z_l"] * 1.0e4 + 101325.0)[:, None, None])
+    rho0m = core.fold_mask(torch.from_numpy(rho0).cuda(), vol0)
+    drho, eta = core.steric_local(dT, dS, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=g["z_i"],
+                                  deptho=g["deptho"])
+    dref = np.where(~np.isnan(g["volcello"]), rho - rho0, np.nan)
+    dz = o.calc_dz(g["z_l"], g["z_i"], g["deptho"])
+    eref = np.where(~np.isnan(g["volcello"][0]), (-1.0 / 1035.0) * np.nansum(dz * dref, axis=1), np.nan)
+    assert_bit_equal(drho.cpu().numpy(), dref, "K2 4-D pressure delta_rho")
+    assert_bit_equal(eta.cpu().numpy(), eref, "K2 4-D pressure eta")
+    rows = core.steric_global_decomp(dT, dS, dT[0], dS[0], vol0, pres).cpu().numpy()
+    assert np.array_equal(rows[0], masso)
+    assert_rel(rows[1], np.nansum(o.wright_density(T, S[0], pres) * g["volcello"], axis=(1, 2, 3)),
+               1e-12, "thermo 4-D pressure")
+
+
+def test_stream_probe_adds():
+    a = torch.rand(4096 * 6, dtype=torch.float64, device="cuda")
+    b = torch.rand(4096 * 6, dtype=torch.float64, device="cuda")
+    assert torch.equal(core.stream_probe(a, b), a + b)

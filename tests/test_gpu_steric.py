@@ -313,6 +313,48 @@ def test_patm_as_dataarray():
     assert_bit_equal(res["delta_rho"].values, drho, "delta_rho with 2-D patm")
 
 
+@pytest.mark.parametrize("domain", ["local", "global"])
+def test_patm_with_a_time_dimension(domain, monkeypatch, capsys):
+    """patm may be any DataArray (steric.py:58-60,96).  With a time dimension the pressure is 4-D:
+    rho(t) = rho(theta(t), S(t), z*1e4 + patm(t)); given a reference state (here from a scalar
+    patm) momlevel computes that.  WITHOUT one, its self-made reference is time dependent too
+    (reference.py:54,71) and fails validate_dataset (rho 4-D, masso/rhoga not scalar) -- same here."""
+    from momlevel_amd import engine
+
+    d = _masked_dataset(nt=5)
+    r = np.random.default_rng(4)
+    patm = 101325.0 + r.normal(0.0, 600.0, (5,) + d["areacello"].shape)
+    patm_da = DataArray(patm, ("time", "yh", "xh"))
+    _, ref = steric(d, domain=domain)  # reference state from a scalar patm
+    monkeypatch.setattr(engine, "chunk_steps", lambda nt, b, dev, budget_bytes=None: 2)
+    res, _ = steric(d, reference=ref, patm=patm_da, domain=domain)
+    T, S, vol0 = d["thetao"].values, d["so"].values, d["volcello"].values[0]
+    pres = d["z_l"].values[None, :, None, None] * 1.0e4 + patm[:, None]
+    rho = o.wright_density(T, S, pres)
+    if domain == "local":
+        drho = np.where(~np.isnan(vol0), rho - ref["rho"].values, np.nan)
+        assert_bit_equal(res["delta_rho"].values, drho, "delta_rho, patm(time,yh,xh)")
+        dz = o.calc_dz(d["z_l"].values, d["z_i"].values, d["deptho"].values)
+        eta = np.where(~np.isnan(vol0[0]), (-1.0 / 1035.0) * np.nansum(dz * drho, axis=1), np.nan)
+        assert_bit_equal(res["steric"].values, eta, "eta, patm(time,yh,xh)")
+    else:
+        masso = np.nansum(rho * vol0, axis=(1, 2, 3))
+        expansion = np.log(float(ref["rhoga"]) / (masso / float(ref["volo"])))
+        h = float(res["reference_height"])
+        assert np.allclose(res["steric"].values / h, expansion, rtol=0, atol=1e-12)
+    capsys.readouterr()
+    with pytest.raises(ValueError, match="Errors found in dataset."):
+        steric(d, patm=patm_da, domain=domain)
+    out = capsys.readouterr().out
+    assert "Variable masso must be a scalar" in out and "Variable rhoga must be a scalar" in out
+    # setup_reference_state itself returns the time-dependent state, as momlevel's does
+    tref = reference_mod.setup_reference_state(d, patm=patm_da)
+    assert tref["rho"].dims == ("time", "z_l", "yh", "xh") and tref["masso"].dims == ("time",)
+    rho0_t = o.wright_density(T[0], S[0], pres)
+    assert_bit_equal(tref["rho"].values, rho0_t, "time-dependent rho0")
+    assert_rel(tref["masso"].values, np.nansum(rho0_t * vol0, axis=(1, 2, 3)), RTOL_SUM)
+
+
 def test_linear_equation_of_state():
     d = _masked_dataset()
     res, ref = steric(d, equation_of_state="linear")
@@ -392,6 +434,68 @@ def test_steric_variants_extension_matches_single_calls(domain, monkeypatch):
             assert float(reference["masso"]) == float(ref1["masso"])
     with pytest.raises(ValueError):
         steric_variants(d, variants=("steric", "bogus"))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_global_decomposition_and_heat_content_in_one_pass(dtype, monkeypatch):
+    """steric_variants(domain="global") runs the all-variants kernel (theta/S read ONCE); every
+    variant stays bit-identical to its own steric() call; heat_content=True adds the OHC row
+    (extension; own numpy oracle, parity unpinned -- momlevel has no such function)."""
+    from momlevel_amd import core, engine, steric_variants
+
+    d = _masked_dataset(nt=7, dtype=dtype)
+    calls = {"decomp": 0, "single": 0}
+    real_decomp, real_single = core.steric_global_decomp, core.steric_global_masso
+
+    def count_decomp(*a, **k):
+        calls["decomp"] += 1
+        return real_decomp(*a, **k)
+
+    def count_single(*a, **k):
+        calls["single"] += 1
+        return real_single(*a, **k)
+
+    monkeypatch.setattr(core, "steric_global_decomp", count_decomp)
+    monkeypatch.setattr(core, "steric_global_masso", count_single)
+    monkeypatch.setattr(engine, "chunk_steps", lambda nt, b, dev, budget_bytes=None: 4)
+    results, reference = steric_variants(d, domain="global", heat_content=True)
+    assert calls == {"decomp": 2, "single": 0}  # two time chunks, one launch each
+    assert set(results) == {"steric", "thermosteric", "halosteric", "heat"}
+    ohc = o.ocean_heat_content(d["thetao"].values, d["volcello"].values[0])
+    assert_rel(results["heat"]["ohc"].values, ohc, 1e-12, "ocean heat content")
+    assert results["heat"]["ohc"].attrs["units"] == "J"
+    for variant in ("steric", "thermosteric", "halosteric"):
+        single, ref1 = steric(d, variant=variant, domain="global")
+        assert_bit_equal(results[variant][variant].values, single[variant].values, variant)
+        assert float(results[variant][variant][0]) == 0.0
+        assert float(reference["masso"]) == float(ref1["masso"])
+    with pytest.raises(ValueError):
+        steric_variants(d, domain="local", heat_content=True)
+
+
+def test_fused_arithmetic_through_the_public_api(monkeypatch):
+    """MOMLEVEL_AMD_ARITH=fused: the whole path (reference rho0, K1, K2) switches together, so
+    the exact zeros at t=0 survive, and results stay within north_star's 1e-10 of the oracle."""
+    d = _masked_dataset(nt=5)
+    exact, _ = steric(d)
+    gexact, _ = steric(d, domain="global")
+    monkeypatch.setenv("MOMLEVEL_AMD_ARITH", "fused")
+    for variant in ("steric", "thermosteric", "halosteric"):
+        res, ref = steric(d, variant=variant)
+        ores, oref = _oracle(d, variant=variant)
+        wet = ~np.isnan(ores["delta_rho"][0])
+        assert np.all(res["delta_rho"].values[0][wet] == 0.0)
+        err = np.nanmax(np.abs(res["delta_rho"].values - ores["delta_rho"]))
+        assert err <= 1e-10 * np.nanmax(np.abs(ores["delta_rho"])) and err > 0.0
+        err = np.nanmax(np.abs(res[variant].values - ores[variant]))
+        assert err <= 1e-10 * np.nanmax(np.abs(ores[variant]))
+        assert_rel(ref["rho"].values, oref["rho"], 1e-10, "fused rho0")
+        gres, gref = steric(d, variant=variant, domain="global")
+        ogres, ogref = _oracle(d, variant=variant, domain="global")
+        assert float(gres[variant][0]) == 0.0
+        assert_rel(gref["masso"].values, ogref["masso"], RTOL_SUM, "fused masso0")
+        h = float(gres["reference_height"])
+        assert np.allclose(gres[variant].values / h, ogres["expansion_coeff"], rtol=0, atol=1e-12)
 
 
 def test_delta_rho_can_be_elided(monkeypatch):
