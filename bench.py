@@ -316,7 +316,7 @@ def main():
     traffic, traffic_src = (None, None) if f32 else measured_traffic(cells_rank)
 
     extras = {}
-    if not a.no_extras and world == 1 and not f32:
+    if not a.no_extras and world == 1:
         extras = local_variant_timings(T, S, vol0, pres, g, dev)
 
     cpu, parity, cpu_fused, cpu_procs = None, None, None, None
@@ -413,6 +413,7 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
     nt, nz, ny, nx = T.shape
     cells = nt * nz * ny * nx
     out = {}
+    B1 = T.element_size()  # bytes per cell of ONE streamed field: 8 (float64) or 4 (float32)
 
     def rate(ms, bytes_per_cell, n=cells):
         return {"Mcells/s": round(n / ms / 1e3, 1), "ms": round(ms, 3),
@@ -424,25 +425,26 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
         tag = "" if arith == "exact" else "_fused"
         ms = _time(lambda: core.steric_global_masso(T, S[0], vol0, pres, skip_dry=False,
                                                     arith=arith))
-        out["thermosteric_global" + tag] = rate(ms, 8)
+        out["thermosteric_global" + tag] = rate(ms, B1)
         ms = _time(lambda: core.steric_global_masso(T[0], S, vol0, pres, skip_dry=False,
                                                     arith=arith))
-        out["halosteric_global" + tag] = rate(ms, 8)
+        out["halosteric_global" + tag] = rate(ms, B1)
     ms = _time(lambda: core.steric_global_masso(T, S, vol0, pres, skip_dry=False, arith="fused"))
-    out["steric_global_fused"] = rate(ms, 16)
+    out["steric_global_fused"] = rate(ms, 2 * B1)
     # BASELINE.json configs[4]: steric + thermosteric + halosteric (+ heat content) from ONE pass
     # over theta/S, against the sum of the three single-variant launches
     for arith in ("exact", "fused"):
         ms = _time(lambda: core.steric_global_decomp(T, S, T[0], S[0], vol0, pres, skip_dry=False,
                                                      arith=arith))
-        r = rate(ms, 16)
+        r = rate(ms, 2 * B1)
         r["note"] = "all three variants + sum(theta*vol0) per step, theta/S read once"
         out["decomposition_one_pass" + ("" if arith == "exact" else "_fused")] = r
     # calibration: this box's plain streaming-read rate through the same 16-byte nt loads
     # (skipna sum of the theta record) -- the practical ceiling K1's 16 B/cell runs against
-    ms = _time(lambda: core.nansum(T))
-    out["stream_read_probe"] = {"GB/s": round(8 * cells / ms / 1e6, 1),
-                                "note": "mlx_nansum over theta (one 112 GB stream, nt loads)"}
+    if B1 == 8:
+        ms = _time(lambda: core.nansum(T))
+        out["stream_read_probe"] = {"GB/s": round(8 * cells / ms / 1e6, 1),
+                                    "note": "mlx_nansum over theta (one 112 GB stream, nt loads)"}
     # the product default (MLX_FLAG_SKIP_DRY): theta/S of all-dry 16-byte packs are never loaded;
     # bit-identical results, fewer HBM bytes than the 16 B/cell the metric counts
     ms = _time(lambda: core.steric_global_masso(T, S, vol0, pres, skip_dry=True))
@@ -459,7 +461,7 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
     ms = _time(lambda: core.steric_local(T, S, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=zi,
                                          deptho=dep, want_delta_rho=False, eta_out=eta,
                                          skip_dry=False))
-    out["local_eta_only"] = rate(ms, 16)
+    out["local_eta_only"] = rate(ms, 2 * B1)
     chunk = min(nt, 16)
     free, _ = torch.cuda.mem_get_info(dev)
     if free > chunk * nz * ny * nx * 8 + (2 << 30):
@@ -474,7 +476,7 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
                                   eta_out=eta[t0:t0 + chunk], skip_dry=skip)
 
         ms = _time(lambda: run(False), reps=2)
-        out["local_with_delta_rho"] = rate(ms, 24, done)
+        out["local_with_delta_rho"] = rate(ms, 2 * B1 + 8, done)
 
         # the same traffic with no arithmetic: 16 B read + 8 B written per cell through the same
         # 16-byte nt loads/stores -- this box's ceiling for the pass above
@@ -482,11 +484,12 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
             for t0 in starts:
                 core.stream_probe(T[t0:t0 + chunk], S[t0:t0 + chunk], out=drho)
 
-        pms = _time(probe, reps=2)
-        out["stream_read_write_probe"] = {
-            "GB/s": round(24 * done / pms / 1e6, 1), "ms": round(pms, 3),
-            "note": "mlx_stream_probe: out = a + b, 16 B read + 8 B written per element"}
-        out["local_with_delta_rho"]["frac_of_read_write_probe"] = round(pms / ms, 4)
+        if B1 == 8:
+            pms = _time(probe, reps=2)
+            out["stream_read_write_probe"] = {
+                "GB/s": round(24 * done / pms / 1e6, 1), "ms": round(pms, 3),
+                "note": "mlx_stream_probe: out = a + b, 16 B read + 8 B written per element"}
+            out["local_with_delta_rho"]["frac_of_read_write_probe"] = round(pms / ms, 4)
         ms = _time(lambda: run(True), reps=2)
         out["land_skipping"]["local_with_delta_rho_Mcells/s"] = round(done / ms / 1e3, 1)
     return out

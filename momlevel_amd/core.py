@@ -312,12 +312,11 @@ def fold_mask(rho0, vol0):
 
 def steric_local(T, S, rho0m, vol0_surface, p, neg_inv_rhozero, dz=None, z_i=None,
                  deptho=None, eos="wright", f32_mode="faithful", want_delta_rho=True,
-                 delta_rho_out=None, eta_out=None, skip_dry=None):
-    """K2: (delta_rho (nt,nz,ny,nx) or None, eta (nt,ny,nx)).  ``skip_dry``: see
-    steric_global_masso."""
+                 delta_rho_out=None, eta_out=None, skip_dry=None, arith=None):
+    """K2: (delta_rho (nt,nz,ny,nx) or None, eta (nt,ny,nx)).  ``skip_dry``, ``arith``: see
+    steric_global_masso.  ``p`` may be time dependent (4-D)."""
     require_device()
-    if skip_dry is None:
-        skip_dry = skip_dry_default()
+    flags = _k1_flags(skip_dry, arith, 0)
     T, S, nt, nz, ny, nx, sT, sS, dt, _ = _pair(T, S, f32_mode)
     dev = T.device
     rho0m = _f64(rho0m, dev)

@@ -19,7 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def build_demo():
     exe = os.path.join(ROOT, "examples", "c_abi_demo")
     src = os.path.join(ROOT, "examples", "c_abi_demo.cpp")
-    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+    deps = [src, os.path.join(ROOT, "include", "momlevel_hip.h"),
+            os.path.join(ROOT, "momlevel_amd", "libmomlevel_hip.so")]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(map(os.path.getmtime, deps)):
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
         subprocess.run(
             [hipcc, "--offload-arch=gfx950", "-O2", src, "-I" + os.path.join(ROOT, "include"),
