@@ -44,7 +44,8 @@ METRIC = "Mcells/s for fused Wright-EOS+steric at 1440\u00d71080\u00d775; % HBM 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_CELL = 16    # theta 8 + S 8; vol0/p are amortised over the time loop
 GRID = (75, 1080, 1440)
-NT_PER_GPU = 120
+NT_PER_GPU = 120        # N=1: BASELINE.json configs[2]
+NT_PER_GPU_TILED = 150  # N>1: configs[3] -- 150*N steps of a 1/N tile (N=8: the 1200-step record)
 
 
 def parse():
@@ -52,7 +53,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--nt", type=int, default=NT_PER_GPU, help="time steps per GPU")
+    ap.add_argument("--nt", type=int, default=0,
+                    help="time steps per GPU in full-grid equivalents (default 120 at N=1, 150 at N>1)")
+    ap.add_argument("--chunks", type=int, default=5,
+                    help="N>1: time chunks the record is walked in (one all-reduce each)")
     ap.add_argument("--grid", default=None, help="nz,ny,nx (default 75,1080,1440)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target seconds of CPU-baseline work (0 disables it)")
@@ -255,6 +259,8 @@ def main():
     tile = synthetic.tile_bounds(ny, nx, rank, world)
     th, tw = tile[1] - tile[0], tile[3] - tile[2]
     g = synthetic.make_grid(ny, nx, nz, tile=tile)
+    if a.nt <= 0:
+        a.nt = NT_PER_GPU if world == 1 else NT_PER_GPU_TILED
     nt_req = a.nt * world
     f32 = a.input_dtype == "f32"
     tdtype = torch.float32 if f32 else torch.float64
@@ -275,9 +281,25 @@ def main():
     torch.cuda.synchronize(dev)
 
     launch_ms = []
+    chunk_steps = -(-nt // max(1, a.chunks))
+
+    def step_tiled(timed):
+        """N>1 (BASELINE.json configs[3]): the rank's tile of the whole record, walked in time
+        chunks -- K1 per chunk, ONE asynchronous all-reduce per chunk overlapping the next chunk's
+        kernel ([volo, masso0, sum(area)] ride in the first), epilogue replicated on every rank."""
+        core.eos_map(T[0], S[0], pres)  # the reference state's rho0, as at N=1
+        evs = []
+        res = parallel.steric_global_tile_streamed(
+            (T, S), vol0, area, pres, variants=("steric",), steps=chunk_steps, skip_dry=False,
+            events=evs)
+        if timed:
+            launch_ms.append(evs)
+        return res["steric"]
 
     def step(timed):
         """One pass of the hot path over the resident batch (what momlevel.steric(global) does)."""
+        if world > 1:
+            return step_tiled(timed)
         _rho0, volo, _ = engine.reference_state(T[0], S[0], vol0, pres, with_masso=False)
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         # skip_dry=False: the headline loads every cell, wet or dry, as the metric defines a cell
@@ -288,7 +310,7 @@ def main():
         red = parallel.exchange_global(masso, volo, masso0, asum)
         out = parallel.finalize(*red)  # D2H + host epilogue (synchronises)
         if timed:
-            launch_ms.append(ev)
+            launch_ms.append([ev])
         return out
 
     def fence():
@@ -310,7 +332,9 @@ def main():
 
     cells_rank = nt * nz * th * tw
     cells_job = cells_rank * world
-    k1_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in launch_ms]))
+    # K1 time of one pass over the record = the sum over its chunk launches (one launch at N=1)
+    k1_ms = float(np.mean([sum(e0.elapsed_time(e1) for e0, e1 in evs) for evs in launch_ms]))
+    n_launches = len(launch_ms[0])
     achieved = bytes_per_cell * cells_rank / (k1_ms * 1e-3) / 1e9
 
     traffic, traffic_src = (None, None) if f32 else measured_traffic(cells_rank)
@@ -350,8 +374,10 @@ def main():
                     "steric (BASELINE.json configs[2])" if world == 1 else
                     f"OM4 0.25deg synthetic grid {nx}x{ny}x{nz} tiled {layout} (yh x xh), {nt} time "
                     f"steps, fp64, global steric: every GPU holds all {nt} steps of its "
-                    f"{tw}x{th} tile = the cells of {nt // world} full-grid steps "
-                    "(BASELINE.json configs[3], weak scaling in time)"),
+                    f"{tw}x{th} tile resident = the cells of {nt / world:g} full-grid steps, walked "
+                    f"in {n_launches} time chunks of <= {chunk_steps} steps with one RCCL all-reduce "
+                    "per chunk (BASELINE.json configs[3]; weak scaling: bytes per GPU are fixed, "
+                    "the record grows with N)"),
                 "grid_xyz": [nx, ny, nz],
                 "nt_per_gpu_resident": nt,
                 "nt_total": nt,
@@ -359,7 +385,10 @@ def main():
                 "tile_xy": [tw, th],
                 "variant": "steric",
                 "domain": "global",
-                "collective": "none" if world == 1 else f"1 all_reduce of {nt + 3} f64 per step",
+                "collective": ("none" if world == 1 else
+                               f"{n_launches} all_reduce per step: {chunk_steps}(+3 in the first) f64 "
+                               "each, asynchronous, overlapped with the next chunk's kernel"),
+                "time_chunks": n_launches,
                 "input_dtype": a.input_dtype,
                 "hbm_resident_gb": round(2 * cells_rank * (4 if f32 else 8) / 1e9, 1),
             },
@@ -375,6 +404,7 @@ def main():
                 "traffic_unit": "GB per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc)",
                 "traffic_source": traffic_src,
                 "launch_ms": round(k1_ms, 4),
+                "launches_per_step": n_launches,
                 "algorithmic_bytes_per_cell": bytes_per_cell,
                 "algorithmic_gb_per_launch": round(bytes_per_cell * cells_rank / 1e9, 2),
                 "cells_per_launch": cells_rank,

@@ -752,7 +752,11 @@ constexpr int kU32 = 2, kVec32 = 4;  // 8 cells/thread (fast f32)
 // share ONE tiling: the reference state's masso0 (VAR 0, nt=1) has to equal masso(t=0) of the
 // held-field launches bit for bit, and the partial-sum order is a function of the tiling.
 constexpr int kUGen = 4;             // generic: 4 scalar cells/thread, 1024 cells/block
-constexpr int kTChunk = 32;          // K1 time steps per block (grid.z = ceil(nt / t_chunk))
+constexpr int kTChunk = 32;          // K1 time steps per block (grid.z = ceil(nt / t_chunk)), steric
+constexpr int kTChunkHeld = 64;      // held-field variants and the all-variants pass: vol0 and the
+                                     // held field are re-read once per chunk -- at 8 B/cell that is
+                                     // 10 % extra traffic with 32-step chunks; 64..120 steps measured
+                                     // 1-3.5 % faster (profiles/r02_tune_tchunk.log), steric is flat
 constexpr int kNTI64 = 16;           // time steps per K2 thread, f64 (2 columns/thread)
 constexpr int kNTI32 = 8;            // f32 (4 columns/thread)
 constexpr int kNTIGen = 8;           // generic scalar path
@@ -863,9 +867,9 @@ int64_t k1_blocks(bool fast, int dtype, int64_t plane) {
   return ceil_div(plane, cells);
 }
 
-int k1_time_chunk(int flags, int64_t nt) {
+int k1_time_chunk(int flags, int64_t nt, int var) {
   const int hint = (flags & MLX_FLAG_TCHUNK_MASK) >> 8;
-  int64_t tc = hint ? (int64_t)hint * 8 : kTChunk;
+  int64_t tc = hint ? (int64_t)hint * 8 : (var == kVarSteric ? kTChunk : kTChunkHeld);
   if (tc > nt) tc = nt;
   return (int)tc;
 }
@@ -899,7 +903,7 @@ int steric_global_impl(const void* T, const void* S, const void* T0, const void*
   }
   K1Args a;
   const int64_t gx = k1_blocks(fast, dtype, plane);
-  a.t_chunk = k1_time_chunk(flags, nt);
+  a.t_chunk = k1_time_chunk(flags, nt, var);
   if (ceil_div(nt, a.t_chunk) > 65535) return fail(MLX_E_SHAPE, "nt too large for one call: chunk it");
   if (gx > 2147483647LL) return fail(MLX_E_SHAPE, "plane too large");
   a.grid = dim3((unsigned)gx, (unsigned)nz, (unsigned)ceil_div(nt, a.t_chunk));

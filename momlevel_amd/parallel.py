@@ -1,14 +1,18 @@
-"""Multi-GPU global steric: horizontal tiles + ONE all-reduce.
+"""Multi-GPU global steric: horizontal tiles + one all-reduce per time chunk.
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  The
 (yh, xh) plane is tiled across ranks (1x2, 2x2, 2x4); every rank runs K1 on its
 own tile for all z and t -- the tiles are independent, nothing is exchanged on
-the data path -- and the only collective is a single ``all_reduce(SUM)`` of the
-packed float64 vector
+the data path -- and the only collective is an ``all_reduce(SUM)`` of the packed
+float64 vector
 
-    [ masso(t) for every local time step | volo | masso0 | sum(areacello) ]
+    [ masso(t) for every time step of the chunk | volo | masso0 | sum(areacello) ]
 
-((nt+3)*8 bytes: latency-bound, a few tens of microseconds on xGMI).  Every rank
+once per time chunk (the last three ride in the first chunk's; (nt_chunk+3)*8 bytes:
+latency-bound, a few tens of microseconds on xGMI, asynchronous and overlapped with the next
+chunk's kernels).  A record that fits in HBM can go as ONE chunk; a 1200-step record
+(BASELINE.json configs[3]) is walked in chunks, from resident tensors, host arrays or a
+generator (``steric_global_tile_streamed``).  Every rank
 then evaluates ``h_ref * ln(rhoga0 * volo / masso(t))`` redundantly.  masso0 and
 masso(t) travel in the same vector and are summed in the same rank order, so
 ``steric[t=0] == 0`` holds exactly for any world size, as on one GPU.
@@ -95,36 +99,173 @@ def finalize(masso, volo, masso0, area_sum):
     }
 
 
+_VARIANTS = ("steric", "thermosteric", "halosteric")
+
+
+class ChunkedExchange:
+    """The data-path collective of the tiled global variants, one all-reduce PER TIME CHUNK
+    (SURVEY.md 8e): chunk k contributes the packed float64 vector
+
+        [ masso_v(t) for every requested row v and every step t of the chunk ]
+        ++ [ volo, masso0, sum(areacello) ]            (first chunk only)
+
+    (``(rows*nt_chunk + 3) * 8`` bytes: latency-bound).  With RCCL the all-reduce is asynchronous:
+    it is enqueued behind the chunk's kernels and overlaps the next chunk's, and nothing is read
+    back before ``finish()``.  Without a process group (one GPU) it is the identity.  The class
+    knows nothing about kernels: ``add`` takes the rank's partial sums as tensors (device tensors
+    from K1 in the product; the gloo tests feed it host tensors).
+    """
+
+    def __init__(self, nrows, group=None):
+        self.nrows = nrows
+        self.group = group
+        self._pending = []  # (vector, work handle or None, nt_chunk, has_tail)
+        self.active = (dist.is_available() and dist.is_initialized()
+                       and dist.get_world_size(group) > 1)
+
+    def add(self, rows, tail=None):
+        """rows: (nrows, nt_chunk) partial sums of this rank; tail: (volo, masso0, area_sum)
+        partials, given with the first chunk."""
+        rows = rows.to(torch.float64).reshape(self.nrows, -1)
+        parts = [rows.reshape(-1)]
+        if tail is not None:
+            parts += [torch.as_tensor(v, dtype=torch.float64, device=rows.device).reshape(1)
+                      for v in tail]
+        vec = torch.cat(parts)
+        work = None
+        if self.active:
+            if vec.is_cuda and dist.get_backend(self.group) == "gloo":
+                host = vec.cpu()  # rehearsal on fewer GPUs than ranks: staged through the host
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                vec = host.to(vec.device)
+            else:
+                work = dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append((vec, work, rows.shape[1], tail is not None))
+
+    def finish(self):
+        """-> (rows (nrows, nt) tensor, volo, masso0, area_sum) of the whole grid."""
+        out, tail = [], None
+        for vec, work, ntc, has_tail in self._pending:
+            if work is not None:
+                work.wait()
+            n = self.nrows * ntc
+            out.append(vec[:n].reshape(self.nrows, ntc))
+            if has_tail:
+                tail = (vec[n], vec[n + 1], vec[n + 2])
+        self._pending = []
+        if tail is None:
+            raise RuntimeError("ChunkedExchange.finish(): the first chunk's tail was never added")
+        return (torch.cat(out, dim=1),) + tail
+
+
+def _chunk_source(source, device, steps):
+    """Normalise the record to an iterator of (t0, t1, T_chunk, S_chunk) device tensors.
+
+    ``source`` is either a pair ``(T, S)`` of (nt,nz,ny_t,nx_t) arrays -- device tensors are
+    sliced, host arrays uploaded chunk by chunk (engine.TimeChunks) -- or a tuple
+    ``(fetch, nt)`` with ``fetch(t0, t1) -> (T_chunk, S_chunk)`` device tensors, for records that
+    exist nowhere in full (bench.py generates chunks with core.synth_field(t0=...)).
+    """
+    first, second = source
+    if callable(first):
+        fetch, nt = first, int(second)
+        steps = nt if steps is None else max(1, min(int(steps), nt))
+
+        def walk():
+            for t0 in range(0, nt, steps):
+                t1 = min(t0 + steps, nt)
+                Tc, Sc = fetch(t0, t1)
+                yield t0, t1, Tc, Sc
+
+        return walk(), nt
+    chunks = engine.TimeChunks(first, second, device, steps=steps)
+    return iter(chunks), chunks.nt
+
+
+def steric_global_tile_streamed(source, vol0, areacello, pres, variants=("steric",), steps=None,
+                                eos="wright", f32_mode="faithful", group=None, validate_area=True,
+                                heat=False, skip_dry=None, events=None):
+    """Global steric of a horizontally tiled grid over a record of ANY length; call on every rank
+    with its tile.  The record is walked in time chunks (``steps`` per chunk): K1 -- the
+    all-variants kernel when more than one row is wanted -- runs on the chunk and its partial sums
+    go into one asynchronous all-reduce per chunk (ChunkedExchange), overlapping the next chunk's
+    kernels; ``[volo, masso0, sum(areacello)]`` ride in the first.  The reference state is time
+    index 0 of the record, as setup_reference_state builds it.
+
+    source: ``(T, S)`` arrays of this rank's tile or ``(fetch, nt)``, see _chunk_source.
+    vol0 (nz,ny_t,nx_t): reference volcello; areacello (ny_t,nx_t).  ``heat``: also the
+    ocean-heat-content integrand sum(theta*vol0) (extension).  ``events``: list that receives a
+    (start, end) torch.cuda.Event pair per chunk around its K1 launch (bench.py).
+    Returns {variant: finalize() dict} (+ "heat": (nt,) numpy, summed over the whole grid).
+    """
+    from . import core
+
+    variants = tuple(variants)
+    for v in variants:
+        if v not in _VARIANTS:
+            raise ValueError(f"Unknown variant '{v}' passed to `steric`")
+    dev = engine.device_of(vol0) if engine._is_device(vol0) else engine.device_of()
+    vol0 = engine.to_device(vol0, dev, torch.float64)
+    if not engine.time_dependent(pres):
+        pres = engine.to_device(pres, dev, torch.float64)
+    one_pass = len(variants) > 1 or heat
+    names = list(variants) + (["heat"] if heat else [])
+    walker, nt = _chunk_source(source, dev, steps)
+    exchange = ChunkedExchange(len(names), group=group)
+    T0 = S0 = None
+    for t0, t1, Tc, Sc in walker:
+        first = T0 is None
+        if first:  # reference state = time level 0 of the record (cloned: chunks may be reused)
+            T0, S0 = Tc[0].clone(), Sc[0].clone()
+        pc = engine.pressure_chunk(pres, t0, t1, dev)
+        ev = None
+        if events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            events.append(ev)
+        if one_pass:
+            rows = core.steric_global_decomp(Tc, Sc, T0, S0, vol0, pc, eos=eos, f32_mode=f32_mode,
+                                             skip_dry=skip_dry, events=ev)
+            rows = torch.stack([rows[core.DECOMP_ROWS.index(v)] for v in names])
+        else:
+            Tv, Sv = engine._variant_operands(variants[0], Tc, Sc, T0, S0)
+            rows = core.steric_global_masso(Tv, Sv, vol0, pc, eos=eos, f32_mode=f32_mode,
+                                            skip_dry=skip_dry, events=ev).reshape(1, -1)
+        tail = None
+        if first:
+            # masso0 = masso(t=0) of this very launch: every variant sees (theta0, S0) there, the
+            # same kernel, tiling and operands -> steric[t=0] == 0 exactly, for any world size
+            area = core.nansum(engine.to_device(areacello, dev, torch.float64))
+            tail = (core.nansum(vol0), rows[0, 0], area)
+        exchange.add(rows, tail)
+    rows, volo, masso0, area = exchange.finish()
+    out = {}
+    for i, v in enumerate(names):
+        if v == "heat":
+            out[v] = rows[i].detach().cpu().numpy()
+        else:
+            out[v] = finalize(rows[i], volo, masso0, area)
+    if validate_area and variants:  # util.validate_areacello on the GLOBAL sum, not the tile's
+        err = (out[variants[0]]["area_sum"] - 3.6111092e14) / 3.6111092e14
+        if not abs(err) < 0.02:
+            raise ValueError("Errors found in dataset.")
+    return out
+
+
 def steric_global_tile(T, S, vol0, areacello, pres, variant="steric", eos="wright",
-                       f32_mode="faithful", group=None, validate_area=True):
-    """Global steric of a horizontally tiled grid; call on every rank with its tile.
+                       f32_mode="faithful", group=None, validate_area=True, steps=None):
+    """Global steric of a horizontally tiled grid, device-resident record; call on every rank
+    with its tile.  ``steps=None``: the whole record in one K1 launch and one all-reduce;
+    otherwise time chunks of ``steps`` (steric_global_tile_streamed).
 
     T, S: (nt,nz,ny_t,nx_t) device tensors of this rank's tile; vol0 (nz,ny_t,nx_t) the
     reference volcello (time index 0); areacello (ny_t,nx_t).  The reference state is
     time index 0 of (T, S), as setup_reference_state builds it.
     """
-    from . import core
-
-    if variant == "thermosteric":
-        Tv, Sv = T, S[0]
-    elif variant == "halosteric":
-        Tv, Sv = T[0], S
-    elif variant == "steric":
-        Tv, Sv = T, S
-    else:
+    if variant not in _VARIANTS:
         raise ValueError(f"Unknown variant '{variant}' passed to `steric`")
-    _rho0, volo, _ = engine.reference_state(T[0], S[0], vol0, pres, eos=eos, f32_mode=f32_mode,
-                                            with_masso=False, with_rho=False)
-    masso = engine.global_masso(Tv, Sv, vol0, pres, eos=eos, f32_mode=f32_mode)
-    masso0 = masso[0]  # the reference slab is step 0 of this record: same launch, same bits
-    area = core.nansum(engine.to_device(areacello, masso.device, torch.float64))
-    masso, volo, masso0, area = exchange_global(masso, volo, masso0, area, group=group)
-    out = finalize(masso, volo, masso0, area)
-    if validate_area:  # util.validate_areacello on the GLOBAL sum, not the tile's
-        err = (out["area_sum"] - 3.6111092e14) / 3.6111092e14
-        if not abs(err) < 0.02:
-            raise ValueError("Errors found in dataset.")
-    return out
+    return steric_global_tile_streamed((T, S), vol0, areacello, pres, variants=(variant,),
+                                       steps=steps, eos=eos, f32_mode=f32_mode, group=group,
+                                       validate_area=validate_area)[variant]
 
 
 def steric_local_tile(T, S, vol0, pres, z_i, deptho, rhozero=1035.0, variant="steric",

@@ -496,3 +496,95 @@ def test_stream_probe_adds():
     a = torch.rand(4096 * 6, dtype=torch.float64, device="cuda")
     b = torch.rand(4096 * 6, dtype=torch.float64, device="cuda")
     assert torch.equal(core.stream_probe(a, b), a + b)
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size launches (BASELINE.json configs[2] and configs[4]); memory is freed between them
+# ---------------------------------------------------------------------------------------------
+def _free_hbm():
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.timeout(1200)
+def test_config3_full_launch_every_time_chunk():
+    """The headline launch itself: 1440x1080x75, 120 steps resident (224 GB), ONE K1 launch of
+    4 time chunks (blockIdx.z) x 75 levels x 760 tiles.  A whole-grid time slab from EVERY chunk
+    -- first, interior and last steps -- is compared with the oracle; round 1 only checked chunk 0
+    at this size (VERDICT r1 weak #5)."""
+    _free_hbm()
+    free, _ = torch.cuda.mem_get_info()
+    nt, nz, ny, nx = 120, 75, 1080, 1440
+    if free < 2 * nt * nz * ny * nx * 8 + (20 << 30):
+        pytest.skip("needs 244 GB of free HBM")
+    g, vol0, T, S, pres = make_case(nt, nz, ny, nx)
+    m = core.steric_global_masso(T, S, vol0, pres, skip_dry=False)
+    assert torch.equal(m, core.steric_global_masso(T, S, vol0, pres, skip_dry=True))
+    m = m.cpu().numpy()
+    for t in (0, 31, 45, 64, 95, 96, 119):  # chunks 0,0,1,2,2,3,3
+        rho = o.calc_rho(T[t].cpu().numpy(), S[t].cpu().numpy(), pres)
+        ref = o.calc_masso(rho, g["volcello"])
+        assert abs(m[t] - ref) <= 1e-12 * abs(ref), f"t={t}: {m[t]!r} vs {ref!r}"
+        del rho
+    # the chunked, tiled walk of the same record (what --gpus N runs) gives the same numbers
+    out = parallel.steric_global_tile_streamed((T, S), vol0, g["areacello"], pres, steps=50,
+                                               skip_dry=False)["steric"]
+    assert np.array_equal(out["masso"], m) and out["eta"][0] == 0.0
+    del T, S
+    _free_hbm()
+
+
+@pytest.mark.timeout(1200)
+def test_config5_f32_properties():
+    """BASELINE.json configs[4]: float32 theta/S at 0.25 degree, steric + thermosteric +
+    halosteric (+ heat content) from ONE pass.  Size-independent properties on the full grid plus an
+    oracle check of one whole time slab per variant, in numpy's float32 mixed precision."""
+    _free_hbm()
+    nt, nz, ny, nx = 8, 75, 1080, 1440
+    g, vol0, T, S, pres = make_case(nt, nz, ny, nx, dtype=torch.float32)
+    rows = core.steric_global_decomp(T, S, T[0], S[0], vol0, pres)
+    # determinism; dry-line skipping changes nothing
+    assert torch.equal(rows, core.steric_global_decomp(T, S, T[0], S[0], vol0, pres))
+    assert torch.equal(rows, core.steric_global_decomp(T, S, T[0], S[0], vol0, pres, skip_dry=False))
+    # one pass == three launches, bit for bit; masso0 == masso(t=0) for all three variants
+    assert torch.equal(rows[0], core.steric_global_masso(T, S, vol0, pres))
+    assert torch.equal(rows[1], core.steric_global_masso(T, S[0], vol0, pres))
+    assert torch.equal(rows[2], core.steric_global_masso(T[0], S, vol0, pres))
+    _rho0, volo, masso0 = engine.reference_state(T[0], S[0], vol0, pres)
+    assert rows[0, 0].item() == rows[1, 0].item() == rows[2, 0].item() == masso0.item()
+    # linearity in vol0 (power of two: exact)
+    assert torch.equal(core.steric_global_decomp(T, S, T[0], S[0], vol0 * 4.0, pres), rows * 4.0)
+    rows = rows.cpu().numpy()
+    # oracle, one whole slab (t=5): numpy on float32 arrays = the reference's arithmetic
+    t = 5
+    Tn, Sn, T0n, S0n = (x.cpu().numpy() for x in (T[t], S[t], T[0], S[0]))
+    assert Tn.dtype == np.float32
+    for row, (a, b) in zip(rows[:3], [(Tn, Sn), (Tn, S0n), (T0n, Sn)]):
+        ref = o.calc_masso(o.calc_rho(a, b, pres), g["volcello"])
+        assert abs(row[t] - ref) <= 1e-12 * abs(ref)
+    heat = np.nansum(Tn.astype(np.float64) * g["volcello"])
+    assert abs(rows[3][t] - heat) <= 1e-12 * abs(heat)
+    # the tolerance study in one line each: upcast and fused arithmetic vs the faithful result
+    up = core.steric_global_decomp(T, S, T[0], S[0], vol0, pres, f32_mode="upcast").cpu().numpy()
+    fu = core.steric_global_decomp(T, S, T[0], S[0], vol0, pres, arith="fused").cpu().numpy()
+    assert np.max(np.abs(up[:3] - rows[:3]) / rows[:3]) < 2e-7   # float32 polynomial rounding
+    assert np.max(np.abs(fu[:3] - up[:3]) / up[:3]) < 1e-12      # fused == upcast to ~1e-15
+    assert np.array_equal(fu[3], rows[3]) and np.array_equal(up[3], rows[3])
+    # local variant on a 135-row band of one step, float32, vs the oracle (bit-exact)
+    y0, y1 = 400, 535
+    rho0m = core.fold_mask(core.eos_map(T[0], S[0], pres), vol0)
+    for a, b, an, bn in [(T[t:t + 1], S[0], Tn, S0n), (T[0], S[t:t + 1], T0n, Sn)]:
+        drho, eta = core.steric_local(a, b, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=g["z_i"],
+                                      deptho=g["deptho"])
+        vn = g["volcello"][:, y0:y1]
+        rho = o.calc_rho(an[:, y0:y1], bn[:, y0:y1], pres)
+        rho0n = o.calc_rho(T0n[:, y0:y1], S0n[:, y0:y1], pres)
+        d = np.where(~np.isnan(vn), rho - rho0n, np.nan)
+        assert_bit_equal(drho[0, :, y0:y1].cpu().numpy(), d, "f32 band delta_rho")
+        dz = o.calc_dz(g["z_l"], g["z_i"], g["deptho"][y0:y1])
+        e = np.where(~np.isnan(vn[0]), (-1.0 / 1035.0) * np.nansum(dz * d, axis=0), np.nan)
+        assert_bit_equal(eta[0, y0:y1].cpu().numpy(), e, "f32 band eta")
+    del T, S
+    _free_hbm()

@@ -51,6 +51,38 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _tile_rows(g, T, S, rank, world):
+    """oracle partial sums of this rank's tile for steric / thermosteric / halosteric + heat"""
+    y0, y1, x0, x1 = synthetic.tile_bounds(NY, NX, rank, world)
+    pres = o.pressure_from_depth(g["z_l"])
+    vol = g["volcello"][:, y0:y1, x0:x1]
+    Tt, St = T[:, :, y0:y1, x0:x1], S[:, :, y0:y1, x0:x1]
+    rows = [o.calc_masso(o.calc_rho(a, b, pres) * np.ones_like(Tt), vol)
+            for a, b in ((Tt, St), (Tt, St[0]), (Tt[0], St))]
+    rows.append(np.nansum(Tt * vol, axis=(1, 2, 3)))
+    return np.stack(rows), np.nansum(vol), np.nansum(g["areacello"][y0:y1, x0:x1])
+
+
+def _chunked_worker(rank, world, port, q):
+    """ChunkedExchange: three time chunks (2+1+1 steps), four rows, the tail in the first chunk"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel.init_from_env(backend="gloo")
+    g, T, S = _case()
+    rows, volo, area = _tile_rows(g, T, S, rank, world)
+    ex = parallel.ChunkedExchange(4)
+    assert ex.active
+    for t0, t1 in ((0, 2), (2, 3), (3, 4)):
+        tail = (volo, rows[0, 0], area) if t0 == 0 else None
+        ex.add(torch.from_numpy(np.ascontiguousarray(rows[:, t0:t1])), tail)
+    red, volo_g, masso0_g, area_g = ex.finish()
+    outs = [parallel.finalize(red[i], volo_g, masso0_g, area_g) for i in range(3)]
+    q.put((rank, [o_["eta"] for o_ in outs], [o_["masso"] for o_ in outs], red[3].numpy(),
+           outs[0]["volo"], outs[0]["area_sum"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -88,3 +120,46 @@ def test_exchange_is_identity_without_a_process_group():
     masso = torch.arange(5, dtype=torch.float64)
     m2, v, m0, a = parallel.exchange_global(masso, 2.0, 3.0, 4.0)
     assert torch.equal(m2, masso) and (v.item(), m0.item(), a.item()) == (2.0, 3.0, 4.0)
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_chunked_exchange_all_variants():
+    """one all-reduce per time chunk, several rows per chunk: result == the single
+    domain for every variant, eta[0] == 0 exactly, ranks bit-identical"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chunked_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    g, T, S = _case()
+    vol4 = np.broadcast_to(g["volcello"], T.shape).copy()
+    for i, variant in enumerate(("steric", "thermosteric", "halosteric")):
+        ref, refstate = o.steric(T, S, vol4, g["areacello"], g["z_l"], domain="global",
+                                 variant=variant)
+        for rank, etas, massos, heat, volo, area in results:
+            assert etas[i][0] == 0.0
+            assert np.allclose(massos[i], ref["masso"], rtol=1e-13, atol=0)
+            href = volo / area
+            assert np.allclose(etas[i] / href, ref["expansion_coeff"], rtol=0, atol=1e-12)
+        assert np.array_equal(results[0][1][i], results[1][1][i])
+    heat = o.ocean_heat_content(T, g["volcello"], 1.0, 1.0)
+    assert np.allclose(results[0][3], heat, rtol=1e-13, atol=0)
+    assert np.array_equal(results[0][3], results[1][3])
+
+
+def test_chunked_exchange_without_a_process_group():
+    ex = parallel.ChunkedExchange(2)
+    assert not ex.active
+    ex.add(torch.tensor([[1.0, 2.0], [10.0, 20.0]], dtype=torch.float64), (5.0, 1.0, 7.0))
+    ex.add(torch.tensor([[3.0], [30.0]], dtype=torch.float64))
+    rows, volo, masso0, area = ex.finish()
+    assert rows.tolist() == [[1.0, 2.0, 3.0], [10.0, 20.0, 30.0]]
+    assert (volo.item(), masso0.item(), area.item()) == (5.0, 1.0, 7.0)
+    with pytest.raises(RuntimeError):
+        parallel.ChunkedExchange(1).finish()
