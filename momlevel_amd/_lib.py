@@ -9,7 +9,9 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmomlevel_hip.so")
+# MOMLEVEL_AMD_LIB: bind another build of the SAME library (scripts/sanitize_host.py points it at
+# the host-sanitized build); the default is the in-tree libmomlevel_hip.so
+LIB_PATH = os.environ.get("MOMLEVEL_AMD_LIB") or os.path.join(HERE, "libmomlevel_hip.so")
 
 # ---- constants mirrored from include/momlevel_hip.h --------------------------------
 ABI_VERSION = 2

@@ -11,7 +11,7 @@ import functools
 
 import numpy as np
 
-from .labeled import DataArray, Dataset
+from .labeled import DataArray, Dataset, is_lazy
 
 try:  # optional
     import xarray as xr
@@ -27,6 +27,16 @@ def is_xarray(obj):
     return xr is not None and isinstance(obj, (xr.DataArray, xr.Dataset))
 
 
+def _raw(var):
+    """The array behind an xarray variable WITHOUT loading it: numpy stays numpy, a dask (or any
+    other lazily evaluated) array is handed on as it is -- the engine reads it one time chunk at a
+    time -- and only exotic wrappers fall back to ``.values``."""
+    data = var.data
+    if isinstance(data, np.ndarray) or is_lazy(data):
+        return data
+    return var.values
+
+
 def from_xarray(obj):
     """xarray.DataArray/Dataset -> labelled DataArray/Dataset (data shared)."""
     if xr is None or not isinstance(obj, (xr.DataArray, xr.Dataset)):
@@ -36,8 +46,7 @@ def from_xarray(obj):
             str(k): DataArray(v.values, tuple(map(str, v.dims)), None, dict(v.attrs), str(k))
             for k, v in obj.coords.items()
         }
-        out = DataArray(obj.data if isinstance(obj.data, np.ndarray) else obj.values,
-                        tuple(map(str, obj.dims)), coords, dict(obj.attrs), obj.name)
+        out = DataArray(_raw(obj), tuple(map(str, obj.dims)), coords, dict(obj.attrs), obj.name)
         out.encoding = dict(obj.encoding)
         return out
     out = Dataset(attrs=dict(obj.attrs))
@@ -45,8 +54,7 @@ def from_xarray(obj):
         out._set(str(k), DataArray(v.values, tuple(map(str, v.dims)), None, dict(v.attrs)),
                  is_coord=True)
     for k, v in obj.data_vars.items():
-        da = DataArray(v.data if isinstance(v.data, np.ndarray) else v.values,
-                       tuple(map(str, v.dims)), None, dict(v.attrs))
+        da = DataArray(_raw(v), tuple(map(str, v.dims)), None, dict(v.attrs))
         da.encoding = dict(v.encoding)
         out[str(k)] = da
     return out

@@ -743,7 +743,18 @@ int hip_status(hipError_t e, const char* what) {
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
-inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int64_t ceil_div(int64_t a, int64_t b) { return a / b + (a % b != 0); }  // a >= 0, b > 0
+
+// overflow-checked product of non-negative extents; false when it does not fit (or tops `limit`)
+inline bool mul_fits(int64_t a, int64_t b, int64_t* out, int64_t limit = INT64_MAX / 16) {
+  return !__builtin_mul_overflow(a, b, out) && *out >= 0 && *out <= limit;
+}
+
+// total element count nt*nz*plane of a 4-D field must be addressable (and its byte size fit int64)
+inline bool extents_fit(int64_t nt, int64_t nz, int64_t plane) {
+  int64_t n3, n4;
+  return mul_fits(nz, plane, &n3) && mul_fits(nt, n3, &n4);
+}
 
 // cells a K1 block covers within one z level
 constexpr int kU64 = 4, kVec64 = 2;  // 8 cells/thread, 2048 cells/block (fast f64)
@@ -780,7 +791,12 @@ int check_common(const void* T, const void* S, int dtype, const double* p, int p
   if (nz > 65535) return fail(MLX_E_SHAPE, "nz must be <= 65535");
   if (nt > 2147483647LL) return fail(MLX_E_SHAPE, "nt too large");
   if (plane > (int64_t)1 << 40) return fail(MLX_E_SHAPE, "plane too large");
+  if (!extents_fit(nt, nz, plane)) return fail(MLX_E_SHAPE, "nt*nz*plane overflows");
   if (sT < 0 || sS < 0) return fail(MLX_E_SHAPE, "time strides must be >= 0");
+  {  // the last time step must be addressable: (nt-1)*stride + nz*plane
+    int64_t span;
+    if (!mul_fits(nt - 1, sT > sS ? sT : sS, &span)) return fail(MLX_E_SHAPE, "time stride too large");
+  }
   const size_t es = (dtype == MLX_DTYPE_F64) ? 8 : 4;
   if (!aligned(T, es) || !aligned(S, es)) return fail(MLX_E_ALIGN, "T/S not element-aligned");
   if (p && !aligned(p, 8)) return fail(MLX_E_ALIGN, "p not 8-byte aligned");
@@ -1065,8 +1081,10 @@ int mlx_inverse_barometer(const void* T, const void* S, int dtype, const double*
 size_t mlx_steric_global_workspace_bytes(int64_t nt, int64_t nz, int64_t plane) {
   if (nt <= 0 || nz <= 0 || plane <= 0) return 0;
   // the generic path has the smaller tile, hence the larger block count: size for it
-  const int64_t nblk = ceil_div(plane, (int64_t)kBlock * kUGen) * nz;
-  return (size_t)(nt * nblk) * sizeof(double);
+  int64_t nblk, n;
+  if (!mul_fits(ceil_div(plane, (int64_t)kBlock * kUGen), nz, &nblk) || !mul_fits(nt, nblk, &n))
+    return 0;  // such a grid is rejected by the entry points (MLX_E_SHAPE)
+  return (size_t)n * sizeof(double);
 }
 
 size_t mlx_steric_global_decomp_workspace_bytes(int64_t nt, int64_t nz, int64_t plane) {
@@ -1251,13 +1269,20 @@ int mlx_synth_field(void* out, int dtype, int64_t nt, int64_t nz, int64_t ny, in
                     int field_id, double lo, double scale, const double* mask3d, void* stream) {
   if (!out) return fail(MLX_E_NULL, "out must not be NULL");
   if (nt <= 0 || nz <= 0 || ny <= 0 || nx <= 0) return fail(MLX_E_SHAPE, "dims must be > 0");
-  if (y0 < 0 || x0 < 0 || t0 < 0 || y0 + ny > NY || x0 + nx > NX)
+  if (y0 < 0 || x0 < 0 || t0 < 0 || NY <= 0 || NX <= 0 || ny > NY || nx > NX || y0 > NY - ny ||
+      x0 > NX - nx)
     return fail(MLX_E_SHAPE, "tile does not fit the global grid");
+  {  // the global cell counter ((t0+nt)*nz*NY*NX) must fit 63 bits
+    int64_t a, b, c;
+    if (t0 > INT64_MAX - nt || !mul_fits(t0 + nt, nz, &a) || !mul_fits(a, NY, &b) ||
+        !mul_fits(b, NX, &c))
+      return fail(MLX_E_SHAPE, "global index overflows");
+  }
   if (field_id < 0 || field_id > 15) return fail(MLX_E_ENUM, "field_id must be 0..15");
   if (int rc = check_dtype(dtype)) return rc;
   if (!aligned(out, dtype == MLX_DTYPE_F64 ? 8 : 4) || (mask3d && !aligned(mask3d, 8)))
     return fail(MLX_E_ALIGN, "out/mask3d not element-aligned");
-  const int64_t n = nt * nz * ny * nx;
+  const int64_t n = nt * nz * ny * nx;  // <= the global counter checked above
   const int64_t want = ceil_div(n, kBlock);
   dim3 grid((unsigned)(want < 16384 ? want : 16384));
   hipStream_t st = (hipStream_t)stream;

@@ -45,7 +45,7 @@ def to_device(x, device, dtype=None):
 
 def _stream_dtype(x):
     """float32 fields stay float32 in HBM (half the bytes); everything else -> float64."""
-    dt = x.dtype if isinstance(x, torch.Tensor) else np.asarray(x).dtype
+    dt = x.dtype if hasattr(x, "dtype") else np.asarray(x).dtype  # never reads a lazy array
     if str(dt) in ("torch.float32", "float32"):
         return torch.float32
     return torch.float64
@@ -76,7 +76,9 @@ def _host_tensor(a, dtype=None):
 class TimeChunks:
     """Iterate a (nt, nz, ny, nx) field pair in device-resident time chunks.
 
-    Device-resident fields are sliced (no copy).  Host (numpy) fields are copied chunk by chunk
+    Device-resident fields are sliced (no copy).  Lazy fields (dask / netCDF4 / h5py / zarr
+    arrays, anything sliceable that is not numpy) are READ chunk by chunk -- ``np.asarray(f[t0:t1])``
+    -- so the host never holds more than the chunks in flight.  Host (numpy) fields are copied chunk by chunk
     straight from the caller's memory into a fresh device tensor -- no staging copy (a pageable
     hipMemcpy already runs at the PCIe Gen5 rate on the MI355X hosts, 56 GB/s measured; staging
     through a pinned buffer halved it).  The chunk's pages are page-locked in place

@@ -7,9 +7,14 @@ it is importable, ``momlevel_amd`` accepts and returns real ``xarray`` objects
 carry names, dims, coords, attrs and encoding but no arithmetic of their own
 beyond what input validation and the tests need.
 
-``DataArray.data`` is either a numpy array (host) or a torch tensor (device);
-``.values`` always gives numpy.  Nothing here is on the hot path: the 4-D fields
-are only ever *relabelled*; their numbers go through the HIP kernels.
+``DataArray.data`` is a numpy array (host), a torch tensor (device) or a LAZY array
+-- anything array-shaped that is not one of the two: a dask array, a netCDF4 / h5py /
+zarr variable -- which is kept as it is and only ever read slice by slice (the engine
+cuts time chunks out of it; momlevel's real inputs are dask-chunked float32 files,
+examples/example.ipynb cell 4).  ``.values`` always gives numpy -- for a lazy array
+that reads ALL of it, so nothing on the steric path calls it on a 4-D field.
+Nothing here is on the hot path: the 4-D fields are only ever *relabelled*; their
+numbers go through the HIP kernels.
 """
 
 import numpy as np
@@ -24,10 +29,49 @@ def _is_tensor(x):
     return torch is not None and isinstance(x, torch.Tensor)
 
 
+def is_lazy(x):
+    """An array-shaped object that is neither numpy nor torch: left unread until sliced."""
+    if _is_tensor(x) or isinstance(x, (np.ndarray, np.generic, list, tuple, int, float, bool)):
+        return False
+    return all(hasattr(x, a) for a in ("shape", "dtype", "__getitem__"))
+
+
 def _to_numpy(x):
     if _is_tensor(x):
         return x.detach().cpu().numpy()
+    if is_lazy(x):
+        return np.asarray(x[...])  # reads all of it
     return np.asarray(x)
+
+
+class LazyTranspose:
+    """A transposed view of a lazy array that stays lazy: indexing the leading axes of the VIEW
+    reads just that part of the base and transposes it in memory."""
+
+    def __init__(self, base, perm):
+        self.base, self.perm = base, tuple(perm)
+        self.shape = tuple(base.shape[i] for i in self.perm)
+        self.dtype = base.dtype
+        self.ndim = len(self.shape)
+
+    def __getitem__(self, key):
+        if key is Ellipsis:
+            key = ()
+        if not isinstance(key, tuple):
+            key = (key,)
+        key = key + (slice(None),) * (self.ndim - len(key))
+        base_key = [slice(None)] * self.ndim
+        for view_axis, k in enumerate(key):
+            base_key[self.perm[view_axis]] = k
+        block = np.asarray(self.base[tuple(base_key)])
+        kept = [ax for ax, k in enumerate(key) if not isinstance(k, (int, np.integer))]
+        order = sorted(range(len(kept)), key=lambda i: self.perm[kept[i]])  # base order of kept axes
+        inv = [order.index(i) for i in range(len(kept))]
+        return block.transpose(inv)
+
+    def __array__(self, dtype=None, copy=None):
+        out = _to_numpy(self.base).transpose(self.perm)
+        return out.astype(dtype) if dtype is not None else out
 
 
 class DataArray:
@@ -41,9 +85,9 @@ class DataArray:
             coords = data.coords if coords is None else coords
             attrs = data.attrs if attrs is None else attrs
             data = data.data
-        if not _is_tensor(data):
+        if not _is_tensor(data) and not is_lazy(data):
             data = np.asarray(data)
-        ndim = data.dim() if _is_tensor(data) else data.ndim
+        ndim = len(data.shape)
         if dims is None:
             dims = tuple(f"dim_{i}" for i in range(ndim))
         if isinstance(dims, str):
@@ -73,9 +117,13 @@ class DataArray:
 
     @property
     def dtype(self):
-        return self.values.dtype if not _is_tensor(self.data) else np.dtype(
-            str(self.data.dtype).replace("torch.", "")
-        )
+        if _is_tensor(self.data):
+            return np.dtype(str(self.data.dtype).replace("torch.", ""))
+        return np.dtype(self.data.dtype)
+
+    @property
+    def is_lazy(self):
+        return is_lazy(self.data)
 
     @property
     def sizes(self):
@@ -113,7 +161,7 @@ class DataArray:
 
     def copy(self, deep=True):
         data = self.data
-        if deep:
+        if deep and not is_lazy(data):
             data = data.clone() if _is_tensor(data) else np.array(data)
         out = DataArray(data, self.dims, self.coords, self.attrs, self.name)
         out.encoding = dict(self.encoding)
@@ -128,6 +176,8 @@ class DataArray:
         key = key + (slice(None),) * (self.ndim - len(key))
         dims = tuple(d for d, k in zip(self.dims, key) if not isinstance(k, (int, np.integer)))
         data = self.data[key]
+        if is_lazy(data) and len(dims) < self.ndim:
+            data = np.asarray(data)  # a slab picked out of a lazy field (the reference state)
         out = self._like(data, dims, keep_attrs=True)
         for d, k in zip(self.dims, key):
             if d in out.coords and not isinstance(k, (int, np.integer)):
@@ -145,7 +195,10 @@ class DataArray:
 
     def squeeze(self):
         keep = [i for i, n in enumerate(self.shape) if n != 1]
-        data = self.data.reshape([self.shape[i] for i in keep])
+        if len(keep) == self.ndim:
+            return self
+        data = self.data if not is_lazy(self.data) else np.asarray(self.data)
+        data = data.reshape([self.shape[i] for i in keep])
         return self._like(data, tuple(self.dims[i] for i in keep), keep_attrs=True)
 
     def reset_coords(self, drop=True):
@@ -164,7 +217,12 @@ class DataArray:
         if tuple(dims) == self.dims:
             return self
         perm = [self.dims.index(d) for d in dims]
-        data = self.data.permute(*perm) if _is_tensor(self.data) else self.data.transpose(perm)
+        if _is_tensor(self.data):
+            data = self.data.permute(*perm)
+        elif is_lazy(self.data):
+            data = LazyTranspose(self.data, perm)
+        else:
+            data = self.data.transpose(perm)
         out = self._like(data, tuple(dims), keep_attrs=True)
         out.encoding = dict(self.encoding)
         return out

@@ -1,0 +1,24 @@
+"""A duck-typed LAZY array for the tests: array-shaped, not numpy, readable only by slicing --
+what a dask array or a netCDF4 / h5py variable looks like to momlevel_amd -- that records every
+read, so a test can assert that a 4-D field is never materialised beyond one time chunk."""
+
+import numpy as np
+
+
+class CountingLazy:
+    def __init__(self, array):
+        self._a = array
+        self.shape, self.dtype, self.ndim = array.shape, array.dtype, array.ndim
+        self.reads = []  # bytes of every slice that was materialised
+
+    def __getitem__(self, key):
+        block = self._a[key]
+        self.reads.append(int(np.asarray(block).nbytes))
+        return np.array(block)
+
+    def __len__(self):
+        return self.shape[0]
+
+    @property
+    def largest_read(self):
+        return max(self.reads) if self.reads else 0

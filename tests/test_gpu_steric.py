@@ -498,6 +498,37 @@ def test_fused_arithmetic_through_the_public_api(monkeypatch):
         assert np.allclose(gres[variant].values / h, ogres["expansion_coeff"], rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("domain", ["local", "global"])
+@pytest.mark.parametrize("order", [("time", "z_l", "yh", "xh"), ("time", "yh", "xh", "z_l")])
+def test_lazy_inputs_are_read_one_time_chunk_at_a_time(domain, order, monkeypatch):
+    """momlevel's real inputs are dask-chunked float32 files (examples/example.ipynb cell 4).  A
+    lazy theta/S/volcello (tests/lazy_array.py counts every read) goes through steric() without
+    EVER being materialised whole: reads are the reference slab and one time chunk at a time, also
+    when the dims need a transpose; results equal the numpy-backed run bit for bit."""
+    from lazy_array import CountingLazy
+    from momlevel_amd import engine
+
+    d = _masked_dataset(nt=7, dtype=np.float32)
+    base, bref = steric(d, domain=domain)
+    lazies = {}
+    dl = d.copy()
+    for k in ("thetao", "so", "volcello"):
+        arr = d[k].transpose(*order).values
+        lazies[k] = CountingLazy(np.ascontiguousarray(arr))
+        dl[k] = DataArray(lazies[k], order)
+    monkeypatch.setattr(engine, "chunk_steps", lambda nt, b, dev, budget_bytes=None: 2)
+    res, ref = steric(dl, domain=domain)
+    step_bytes = d["thetao"].values[0].nbytes
+    for k in ("thetao", "so"):
+        assert lazies[k].largest_read <= 2 * step_bytes, (k, lazies[k].reads)
+        assert sum(lazies[k].reads) <= (7 + 2) * step_bytes  # every step once + the reference slab
+    assert lazies["volcello"].largest_read <= d["volcello"].values[0].nbytes
+    assert_bit_equal(res["steric"].values, base["steric"].values, "lazy vs numpy inputs")
+    if domain == "local":
+        assert_bit_equal(res["delta_rho"].values, base["delta_rho"].values)
+    assert_bit_equal(ref["rho"].transpose(*bref["rho"].dims).values, bref["rho"].values)
+
+
 def test_delta_rho_can_be_elided(monkeypatch):
     d = _masked_dataset()
     base, _ = steric(d)

@@ -251,3 +251,25 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+
+
+def test_lazy_arrays_stay_lazy_in_the_labelled_layer():
+    """dask-like inputs (VERDICT r1 missing #4): relabelling, transposing and picking the
+    reference slab never read the whole 4-D field; only slicing does"""
+    from lazy_array import CountingLazy
+    from momlevel_amd.labeled import DataArray, is_lazy
+
+    a = np.arange(6 * 3 * 4 * 5, dtype=np.float32).reshape(6, 3, 4, 5)
+    lazy = CountingLazy(a)
+    assert is_lazy(lazy) and not is_lazy(a) and not is_lazy([1.0, 2.0])
+    da = DataArray(lazy, ("time", "z_l", "yh", "xh"))
+    assert da.is_lazy and da.shape == a.shape and da.dtype == np.float32 and lazy.reads == []
+    assert da.transpose("time", "z_l", "yh", "xh").data is lazy
+    moved = da.transpose("time", "yh", "z_l", "xh")
+    assert moved.is_lazy and moved.shape == (6, 4, 3, 5) and lazy.reads == []
+    assert np.array_equal(moved.data[2:4], a.transpose(0, 2, 1, 3)[2:4])
+    assert lazy.largest_read == 2 * 3 * 4 * 5 * 4
+    slab = da.isel({"time": 0}).squeeze().reset_coords(drop=True)
+    assert not slab.is_lazy and np.array_equal(slab.values, a[0])
+    assert lazy.largest_read == 2 * 3 * 4 * 5 * 4  # still: nothing larger than the 2-step chunk
+    assert np.array_equal(da.values, a)  # an explicit .values reads everything -- by request
