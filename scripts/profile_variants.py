@@ -1,6 +1,6 @@
 """Run every hot kernel a few times on resident synthetic data -- the command profiled with
-rocprofv3 for the per-kernel evidence under profiles/ (K1 steric / thermosteric / halosteric,
-K2 with and without delta_rho, K0).
+rocprofv3 for the per-kernel evidence under profiles/ (K1 steric / thermosteric / halosteric in
+exact and fused arithmetic, the one-pass all-variants kernel, K2 with and without delta_rho).
 
     python scripts/profile_variants.py [--nt 40] [--reps 3]
 """
@@ -22,6 +22,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nt", type=int, default=40)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--plan-out", default=None,
+                    help="write the launch plan (case -> kernel, launches) for summarize_variants.py")
     a = ap.parse_args()
     nz, ny, nx = 75, 1080, 1440
     nt = a.nt
@@ -30,8 +33,9 @@ def main():
     pres = torch.from_numpy(np.asarray(g["z_l"]) * 1.0e4 + 101325.0).cuda()
     shape = (nt, nz, ny, nx)
     kw = dict(seed=synthetic.SEED, mask3d=vol0)
-    T = core.synth_field(shape, field_id=1, lo=-2.0, scale=34.0, **kw)
-    S = core.synth_field(shape, field_id=2, lo=30.0, scale=10.0, **kw)
+    td = torch.float32 if a.dtype == "f32" else torch.float64
+    T = core.synth_field(shape, td, field_id=1, lo=-2.0, scale=34.0, **kw)
+    S = core.synth_field(shape, td, field_id=2, lo=30.0, scale=10.0, **kw)
     rho0 = core.eos_map(T[0], S[0], pres)
     rho0m = core.fold_mask(rho0, vol0)
     zi = torch.from_numpy(g["z_i"]).cuda()
@@ -40,23 +44,41 @@ def main():
     eta = torch.empty((nt, ny, nx), dtype=torch.float64, device="cuda")
     rho = drho  # K0 output buffer (same size)
     cells = nt * nz * ny * nx
+    k1 = lambda a, b, **kw: core.steric_global_masso(a, b, vol0, pres, skip_dry=False, **kw)  # noqa: E731
+    dec = lambda **kw: core.steric_global_decomp(T, S, T[0], S[0], vol0, pres, skip_dry=False, **kw)  # noqa: E731
+
+    def k2(want, skip=False, **kw):
+        return core.steric_local(T, S, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=zi, deptho=dep,
+                                 want_delta_rho=want, delta_rho_out=drho if want else None,
+                                 eta_out=eta, skip_dry=skip, **kw)
+
+    B = T.element_size()
     cases = [
-        ("K1 steric", 16, lambda: core.steric_global_masso(T, S, vol0, pres, skip_dry=False)),
-        ("K1 thermosteric", 8, lambda: core.steric_global_masso(T, S[0], vol0, pres, skip_dry=False)),
-        ("K1 halosteric", 8, lambda: core.steric_global_masso(T[0], S, vol0, pres, skip_dry=False)),
-        ("K2 local eta only", 16, lambda: core.steric_local(
-            T, S, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=zi, deptho=dep,
-            want_delta_rho=False, eta_out=eta, skip_dry=False)),
-        ("K2 local + delta_rho", 24, lambda: core.steric_local(
-            T, S, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=zi, deptho=dep,
-            delta_rho_out=drho, eta_out=eta, skip_dry=False)),
-        ("K1 steric, dry lines skipped", 16,
+        ("K1 steric", 2 * B, "k_steric_global", lambda: k1(T, S)),
+        ("K1 thermosteric", B, "k_steric_global", lambda: k1(T, S[0])),
+        ("K1 halosteric", B, "k_steric_global", lambda: k1(T[0], S)),
+        ("K1 steric, fused arithmetic", 2 * B, "k_steric_global", lambda: k1(T, S, arith="fused")),
+        ("K1 thermosteric, fused arithmetic", B, "k_steric_global",
+         lambda: k1(T, S[0], arith="fused")),
+        ("K1 halosteric, fused arithmetic", B, "k_steric_global",
+         lambda: k1(T[0], S, arith="fused")),
+        ("K1 all variants + heat, one pass", 2 * B, "k_steric_global", lambda: dec()),
+        ("K1 all variants + heat, one pass, fused arithmetic", 2 * B, "k_steric_global",
+         lambda: dec(arith="fused")),
+        ("K2 local eta only", 2 * B, "k_steric_local", lambda: k2(False)),
+        ("K2 local + delta_rho", 2 * B + 8, "k_steric_local", lambda: k2(True)),
+        ("K1 steric, dry lines skipped", 2 * B, "k_steric_global",
          lambda: core.steric_global_masso(T, S, vol0, pres, skip_dry=True)),
-        ("K2 local + delta_rho, dry lines skipped", 24, lambda: core.steric_local(
-            T, S, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=zi, deptho=dep,
-            delta_rho_out=drho, eta_out=eta, skip_dry=True)),
+        ("K2 local + delta_rho, dry lines skipped", 2 * B + 8, "k_steric_local",
+         lambda: k2(True, skip=True)),
     ]
-    for name, bpc, fn in cases:
+    if a.plan_out:
+        with open(a.plan_out, "w") as f:
+            json.dump({"grid": [nx, ny, nz], "nt": nt, "dtype": a.dtype, "cells_per_launch": cells,
+                       "cases": [{"case": c[0], "algorithmic_bytes_per_cell": c[1],
+                                  "kernel": c[2], "launches": a.reps + 1} for c in cases]}, f,
+                      indent=1)
+    for name, bpc, _kernel, fn in cases:
         fn()
         torch.cuda.synchronize()
         ms = []

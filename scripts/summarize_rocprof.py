@@ -69,7 +69,7 @@ def main(src, prefix, kernel="k_steric_global"):
         summary["hbm_write_bytes_per_launch"] = write
         summary["hbm_traffic_bytes_per_launch"] = fetch + write
     # the bench line printed by the profiled command (same workload as the committed BENCH line)
-    for log in ("bench_trace.log", "bench_pmc_fetch.log"):
+    for log in ("bench_trace.log", "bench_pmc_fetch.log", "bench_pmc_write.log"):
         path = os.path.join(src, log)
         if os.path.exists(path):
             for line in open(path):
@@ -83,6 +83,16 @@ def main(src, prefix, kernel="k_steric_global"):
     if "hbm_traffic_bytes_per_launch" in summary and "cells_per_launch" in summary:
         summary["hbm_traffic_bytes_per_cell"] = (
             summary["hbm_traffic_bytes_per_launch"] / summary["cells_per_launch"])
+    # the sha bench.py compares against: a counter profile is quoted only for the sources it was
+    # taken on (bench.py kernel_source_sha)
+    import hashlib
+
+    h = hashlib.sha256()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for rel in ("momlevel_amd/csrc/momlevel_hip.hip", "momlevel_amd/csrc/eos_device.hpp"):
+        with open(os.path.join(root, rel), "rb") as f:
+            h.update(f.read())
+    summary["kernel_source_sha"] = h.hexdigest()[:16]
     json.dump(summary, open(prefix + "_summary.json", "w"), indent=1)
     print(json.dumps(summary, indent=1))
 
