@@ -12,15 +12,15 @@ B=gpurun_out/prof_${TAG}
 V=gpurun_out/prof_${TAG}v
 mkdir -p $B $V
 BENCH="python3 bench.py --steps 5 --warmup 1 --no-extras --cpu-seconds 0"
-echo "== bench: kernel trace + stats"; rocprofv3 --kernel-trace --stats -d $B/trace -o run -- $BENCH > $B/bench_trace.log 2>&1
-echo "== bench: FETCH_SIZE";           rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $B/pmc_fetch -o run -- $BENCH > $B/bench_pmc_fetch.log 2>&1
-echo "== bench: WRITE_SIZE";           rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $B/pmc_write -o run -- $BENCH > $B/bench_pmc_write.log 2>&1
+echo "== bench: kernel trace + stats"; rocprofv3 --output-format csv --kernel-trace --stats -d $B/trace -o run -- $BENCH > $B/bench_trace.log 2>&1
+echo "== bench: FETCH_SIZE";           rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $B/pmc_fetch -o run -- $BENCH > $B/bench_pmc_fetch.log 2>&1
+echo "== bench: WRITE_SIZE";           rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $B/pmc_write -o run -- $BENCH > $B/bench_pmc_write.log 2>&1
 VAR="python3 scripts/profile_variants.py --nt 40 --reps 2"
 echo "== variants: plain";             $VAR --plan-out $V/plan.json > $V/plain.log 2>&1
-echo "== variants: kernel trace";      rocprofv3 --kernel-trace --stats -d $V/trace -o run -- $VAR > $V/trace.log 2>&1
-echo "== variants: FETCH_SIZE";        rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $V/pmc_fetch -o run -- $VAR > $V/pmc_fetch.log 2>&1
-echo "== variants: WRITE_SIZE";        rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $V/pmc_write -o run -- $VAR > $V/pmc_write.log 2>&1
-echo "== variants: SQ";                rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -d $V/pmc_sq -o run -- $VAR > $V/pmc_sq.log 2>&1
+echo "== variants: kernel trace";      rocprofv3 --output-format csv --kernel-trace --stats -d $V/trace -o run -- $VAR > $V/trace.log 2>&1
+echo "== variants: FETCH_SIZE";        rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $V/pmc_fetch -o run -- $VAR > $V/pmc_fetch.log 2>&1
+echo "== variants: WRITE_SIZE";        rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $V/pmc_write -o run -- $VAR > $V/pmc_write.log 2>&1
+echo "== variants: SQ";                rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -d $V/pmc_sq -o run -- $VAR > $V/pmc_sq.log 2>&1
 # raw CSVs of the counter passes are large (one row per dispatch and counter): keep what the
 # summaries need
 find $B $V -name "*_agent_info.csv" -delete

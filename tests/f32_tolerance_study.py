@@ -1,6 +1,6 @@
 """BASELINE.json configs[4]: float32 tolerance study at the 0.25-degree grid (one MI355X).
 
-    python tests/f32_tolerance_study.py [--nt 120] > profiles/r01_f32_study.json
+    python tests/f32_tolerance_study.py [--nt 120] > profiles/r02_f32_study.json
 
 Real MOM6 output is float32 on disk.  The reference then computes in numpy's mixed precision
 (al0, p0, lam rounded in float32, the rest in float64 -- SURVEY.md 3.4 #7).  This script
@@ -10,8 +10,14 @@ Real MOM6 output is float32 on disk.  The reference then computes in numpy's mix
  (2) reports, on a sample of time slabs, the error of each interpretation against the
      float64 evaluation of the same (float32-representable) inputs, and checks the
      "faithful" mode against the oracle (numpy on float32 arrays) bit for bit.
-Ocean heat content (named in that config) has no reference implementation:
-parity unpinned, not built.
+ (3) round 2: the ONE-PASS decomposition (steric + thermosteric + halosteric + the heat-content
+     integrand from a single read of theta/S, mlx_steric_global_decomp) against the sum of the
+     three single-variant launches, for the three arithmetic interpretations (faithful, upcast,
+     fused = MLX_FLAG_FMA), and the spread of the resulting global sea-level / heat-content
+     numbers between interpretations.
+Ocean heat content (named in that config) has no reference implementation: it is
+an extension with its own numpy oracle line (oracle.momlevel_numpy.ocean_heat_content), PARITY
+UNPINNED.  The GPU test of this config is tests/test_gpu_kernels.py::test_config5_f32_properties.
 """
 
 import argparse
@@ -77,8 +83,44 @@ def main():
         "ms": round(ms, 3), "Mcells/s": round(cells / ms / 1e3, 1),
         "GB/s_algorithmic": round(8 * cells / ms / 1e6, 1), "bytes_per_cell": 8}
 
+    # ---- one pass vs three launches ------------------------------------------------------------
+    interpretations = (("faithful", dict(f32_mode="faithful", arith="exact")),
+                       ("upcast", dict(f32_mode="upcast", arith="exact")),
+                       ("fused", dict(f32_mode="upcast", arith="fused")))
+    rows = {}
+    for tag, kwv in interpretations:
+        ms1 = timed(lambda: core.steric_global_decomp(T, S, T[0], S[0], vol0, pres, **kwv))
+        ms3 = sum(timed(lambda: core.steric_global_masso(a_, b_, vol0, pres, **kwv))
+                  for a_, b_ in ((T, S), (T, S[0]), (T[0], S)))
+        rows[tag] = core.steric_global_decomp(T, S, T[0], S[0], vol0, pres, **kwv).cpu().numpy()
+        out["timings"][f"decomposition_one_pass_{tag}"] = {
+            "ms": round(ms1, 3), "Mcells/s": round(cells / ms1 / 1e3, 1),
+            "three_single_variant_launches_ms": round(ms3, 3),
+            "one_pass_speedup": round(ms3 / ms1, 3), "bytes_per_cell": 8}
+    # spread of the END RESULTS between interpretations: expansion coefficient ln(masso0/masso(t))
+    # of every variant (x reference height ~3.7 km = metres of sea level) and the heat integrand
+    def expansion(r):
+        return np.log(r[:3, :1] / r[:3])
+
+    ref = expansion(rows["upcast"])
+    out["errors"]["decomposition_expansion_coeff_max_abs_diff_vs_upcast"] = {
+        tag: float(np.max(np.abs(expansion(rows[tag]) - ref))) for tag in ("faithful", "fused")}
+    out["errors"]["decomposition_masso_max_rel_diff_vs_upcast"] = {
+        tag: float(np.max(np.abs(rows[tag][:3] - rows["upcast"][:3]) / rows["upcast"][:3]))
+        for tag in ("faithful", "fused")}
+    out["errors"]["heat_integrand_identical_in_all_interpretations"] = bool(
+        np.array_equal(rows["faithful"][3], rows["upcast"][3])
+        and np.array_equal(rows["fused"][3], rows["upcast"][3]))
+    Tn = T[nt // 2].cpu().numpy()
+    ohc = o.ocean_heat_content(Tn[None], g["volcello"])[0]
+    got = 1035.0 * 3992.0 * rows["upcast"][3][nt // 2]
+    out["errors"]["ocean_heat_content_rel_err_vs_numpy_oracle_one_slab"] = float(abs(got - ohc) / abs(ohc))
+    out["errors"]["ocean_heat_content_note"] = ("extension, parity unpinned: momlevel has no OHC "
+                                                "function; checked against the build's own numpy line")
+
     # ---- tolerance: slabs t = 0, nt//2, nt-1 ------------------------------------------------
-    worst = {"faithful_vs_f64": 0.0, "upcast_vs_f64": 0.0, "pure_f32_vs_f64": 0.0}
+    worst = {"faithful_vs_f64": 0.0, "upcast_vs_f64": 0.0, "pure_f32_vs_f64": 0.0,
+             "fused_vs_f64": 0.0}
     bit_exact = True
     for t in sorted({0, nt // 2, nt - 1}):
         T32, S32 = T[t].cpu().numpy(), S[t].cpu().numpy()
@@ -86,6 +128,7 @@ def main():
                                  pres_h[:, None, None])
         faithful = core.eos_map(T[t], S[t], pres, f32_mode="faithful").cpu().numpy()
         upcast = core.eos_map(T[t], S[t], pres, f32_mode="upcast").cpu().numpy()
+        fused = core.eos_map(T[t], S[t], pres, arith="fused").cpu().numpy()
         pure32 = o.wright_density(T32, S32, pres_h.astype(np.float32)[:, None, None])
         oracle_mixed = o.wright_density(T32, S32, pres_h[:, None, None])
         m = ~np.isnan(ref64)
@@ -95,13 +138,15 @@ def main():
         worst["faithful_vs_f64"] = max(worst["faithful_vs_f64"], rel(faithful))
         worst["upcast_vs_f64"] = max(worst["upcast_vs_f64"], rel(upcast))
         worst["pure_f32_vs_f64"] = max(worst["pure_f32_vs_f64"], rel(pure32))
-    out["errors"] = {
+        worst["fused_vs_f64"] = max(worst["fused_vs_f64"], rel(fused))
+    out["errors"].update({
         "max_rel_density_error_vs_float64_evaluation": worst,
         "faithful_mode_bit_identical_to_numpy_mixed_precision": bit_exact,
         "note": ("faithful = what momlevel computes on float32 input; upcast = float64 arithmetic "
                  "on the float32 values (exact by construction); pure_f32 = everything in float32 "
-                 "(not offered: loses ~1e-7)"),
-    }
+                 "(not offered: loses ~1e-7); fused = MLX_FLAG_FMA, float64 with contracted multiply-adds "
+                 "and a Newton reciprocal (opt-in)"),
+    })
     # global steric sensitivity: expansion coefficient difference between the two modes
     mf = core.steric_global_masso(T, S, vol0, pres, f32_mode="faithful").cpu().numpy()
     mu = core.steric_global_masso(T, S, vol0, pres, f32_mode="upcast").cpu().numpy()
