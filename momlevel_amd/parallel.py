@@ -204,7 +204,9 @@ def steric_global_tile_streamed(source, vol0, areacello, pres, variants=("steric
     for v in variants:
         if v not in _VARIANTS:
             raise ValueError(f"Unknown variant '{v}' passed to `steric`")
-    dev = engine.device_of(vol0) if engine._is_device(vol0) else engine.device_of()
+    # the GPU that owns the record (or vol0); host-only operands go to the current device
+    owners = [x for x in (source[0], source[1], vol0) if engine._is_device(x)]
+    dev = engine.device_of(*owners)
     vol0 = engine.to_device(vol0, dev, torch.float64)
     if not engine.time_dependent(pres):
         pres = engine.to_device(pres, dev, torch.float64)
