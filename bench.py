@@ -520,8 +520,42 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
                 "GB/s": round(24 * done / pms / 1e6, 1), "ms": round(pms, 3),
                 "note": "mlx_stream_probe: out = a + b, 16 B read + 8 B written per element"}
             out["local_with_delta_rho"]["frac_of_read_write_probe"] = round(pms / ms, 4)
-        ms = _time(lambda: run(True), reps=2)
-        out["land_skipping"]["local_with_delta_rho_Mcells/s"] = round(done / ms / 1e3, 1)
+        ms_skip = _time(lambda: run(True), reps=2)
+        out["land_skipping"]["local_with_delta_rho_Mcells/s"] = round(done / ms_skip / 1e3, 1)
+
+        # all three local variants: three launches (24 + 16 + 16 B/cell) vs ONE pass of the
+        # all-variants K2 (16 B read + 3 x 8 B written per cell)
+        def run_held(Tv, Sv):
+            for t0 in starts:
+                core.steric_local(Tv[t0:t0 + chunk] if Tv.dim() == 4 else Tv,
+                                  Sv[t0:t0 + chunk] if Sv.dim() == 4 else Sv, rho0m, vol0[0], pres,
+                                  -1.0 / 1035.0, z_i=zi, deptho=dep, delta_rho_out=drho,
+                                  eta_out=eta[t0:t0 + chunk], skip_dry=False)
+
+        three = ms + _time(lambda: run_held(T, S[0]), reps=2) + _time(lambda: run_held(T[0], S), reps=2)
+        del drho
+        c3 = max(1, chunk // 2)
+        free, _ = torch.cuda.mem_get_info(dev)
+        if free > 3 * c3 * nz * ny * nx * 8 + 3 * nt * ny * nx * 8 + (2 << 30):
+            d3 = torch.empty((3, c3, nz, ny, nx), dtype=torch.float64, device=dev)
+            e3 = torch.empty((3, nt, ny, nx), dtype=torch.float64, device=dev)
+            starts3 = range(0, nt - c3 + 1, c3)
+            done3 = len(starts3) * c3 * nz * ny * nx
+
+            def run3():
+                for t0 in starts3:
+                    core.steric_local_decomp(T[t0:t0 + c3], S[t0:t0 + c3], T[0], S[0], rho0m,
+                                             vol0[0], pres, -1.0 / 1035.0, z_i=zi, deptho=dep,
+                                             delta_rho_out=d3, eta_out=e3[:, t0:t0 + c3],
+                                             skip_dry=False)
+
+            ms3 = _time(run3, reps=2)
+            r = rate(ms3, 2 * B1 + 24, done3)
+            r["three_single_variant_launches_ms"] = round(three * done3 / done, 3)
+            r["one_pass_speedup"] = round(three * done3 / done / ms3, 3)
+            r["note"] = "steric + thermosteric + halosteric delta_rho and eta, theta/S read once"
+            out["local_decomposition_one_pass"] = r
+            del d3, e3
     return out
 
 

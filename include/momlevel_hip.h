@@ -38,7 +38,8 @@
 extern "C" {
 #endif
 
-#define MLX_ABI_VERSION 2 /* 2: mlx_eos_map takes flags; mlx_steric_global_decomp, mlx_stream_probe;
+#define MLX_ABI_VERSION 2 /* 2: mlx_eos_map takes flags; mlx_steric_global_decomp, mlx_steric_local_decomp,
+                             mlx_stream_probe;
                              MLX_FLAG_FMA, MLX_FLAG_TCHUNK; MLX_P_FULL4D in K1/K2 */
 
 /* argument-error codes (negative) */
@@ -184,6 +185,26 @@ int mlx_steric_local(const void *T, const void *S, int dtype,
                      int64_t nt, int64_t nz, int64_t plane,
                      int64_t t_stride_T, int64_t t_stride_S, int flags,
                      double *delta_rho_out, double *eta_out, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * K2, all variants in ONE pass over theta/S: what three calls of steric(..., domain="local")
+ * with variant = "steric", "thermosteric", "halosteric" compute (src/momlevel/steric.py:115-125,
+ * 150-166), from a single read of the 4-D fields (16 B read + 3 x 8 B written per cell instead of
+ * 3 x (16|8 read + 8 written)).  T0, S0: the (z,y,x) reference slabs (same dtype as T, S).
+ * Variant v (0 steric, 1 thermosteric, 2 halosteric) lands at
+ *   delta_rho_out + v*delta_rho_variant_stride   (nt,nz,plane)   [delta_rho_out may be NULL]
+ *   eta_out       + v*eta_variant_stride         (nt,plane)
+ * (strides in elements, >= the size of one field).  Each field is bit-identical to the
+ * corresponding mlx_steric_local call.
+ * ------------------------------------------------------------------------------- */
+int mlx_steric_local_decomp(const void *T, const void *S, const void *T0, const void *S0, int dtype,
+                            const double *rho0m, const double *vol0_surface,
+                            const double *dz, const double *z_i, const double *deptho,
+                            const double *p, int p_mode, int eos, double neg_inv_rhozero,
+                            int64_t nt, int64_t nz, int64_t plane,
+                            int64_t t_stride_T, int64_t t_stride_S, int flags,
+                            double *delta_rho_out, int64_t delta_rho_variant_stride,
+                            double *eta_out, int64_t eta_variant_stride, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * skipna sum of n float64 values -> out[0].  Replaces volcello.sum() in

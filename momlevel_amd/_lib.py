@@ -74,6 +74,11 @@ SIGNATURES = {
         [_vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _dbl,
          _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp],
     ),
+    "mlx_steric_local_decomp": (
+        _int,
+        [_vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _dbl,
+         _i64, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp, _i64, _vp],
+    ),
     "mlx_nansum_workspace_bytes": (_sz, [_i64]),
     "mlx_nansum": (_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
     "mlx_masso": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),

@@ -352,6 +352,69 @@ def steric_local(T, S, rho0m, vol0_surface, p, neg_inv_rhozero, dz=None, z_i=Non
     return drho, eta
 
 
+LOCAL_DECOMP_ROWS = ("steric", "thermosteric", "halosteric")
+
+
+def steric_local_decomp(T, S, T0, S0, rho0m, vol0_surface, p, neg_inv_rhozero, dz=None, z_i=None,
+                        deptho=None, eos="wright", f32_mode="faithful", want_delta_rho=True,
+                        delta_rho_out=None, eta_out=None, skip_dry=None, arith=None):
+    """K2, all variants in one pass over theta/S: (delta_rho (3,nt,nz,ny,nx) or None,
+    eta (3,nt,ny,nx)), variant order LOCAL_DECOMP_ROWS; each field bit-identical to its
+    steric_local call.  ``delta_rho_out`` / ``eta_out``: optional (3, nt, ...) float64 device
+    tensors (or views whose variant axis has any stride, e.g. ``full[:, t0:t1]``)."""
+    require_device()
+    flags = _k1_flags(skip_dry, arith, 0)
+    T, S, nt, nz, ny, nx, sT, sS, dt, _ = _pair(T, S, f32_mode)
+    if T.dim() != 4 or S.dim() != 4:
+        raise ValueError("steric_local_decomp streams both fields: thetao and so must be 4-D")
+    dev = T.device
+    T0 = T0.to(device=dev, dtype=T.dtype).contiguous()
+    S0 = S0.to(device=dev, dtype=S.dtype).contiguous()
+    if tuple(T0.shape) != (nz, ny, nx) or tuple(S0.shape) != (nz, ny, nx):
+        raise ValueError(f"T0 and S0 must be {(nz, ny, nx)}")
+    rho0m = _f64(rho0m, dev)
+    vol0_surface = _f64(vol0_surface, dev)
+    if tuple(rho0m.shape) != (nz, ny, nx) or tuple(vol0_surface.shape) != (ny, nx):
+        raise ValueError("rho0m must be (nz,ny,nx) and vol0_surface (ny,nx)")
+    pt, p_mode = _pressure(p, nt, nz, ny, nx, dev, allow4d=True)
+    if dz is not None:
+        dz = _f64(dz, dev)
+        if tuple(dz.shape) != (nz, ny, nx):
+            raise ValueError("dz must be (nz,ny,nx)")
+    else:
+        z_i = _f64(z_i, dev)
+        deptho = _f64(deptho, dev)
+        if z_i.numel() != nz + 1 or tuple(deptho.shape) != (ny, nx):
+            raise ValueError("z_i must have nz+1 entries and deptho be (ny,nx)")
+
+    def variant_major(x, shape):
+        """(3, nt, ...) float64 device tensor whose per-variant fields are contiguous"""
+        if tuple(x.shape) != shape or x.dtype != torch.float64 or x.device != dev:
+            raise ValueError(f"output must be a float64 {shape} tensor on {dev}")
+        if not x[0].is_contiguous() or x.stride(0) < x[0].numel():
+            raise ValueError("each variant's field must be contiguous")
+        return x
+
+    drho = None
+    if want_delta_rho:
+        drho = delta_rho_out if delta_rho_out is not None else torch.empty(
+            (3, nt, nz, ny, nx), dtype=torch.float64, device=dev)
+        variant_major(drho, (3, nt, nz, ny, nx))
+    eta = eta_out if eta_out is not None else torch.empty((3, nt, ny, nx), dtype=torch.float64,
+                                                           device=dev)
+    variant_major(eta, (3, nt, ny, nx))
+    with _on(dev):
+        rc = _lib.load().mlx_steric_local_decomp(
+            _ptr(T), _ptr(S), _ptr(T0), _ptr(S0), dt, _ptr(rho0m), _ptr(vol0_surface), _ptr(dz),
+            _ptr(z_i), _ptr(deptho), _ptr(pt), p_mode, EOS_IDS[eos.lower()],
+            float(neg_inv_rhozero), nt, nz, ny * nx, sT, sS, flags,
+            _ptr(drho), drho.stride(0) if drho is not None else 0, _ptr(eta), eta.stride(0),
+            _stream(dev),
+        )
+    _lib.check(rc, "mlx_steric_local_decomp")
+    return drho, eta
+
+
 def nansum(x):
     """skipna sum of a float64 device tensor -> 0-d device tensor."""
     require_device()

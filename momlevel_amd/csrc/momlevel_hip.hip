@@ -65,6 +65,11 @@ __device__ __forceinline__ Pack<TIn, VEC> load_pack(const TIn* __restrict__ p) {
   if constexpr (VEC == 1) {
     if constexpr (STREAM) r.v[0] = __builtin_nontemporal_load(p);
     else r.v[0] = p[0];
+  } else if constexpr (sizeof(TIn) * VEC == 8) {  // float2: one global_load_dwordx2
+    double raw;
+    if constexpr (STREAM) raw = __builtin_nontemporal_load(reinterpret_cast<const double*>(p));
+    else raw = *reinterpret_cast<const double*>(p);
+    __builtin_memcpy(&r, &raw, 8);
   } else if constexpr (sizeof(TIn) * VEC == 16) {
     f4_t raw = load16<STREAM>(p);  // one global_load_dwordx4
     __builtin_memcpy(&r, &raw, 16);
@@ -502,14 +507,25 @@ __device__ __forceinline__ double dz_default(double depth, double ztop, double z
 // (scripts/tune_k2.hip) than NTI=8 at 4 waves/SIMD: half the rho0m re-reads and twice the
 // bytes in flight per wave.  theta/S loads and the delta_rho stores use the nt policy.
 // ------------------------------------------------------------------------------------
-template <typename TIn, int VEC, int NTI, int HOLD, int MODE, bool GENERIC, bool SKIP, bool FMA>
+// VAR (steric.py:115-125), as in K1: 0 steric; 1 halosteric (theta held: T is the (z,y,x) slab,
+// stride 0); 2 thermosteric (S held); 3 = ALL THREE in one pass: theta/S are read once, the held
+// slabs T0/S0 once per level, and three delta_rho / eta fields are written, variant v at
+// out + v*variant_stride (v = 0 steric, 1 thermosteric, 2 halosteric, the order of K1's rows):
+// 16 B read + 3*8 B written per cell instead of 3 x (16 or 8 read + 8 written).  Each field is
+// bit-identical to its single-variant launch (same arithmetic tree, z ascending).
+template <typename TIn, int VEC, int NTI, int VAR, int MODE, bool GENERIC, bool SKIP, bool FMA>
 __global__ __launch_bounds__(kBlock) void k_steric_local(
-    const TIn* __restrict__ T, const TIn* __restrict__ S, const double* __restrict__ rho0m,
+    const TIn* __restrict__ T, const TIn* __restrict__ S, const TIn* __restrict__ T0,
+    const TIn* __restrict__ S0, const double* __restrict__ rho0m,
     const double* __restrict__ vol0_surface, const double* __restrict__ dz,
     const double* __restrict__ z_i, const double* __restrict__ deptho,
     const double* __restrict__ p, int p_mode, int eos, double neg_inv_rhozero, int nt, int nz,
     int64_t plane, int64_t t_stride_T, int64_t t_stride_S, double* __restrict__ drho_out,
-    double* __restrict__ eta_out) {
+    int64_t drho_vstride, double* __restrict__ eta_out, int64_t eta_vstride) {
+  constexpr int NOUT = (VAR == kVarAll) ? 3 : 1;
+  constexpr bool STREAM_T = (VAR != kVarHalo), STREAM_S = (VAR != kVarThermo);
+  constexpr bool HELD_T = (VAR == kVarHalo || VAR == kVarAll);
+  constexpr bool HELD_S = (VAR == kVarThermo || VAR == kVarAll);
   typedef typename PolyType<MODE>::type R;
   typedef typename std::conditional<FMA, FusedOps, ExactOps>::type Ops;
   static_assert(!FMA || MODE != kF32Faithful, "fused arithmetic is float64");
@@ -518,11 +534,13 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
   const int t0 = blockIdx.y * NTI;
   const int64_t n3 = (int64_t)nz * plane;
 
-  double acc[NTI][VEC];
+  double acc[NOUT][NTI][VEC];
 #pragma unroll
-  for (int j = 0; j < NTI; ++j)
+  for (int o = 0; o < NOUT; ++o)
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) acc[j][k] = 0.0;
+    for (int j = 0; j < NTI; ++j)
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[o][j][k] = 0.0;
 
   Pack<double, VEC> depth;
   if (dz == nullptr) depth = load_pack<double, VEC>(deptho + col);
@@ -557,21 +575,21 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
       for (int k = 0; k < VEC; ++k) alive = alive || !is_nan(r0.v[k]);
     }
 
-    // the held field (HOLD 1: theta, 2: S) is read once per level and -- fast path -- its part
-    // of the polynomial evaluated once for the NTI time steps (eos_device.hpp TPart/SPart)
+    // a held field is read once per level and -- fast path -- its part of the polynomial
+    // evaluated once for the NTI time steps (eos_device.hpp TPart/SPart)
     Pack<TIn, VEC> hT = {}, hS = {};
     if (alive) {
-      if (HOLD == 1) hT = load_pack<TIn, VEC>(T + off);
-      if (HOLD == 2) hS = load_pack<TIn, VEC>(S + off);
+      if (HELD_T) hT = load_pack<TIn, VEC>((VAR == kVarAll ? T0 : T) + off);
+      if (HELD_S) hS = load_pack<TIn, VEC>((VAR == kVarAll ? S0 : S) + off);
     }
     const R pfold = FMA ? (R)pz : R(0);
     TPart<R> hTp[VEC];
     SPart<R> hSp[VEC];
-    if constexpr (!GENERIC && HOLD == 1) {
+    if constexpr (!GENERIC && HELD_T) {
 #pragma unroll
       for (int k = 0; k < VEC; ++k) hTp[k] = t_part<Ops, R>((R)hT.v[k]);
     }
-    if constexpr (!GENERIC && HOLD == 2) {
+    if constexpr (!GENERIC && HELD_S) {
 #pragma unroll
       for (int k = 0; k < VEC; ++k) hSp[k] = s_part<Ops, R>((R)hS.v[k], pfold);
     }
@@ -583,53 +601,73 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
       b[j] = {};
       if (alive && t0 + j < nt) {  // the ragged last chunk issues no surplus loads
         const int64_t t = t0 + j;
-        if (HOLD != 1) a[j] = load_pack<TIn, VEC, true>(T + t * t_stride_T + off);
-        if (HOLD != 2) b[j] = load_pack<TIn, VEC, true>(S + t * t_stride_S + off);
+        if (STREAM_T) a[j] = load_pack<TIn, VEC, true>(T + t * t_stride_T + off);
+        if (STREAM_S) b[j] = load_pack<TIn, VEC, true>(S + t * t_stride_S + off);
       }
     }
 #pragma unroll
     for (int j = 0; j < NTI; ++j) {
       if (t0 + j < nt) {
-        Pack<double, VEC> d;
+        Pack<double, VEC> d[NOUT];
         // dry lanes (SKIP) run the same arithmetic on zeros: rho - NaN is NaN and the NaN term is
         // skipped, exactly as if theta/S had been loaded.  Only their LOADS are masked -- a
         // divergent store path would split every partly-dry line into two transactions.
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-          const TIn tv = (HOLD == 1) ? hT.v[k] : a[j].v[k];
-          const TIn sv = (HOLD == 2) ? hS.v[k] : b[j].v[k];
-          double rho;
+          const TIn tv = STREAM_T ? a[j].v[k] : hT.v[k];
+          const TIn sv = STREAM_S ? b[j].v[k] : hS.v[k];
+          double rho[NOUT];
           if constexpr (GENERIC) {
             double pp = (p_mode == MLX_P_FULL3D) ? pfull.v[k] : pz;
             if (p_mode == MLX_P_FULL4D) pp = p[(int64_t)(t0 + j) * n3 + off + k];
-            rho = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, sv, pp);
-          } else if constexpr (HOLD == 1) {
-            rho = wright_combine<Ops, R>(hTp[k], s_part<Ops, R>((R)sv, pfold), pz);
-          } else if constexpr (HOLD == 2) {
-            rho = wright_combine<Ops, R>(t_part<Ops, R>((R)tv), hSp[k], pz);
+            rho[0] = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, sv, pp);
+            if constexpr (VAR == kVarAll) {
+              rho[1] = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, hS.v[k], pp);
+              rho[2] = eos_eval<MODE, TIn, Ops>(eos, kDensity, hT.v[k], sv, pp);
+            }
           } else {
-            rho = wright_density<MODE, TIn, Ops>(tv, sv, pz);
+            TPart<R> tp;
+            SPart<R> sp;
+            if constexpr (STREAM_T) tp = t_part<Ops, R>((R)tv);
+            if constexpr (STREAM_S) sp = s_part<Ops, R>((R)sv, pfold);
+            if constexpr (VAR == kVarSteric) rho[0] = wright_combine<Ops, R>(tp, sp, pz);
+            if constexpr (VAR == kVarHalo) rho[0] = wright_combine<Ops, R>(hTp[k], sp, pz);
+            if constexpr (VAR == kVarThermo) rho[0] = wright_combine<Ops, R>(tp, hSp[k], pz);
+            if constexpr (VAR == kVarAll) {
+              rho[0] = wright_combine<Ops, R>(tp, sp, pz);
+              rho[1] = wright_combine<Ops, R>(tp, hSp[k], pz);
+              rho[2] = wright_combine<Ops, R>(hTp[k], sp, pz);
+            }
           }
-          double dr = rho - r0.v[k];               // steric.py:152 (NaN where vol0 is NaN)
-          dr = is_nan(dr) ? canonical_nan() : dr;  // canonical payload
-          d.v[k] = dr;
-          const double term = dzv.v[k] * dr;       // steric.py:163
-          acc[j][k] += is_nan(term) ? 0.0 : term;  // skipna, z ascending like numpy
+#pragma unroll
+          for (int o = 0; o < NOUT; ++o) {
+            double dr = rho[o] - r0.v[k];            // steric.py:152 (NaN where vol0 is NaN)
+            dr = is_nan(dr) ? canonical_nan() : dr;  // canonical payload
+            d[o].v[k] = dr;
+            const double term = dzv.v[k] * dr;          // steric.py:163
+            acc[o][j][k] += is_nan(term) ? 0.0 : term;  // skipna, z ascending like numpy
+          }
         }
-        if (drho_out != nullptr)
-          store_pack<VEC, true>(drho_out + (int64_t)(t0 + j) * n3 + off, d);
+        if (drho_out != nullptr) {
+#pragma unroll
+          for (int o = 0; o < NOUT; ++o)
+            store_pack<VEC, true>(drho_out + o * drho_vstride + (int64_t)(t0 + j) * n3 + off, d[o]);
+        }
       }
     }
   }
   const Pack<double, VEC> surf = load_pack<double, VEC>(vol0_surface + col);
 #pragma unroll
-  for (int j = 0; j < NTI; ++j) {
-    if (t0 + j < nt) {
-      Pack<double, VEC> e;
+  for (int o = 0; o < NOUT; ++o) {
 #pragma unroll
-      for (int k = 0; k < VEC; ++k)
-        e.v[k] = is_nan(surf.v[k]) ? canonical_nan() : neg_inv_rhozero * acc[j][k];
-      store_pack<VEC>(eta_out + (int64_t)(t0 + j) * plane + col, e);
+    for (int j = 0; j < NTI; ++j) {
+      if (t0 + j < nt) {
+        Pack<double, VEC> e;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+          e.v[k] = is_nan(surf.v[k]) ? canonical_nan() : neg_inv_rhozero * acc[o][j][k];
+        store_pack<VEC>(eta_out + o * eta_vstride + (int64_t)(t0 + j) * plane + col, e);
+      }
     }
   }
 }
@@ -940,44 +978,121 @@ int steric_global_impl(const void* T, const void* S, const void* T0, const void*
 struct K2Args {
   dim3 grid;
   hipStream_t st;
-  const void *T, *S;
+  const void *T, *S, *T0, *S0;
   const double *rho0m, *surf, *dz, *z_i, *deptho, *p;
   int p_mode, eos, nt, nz;
   double neg_inv_rhozero;
   int64_t plane, sT, sS;
   double *drho, *eta;
+  int64_t drho_vstride, eta_vstride;
 };
 
-template <typename TIn, int VEC, int NTI, int HOLD, int MODE, bool GEN, bool SKIP, bool FMA>
+template <typename TIn, int VEC, int NTI, int VAR, int MODE, bool GEN, bool SKIP, bool FMA>
 void k2_go(const K2Args& a) {
-  hipLaunchKernelGGL((k_steric_local<TIn, VEC, NTI, HOLD, MODE, GEN, SKIP, FMA>), a.grid,
-                     dim3(kBlock), 0, a.st, (const TIn*)a.T, (const TIn*)a.S, a.rho0m, a.surf,
-                     a.dz, a.z_i, a.deptho, a.p, a.p_mode, a.eos, a.neg_inv_rhozero, a.nt, a.nz,
-                     a.plane, a.sT, a.sS, a.drho, a.eta);
+  hipLaunchKernelGGL((k_steric_local<TIn, VEC, NTI, VAR, MODE, GEN, SKIP, FMA>), a.grid,
+                     dim3(kBlock), 0, a.st, (const TIn*)a.T, (const TIn*)a.S, (const TIn*)a.T0,
+                     (const TIn*)a.S0, a.rho0m, a.surf, a.dz, a.z_i, a.deptho, a.p, a.p_mode, a.eos,
+                     a.neg_inv_rhozero, a.nt, a.nz, a.plane, a.sT, a.sS, a.drho, a.drho_vstride,
+                     a.eta, a.eta_vstride);
 }
 
-template <typename TIn, int VEC, int NTI, int HOLD, int MODE, bool GEN>
+template <typename TIn, int VEC, int NTI, int VAR, int MODE, bool GEN>
 void k2_flags(const K2Args& a, bool skip, bool fma) {
   constexpr int FM = (MODE == kF32Faithful) ? kF32Upcast : MODE;
   constexpr bool S1 = !GEN;
   if (fma) {
-    if (skip && S1) k2_go<TIn, VEC, NTI, HOLD, FM, GEN, S1, true>(a);
-    else k2_go<TIn, VEC, NTI, HOLD, FM, GEN, false, true>(a);
+    if (skip && S1) k2_go<TIn, VEC, NTI, VAR, FM, GEN, S1, true>(a);
+    else k2_go<TIn, VEC, NTI, VAR, FM, GEN, false, true>(a);
   } else {
-    if (skip && S1) k2_go<TIn, VEC, NTI, HOLD, MODE, GEN, S1, false>(a);
-    else k2_go<TIn, VEC, NTI, HOLD, MODE, GEN, false, false>(a);
+    if (skip && S1) k2_go<TIn, VEC, NTI, VAR, MODE, GEN, S1, false>(a);
+    else k2_go<TIn, VEC, NTI, VAR, MODE, GEN, false, false>(a);
   }
 }
 
-template <typename TIn, int VEC, int NTI, int MODE, bool GEN>
-void k2_hold(const K2Args& a, int hold, bool skip, bool fma) {
-  if constexpr (GEN) {
-    k2_flags<TIn, VEC, NTI, 0, MODE, GEN>(a, skip, fma);
+// NTI1: time steps per thread of the single-variant kernels; VEC3/NTI3: columns and time steps per
+// thread of the all-variants kernel (three sets of column sums in registers)
+template <typename TIn, int VEC, int NTI1, int VEC3, int NTI3, int MODE, bool GEN>
+void k2_var(const K2Args& a, int var, bool skip, bool fma) {
+  if (var == kVarAll) {
+    k2_flags<TIn, VEC3, NTI3, kVarAll, MODE, GEN>(a, skip, fma);
+  } else if constexpr (GEN) {  // held fields reach the generic twin as stride-0 streams
+    k2_flags<TIn, VEC, NTI1, kVarSteric, MODE, GEN>(a, skip, fma);
   } else {
-    if (hold == 0) k2_flags<TIn, VEC, NTI, 0, MODE, GEN>(a, skip, fma);
-    else if (hold == 1) k2_flags<TIn, VEC, NTI, 1, MODE, GEN>(a, skip, fma);
-    else k2_flags<TIn, VEC, NTI, 2, MODE, GEN>(a, skip, fma);
+    if (var == kVarSteric) k2_flags<TIn, VEC, NTI1, kVarSteric, MODE, GEN>(a, skip, fma);
+    else if (var == kVarHalo) k2_flags<TIn, VEC, NTI1, kVarHalo, MODE, GEN>(a, skip, fma);
+    else k2_flags<TIn, VEC, NTI1, kVarThermo, MODE, GEN>(a, skip, fma);
   }
+}
+
+// all-variants kernel: 2 columns x 8 time steps per thread for BOTH dtypes (float32 theta/S then
+// come as float2 = 8-byte loads; four columns' worth of held parts and three sets of column sums
+// would not fit 256 VGPRs)
+constexpr int kNTI64All = 8, kNTI32All = 8, kNTIGenAll = 4, kVec32All = 2;
+
+// shared body of mlx_steric_local (var 0/1/2 from the strides) and mlx_steric_local_decomp (var 3)
+int steric_local_impl(const void* T, const void* S, const void* T0, const void* S0, int var,
+                      int dtype, const double* rho0m, const double* vol0_surface, const double* dz,
+                      const double* z_i, const double* deptho, const double* p, int p_mode, int eos,
+                      double neg_inv_rhozero, int64_t nt, int64_t nz, int64_t plane, int64_t sT,
+                      int64_t sS, int flags, double* delta_rho_out, int64_t drho_vstride,
+                      double* eta_out, int64_t eta_vstride, void* stream) {
+  if (flags & ~(MLX_FLAG_SKIP_DRY | MLX_FLAG_FMA)) return fail(MLX_E_ENUM, "unknown flag bits");
+  const bool skip = (flags & MLX_FLAG_SKIP_DRY) != 0, fma = (flags & MLX_FLAG_FMA) != 0;
+  if (int rc = check_common(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS)) return rc;
+  if (!rho0m || !vol0_surface || !eta_out)
+    return fail(MLX_E_NULL, "rho0m, vol0_surface and eta_out must not be NULL");
+  if (!dz && (!z_i || !deptho))
+    return fail(MLX_E_NULL, "either dz or both z_i and deptho must be given");
+  for (const void* q : {(const void*)rho0m, (const void*)vol0_surface, (const void*)dz,
+                        (const void*)z_i, (const void*)deptho, (const void*)delta_rho_out,
+                        (const void*)eta_out})
+    if (q && !aligned(q, 8)) return fail(MLX_E_ALIGN, "operands not 8-byte aligned");
+  if (var == kVarAll) {
+    if (!T0 || !S0) return fail(MLX_E_NULL, "T0 and S0 must not be NULL");
+    const size_t es = (dtype == MLX_DTYPE_F64) ? 8 : 4;
+    if (!aligned(T0, es) || !aligned(S0, es)) return fail(MLX_E_ALIGN, "T0/S0 not element-aligned");
+    int64_t n3, n4;
+    if (!mul_fits(nz, plane, &n3) || !mul_fits(nt, n3, &n4)) return fail(MLX_E_SHAPE, "overflow");
+    if (eta_vstride < nt * plane || (delta_rho_out && drho_vstride < n4))
+      return fail(MLX_E_SHAPE, "variant strides must be >= the size of one variant's field");
+  }
+  const bool f64 = (dtype == MLX_DTYPE_F64);
+  // both strides must be whole packs too in the all-variants kernel (three fields, one base)
+  bool fast = fast_layout(dtype, p_mode, eos, plane, sT, sS,
+                          {T, S, T0, S0, rho0m, vol0_surface, eta_out, dz, dz ? nullptr : deptho,
+                           delta_rho_out}) &&
+              !(sT == 0 && sS == 0);
+  if (var == kVarAll && fast) {
+    const int vec = vec_of(dtype);
+    if (eta_vstride % vec || drho_vstride % vec) fast = false;
+  }
+  if (var != kVarAll) var = (sT == 0) ? kVarHalo : ((sS == 0) ? kVarThermo : kVarSteric);
+  const int v = !fast ? 1 : ((var == kVarAll && !f64) ? kVec32All : vec_of(dtype));
+  const int nti = (var == kVarAll) ? (fast ? (f64 ? kNTI64All : kNTI32All) : kNTIGenAll)
+                                   : (fast ? (f64 ? kNTI64 : kNTI32) : kNTIGen);
+  if (ceil_div(nt, nti) > 65535) return fail(MLX_E_SHAPE, "nt too large for one call: chunk it");
+  const int64_t gx = ceil_div(plane, (int64_t)kBlock * v);
+  if (gx > 2147483647LL) return fail(MLX_E_SHAPE, "plane too large");
+  K2Args a;
+  a.grid = dim3((unsigned)gx, (unsigned)ceil_div(nt, nti));
+  a.st = (hipStream_t)stream;
+  a.T = T; a.S = S; a.T0 = T0 ? T0 : T; a.S0 = S0 ? S0 : S;
+  a.rho0m = rho0m; a.surf = vol0_surface; a.dz = dz; a.z_i = z_i;
+  a.deptho = deptho; a.p = p ? p : rho0m; a.p_mode = p_mode; a.eos = eos; a.nt = (int)nt;
+  a.nz = (int)nz; a.neg_inv_rhozero = neg_inv_rhozero; a.plane = plane; a.sT = sT; a.sS = sS;
+  a.drho = delta_rho_out; a.eta = eta_out; a.drho_vstride = drho_vstride; a.eta_vstride = eta_vstride;
+  if (fast) {
+    if (f64) k2_var<double, kVec64, kNTI64, kVec64, kNTI64All, kF64, false>(a, var, skip, fma);
+    else if (dtype == MLX_DTYPE_F32)
+      k2_var<float, kVec32, kNTI32, kVec32All, kNTI32All, kF32Faithful, false>(a, var, skip, fma);
+    else k2_var<float, kVec32, kNTI32, kVec32All, kNTI32All, kF32Upcast, false>(a, var, skip, fma);
+  } else {
+    if (f64) k2_var<double, 1, kNTIGen, 1, kNTIGenAll, kF64, true>(a, var, skip, fma);
+    else if (dtype == MLX_DTYPE_F32)
+      k2_var<float, 1, kNTIGen, 1, kNTIGenAll, kF32Faithful, true>(a, var, skip, fma);
+    else k2_var<float, 1, kNTIGen, 1, kNTIGenAll, kF32Upcast, true>(a, var, skip, fma);
+  }
+  return hip_status(hipGetLastError(), "k_steric_local launch");
 }
 
 }  // namespace
@@ -1130,45 +1245,24 @@ int mlx_steric_local(const void* T, const void* S, int dtype, const double* rho0
                      const double* deptho, const double* p, int p_mode, int eos,
                      double neg_inv_rhozero, int64_t nt, int64_t nz, int64_t plane, int64_t sT,
                      int64_t sS, int flags, double* delta_rho_out, double* eta_out, void* stream) {
-  if (flags & ~(MLX_FLAG_SKIP_DRY | MLX_FLAG_FMA)) return fail(MLX_E_ENUM, "unknown flag bits");
-  const bool skip = (flags & MLX_FLAG_SKIP_DRY) != 0, fma = (flags & MLX_FLAG_FMA) != 0;
-  if (int rc = check_common(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS)) return rc;
-  if (!rho0m || !vol0_surface || !eta_out)
-    return fail(MLX_E_NULL, "rho0m, vol0_surface and eta_out must not be NULL");
-  if (!dz && (!z_i || !deptho))
-    return fail(MLX_E_NULL, "either dz or both z_i and deptho must be given");
-  for (const void* q : {(const void*)rho0m, (const void*)vol0_surface, (const void*)dz,
-                        (const void*)z_i, (const void*)deptho, (const void*)delta_rho_out,
-                        (const void*)eta_out})
-    if (q && !aligned(q, 8)) return fail(MLX_E_ALIGN, "operands not 8-byte aligned");
-  if (ceil_div(nt, kNTIGen) > 65535) return fail(MLX_E_SHAPE, "nt too large for one call: chunk it");
-  const bool f64 = (dtype == MLX_DTYPE_F64);
-  const bool fast = fast_layout(dtype, p_mode, eos, plane, sT, sS,
-                                {T, S, rho0m, vol0_surface, eta_out, dz, dz ? nullptr : deptho,
-                                 delta_rho_out}) &&
-                    !(sT == 0 && sS == 0);
-  const int hold = (sT == 0) ? 1 : ((sS == 0) ? 2 : 0);
-  const int v = fast ? vec_of(dtype) : 1;
-  const int nti = fast ? (f64 ? kNTI64 : kNTI32) : kNTIGen;
-  const int64_t gx = ceil_div(plane, (int64_t)kBlock * v);
-  if (gx > 2147483647LL) return fail(MLX_E_SHAPE, "plane too large");
-  K2Args a;
-  a.grid = dim3((unsigned)gx, (unsigned)ceil_div(nt, nti));
-  a.st = (hipStream_t)stream;
-  a.T = T; a.S = S; a.rho0m = rho0m; a.surf = vol0_surface; a.dz = dz; a.z_i = z_i;
-  a.deptho = deptho; a.p = p ? p : rho0m; a.p_mode = p_mode; a.eos = eos; a.nt = (int)nt;
-  a.nz = (int)nz; a.neg_inv_rhozero = neg_inv_rhozero; a.plane = plane; a.sT = sT; a.sS = sS;
-  a.drho = delta_rho_out; a.eta = eta_out;
-  if (fast) {
-    if (f64) k2_hold<double, kVec64, kNTI64, kF64, false>(a, hold, skip, fma);
-    else if (dtype == MLX_DTYPE_F32) k2_hold<float, kVec32, kNTI32, kF32Faithful, false>(a, hold, skip, fma);
-    else k2_hold<float, kVec32, kNTI32, kF32Upcast, false>(a, hold, skip, fma);
-  } else {
-    if (f64) k2_hold<double, 1, kNTIGen, kF64, true>(a, hold, skip, fma);
-    else if (dtype == MLX_DTYPE_F32) k2_hold<float, 1, kNTIGen, kF32Faithful, true>(a, hold, skip, fma);
-    else k2_hold<float, 1, kNTIGen, kF32Upcast, true>(a, hold, skip, fma);
-  }
-  return hip_status(hipGetLastError(), "k_steric_local launch");
+  return steric_local_impl(T, S, nullptr, nullptr, kVarSteric, dtype, rho0m, vol0_surface, dz, z_i,
+                           deptho, p, p_mode, eos, neg_inv_rhozero, nt, nz, plane, sT, sS, flags,
+                           delta_rho_out, 0, eta_out, 0, stream);
+}
+
+int mlx_steric_local_decomp(const void* T, const void* S, const void* T0, const void* S0, int dtype,
+                            const double* rho0m, const double* vol0_surface, const double* dz,
+                            const double* z_i, const double* deptho, const double* p, int p_mode,
+                            int eos, double neg_inv_rhozero, int64_t nt, int64_t nz, int64_t plane,
+                            int64_t sT, int64_t sS, int flags, double* delta_rho_out,
+                            int64_t delta_rho_variant_stride, double* eta_out,
+                            int64_t eta_variant_stride, void* stream) {
+  if (sT == 0 || sS == 0)
+    return fail(MLX_E_SHAPE, "mlx_steric_local_decomp streams both fields: time strides must be > 0");
+  return steric_local_impl(T, S, T0, S0, kVarAll, dtype, rho0m, vol0_surface, dz, z_i, deptho, p,
+                           p_mode, eos, neg_inv_rhozero, nt, nz, plane, sT, sS, flags,
+                           delta_rho_out, delta_rho_variant_stride, eta_out, eta_variant_stride,
+                           stream);
 }
 
 // ---------------------------------------------------------------------------- sums

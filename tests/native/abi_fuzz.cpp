@@ -115,7 +115,7 @@ int main(int argc, char** argv) {
     // the products may overflow int64 for the extreme draws: computed unsigned, only as a hint
     const int64_t n3 = (int64_t)((uint64_t)nz * (uint64_t)plane);
     const int dtype = small_enum(), p_mode = small_enum(), eos = small_enum(), func = small_enum();
-    switch (rnd() % 11) {
+    switch (rnd() % 12) {
       case 0:
         check(mlx_eos_map(ptr(), ptr(), dtype, (const double*)ptr(), p_mode, eos, func, nt, nz,
                           plane, stride(n3), stride(n3), flagbits(), (double*)ptr(), nullptr),
@@ -155,6 +155,18 @@ int main(int argc, char** argv) {
                                stride(n3), stride(n3), flagbits(), (double*)ptr(), (double*)ptr(),
                                nullptr),
               "mlx_steric_local");
+        break;
+      case 11:
+        check(mlx_steric_local_decomp(ptr(), ptr(), ptr(), ptr(), dtype, (const double*)ptr(),
+                                      (const double*)ptr(), (const double*)ptr(),
+                                      (const double*)ptr(), (const double*)ptr(),
+                                      (const double*)ptr(), p_mode, eos, -1.0 / 1035.0, nt, nz,
+                                      plane, stride(n3), stride(n3), flagbits(), (double*)ptr(),
+                                      (rnd() % 2) ? (int64_t)((uint64_t)nt * (uint64_t)n3) : dim(),
+                                      (double*)ptr(),
+                                      (rnd() % 2) ? (int64_t)((uint64_t)nt * (uint64_t)plane) : dim(),
+                                      nullptr),
+              "mlx_steric_local_decomp");
         break;
       case 6: {
         const int64_t n = dim();

@@ -588,3 +588,51 @@ def test_config5_f32_properties():
         assert_bit_equal(eta[0, y0:y1].cpu().numpy(), e, "f32 band eta")
     del T, S
     _free_hbm()
+
+
+@pytest.mark.parametrize("want_delta_rho", [True, False])
+@pytest.mark.parametrize("dtype,f32_mode,arith", [(np.float64, "faithful", "exact"),
+                                                  (np.float32, "faithful", "exact"),
+                                                  (np.float32, "upcast", "exact"),
+                                                  (np.float64, "faithful", "fused"),
+                                                  (np.float32, "faithful", "fused")])
+@pytest.mark.parametrize("shape", [(19, 5, 12, 40), (9, 3, 7, 9), (5, 4, 6, 10)])
+def test_local_decomposition_fields_equal_single_variant_launches(shape, dtype, f32_mode, arith,
+                                                                   want_delta_rho):
+    """mlx_steric_local_decomp: the three delta_rho / eta fields from ONE pass over theta/S are
+    bit-identical to three mlx_steric_local calls (12x40: dwordx4 / float2 kernels, nt=19 = ragged
+    8+8+3; 7x9 and 6x10: the scalar twin), and -- exact arithmetic -- to the oracle."""
+    g, T, S = _case_fields(shape, dtype)
+    dT, dS = torch.from_numpy(T).cuda(), torch.from_numpy(S).cuda()
+    vol0 = torch.from_numpy(g["volcello"]).cuda()
+    pres = o.pressure_from_depth(g["z_l"])
+    kw = dict(f32_mode=f32_mode, arith=arith, z_i=g["z_i"], deptho=g["deptho"])
+    rho0m = core.fold_mask(core.eos_map(dT[0], dS[0], pres, f32_mode=f32_mode, arith=arith), vol0)
+    d3, e3 = core.steric_local_decomp(dT, dS, dT[0], dS[0], rho0m, vol0[0], pres, -1.0 / 1035.0,
+                                      want_delta_rho=want_delta_rho, **kw)
+    assert (d3 is None) == (not want_delta_rho)
+    Tn, Sn = (T.astype(np.float64), S.astype(np.float64)) if f32_mode == "upcast" else (T, S)
+    pb = pres[:, None, None]
+    rho0 = o.wright_density(Tn[0], Sn[0], pb)
+    dz = o.calc_dz(g["z_l"], g["z_i"], g["deptho"])
+    wet = ~np.isnan(g["volcello"])
+    for i, (a, b, an, bn) in enumerate([(dT, dS, Tn, Sn), (dT, dS[0], Tn, Sn[0]),
+                                        (dT[0], dS, Tn[0], Sn)]):
+        d1, e1 = core.steric_local(a, b, rho0m, vol0[0], pres, -1.0 / 1035.0,
+                                   want_delta_rho=want_delta_rho, **kw)
+        assert torch.equal(torch.nan_to_num(e3[i], nan=-7.0), torch.nan_to_num(e1, nan=-7.0))
+        if want_delta_rho:
+            assert torch.equal(torch.nan_to_num(d3[i], nan=-7.0), torch.nan_to_num(d1, nan=-7.0))
+        if arith == "exact":
+            dref = np.where(wet, np.broadcast_to(o.wright_density(an, bn, pb), T.shape) - rho0, np.nan)
+            eref = np.where(wet[0], (-1.0 / 1035.0) * np.nansum(dz * dref, axis=1), np.nan)
+            assert_bit_equal(e3[i].cpu().numpy(), eref, f"one-pass eta, variant {i}")
+            if want_delta_rho:
+                assert_bit_equal(d3[i].cpu().numpy(), dref, f"one-pass delta_rho, variant {i}")
+    # strided outputs: the kernel writes straight into a slice of the full-record tensors
+    full_e = torch.full((3, shape[0] + 4) + shape[2:], -1.0, dtype=torch.float64, device="cuda")
+    core.steric_local_decomp(dT, dS, dT[0], dS[0], rho0m, vol0[0], pres, -1.0 / 1035.0,
+                             want_delta_rho=False, eta_out=full_e[:, 2:2 + shape[0]], **kw)
+    assert torch.equal(torch.nan_to_num(full_e[:, 2:2 + shape[0]], nan=-7.0),
+                       torch.nan_to_num(e3, nan=-7.0))
+    assert torch.all(full_e[:, :2] == -1.0) and torch.all(full_e[:, 2 + shape[0]:] == -1.0)

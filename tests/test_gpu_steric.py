@@ -529,6 +529,42 @@ def test_lazy_inputs_are_read_one_time_chunk_at_a_time(domain, order, monkeypatc
     assert_bit_equal(ref["rho"].transpose(*bref["rho"].dims).values, bref["rho"].values)
 
 
+@pytest.mark.parametrize("resident", [False, True])
+def test_local_variants_come_from_one_pass(resident, monkeypatch):
+    """steric_variants(domain="local") with all three variants: one launch of the all-variants K2
+    per time chunk, no single-variant launch; results == the three steric() calls"""
+    from momlevel_amd import core, engine, steric_variants
+
+    d = _masked_dataset(nt=7)
+    if resident:
+        dd = d.copy()
+        for k in ("thetao", "so", "volcello"):
+            dd[k] = DataArray(torch.from_numpy(d[k].values).cuda(), d[k].dims)
+    else:
+        dd = d
+    calls = {"decomp": 0, "single": 0}
+    real_decomp, real_single = core.steric_local_decomp, core.steric_local
+
+    def count_decomp(*a, **k):
+        calls["decomp"] += 1
+        return real_decomp(*a, **k)
+
+    def count_single(*a, **k):
+        calls["single"] += 1
+        return real_single(*a, **k)
+
+    monkeypatch.setattr(core, "steric_local_decomp", count_decomp)
+    monkeypatch.setattr(core, "steric_local", count_single)
+    monkeypatch.setattr(engine, "chunk_steps", lambda nt, b, dev, budget_bytes=None: 3)
+    results, _ = steric_variants(dd, domain="local")
+    assert calls["single"] == 0 and calls["decomp"] == (1 if resident else 3)
+    monkeypatch.setattr(core, "steric_local", real_single)
+    for variant in ("steric", "thermosteric", "halosteric"):
+        single, _ = steric(d, variant=variant)
+        assert_bit_equal(results[variant][variant].values, single[variant].values, variant)
+        assert_bit_equal(results[variant]["delta_rho"].values, single["delta_rho"].values)
+
+
 def test_delta_rho_can_be_elided(monkeypatch):
     d = _masked_dataset()
     base, _ = steric(d)
