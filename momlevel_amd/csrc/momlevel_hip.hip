@@ -641,17 +641,20 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
           }
 #pragma unroll
           for (int o = 0; o < NOUT; ++o) {
-            double dr = rho[o] - r0.v[k];            // steric.py:152 (NaN where vol0 is NaN)
-            dr = is_nan(dr) ? canonical_nan() : dr;  // canonical payload
+            const double dr = rho[o] - r0.v[k];  // steric.py:152 (NaN where vol0 is NaN)
             d[o].v[k] = dr;
             const double term = dzv.v[k] * dr;          // steric.py:163
             acc[o][j][k] += is_nan(term) ? 0.0 : term;  // skipna, z ascending like numpy
           }
         }
-        if (drho_out != nullptr) {
+        if (drho_out != nullptr) {  // wave-uniform: the eta-only mode skips payload fix and store
 #pragma unroll
-          for (int o = 0; o < NOUT; ++o)
+          for (int o = 0; o < NOUT; ++o) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k)
+              d[o].v[k] = is_nan(d[o].v[k]) ? canonical_nan() : d[o].v[k];  // canonical payload
             store_pack<VEC, true>(drho_out + o * drho_vstride + (int64_t)(t0 + j) * n3 + off, d[o]);
+          }
         }
       }
     }
