@@ -12,9 +12,11 @@ batch: reference state (K0 rho0, volo; masso0 = masso(t=0) of the K1 launch) + K
 reduce + the area sum + [N>1: one RCCL all-reduce of nt+3 doubles] + the host epilogue
 (D2H of masso(t), log, scale).  A cell is one (t,z,y,x) grid point, wet or dry.
 
-N>1 (weak scaling): the (yh,xh) plane is tiled 1x2 / 2x2 / 2x4 over the ranks and every
-rank holds 120*N time steps of its tile, so the bytes per GPU stay those of N=1; value =
-all ranks' cells / max-over-ranks time.
+N>1 (BASELINE.json configs[3], weak scaling): the (yh,xh) plane is tiled 1x2 / 2x2 / 2x4 over
+the ranks and every rank holds 150*N time steps of its tile resident (N=8: the 1200-step record
+on 360x540 tiles, 279.9 GB of the card's 288 GiB), walked in 5 time chunks: K1 per chunk and ONE
+asynchronous RCCL all-reduce of the chunk's masso(t) (+ volo, masso0, sum(area) in the first)
+overlapping the next chunk's kernel; value = all ranks' cells / max-over-ranks time.
 
 Besides the contract fields the JSON line carries
   roofline     -- K1 (k_steric_global): 16 algorithmic bytes per cell x cells per launch /
