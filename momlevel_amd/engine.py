@@ -130,8 +130,13 @@ class TimeChunks:
             return src.to(device=self.device, dtype=dt)
         host = _host_tensor(src, np.float32 if dt == torch.float32 else np.float64)
         dev = torch.empty(host.shape, dtype=dt, device=self.device)
-        if self._copy_stream is not None and os.environ.get("MOMLEVEL_AMD_ASYNC_H2D", "1") != "0":
-            ptr, nbytes = host.data_ptr(), host.numel() * host.element_size()
+        ptr, nbytes = host.data_ptr(), host.numel() * host.element_size()
+        # In-place page-locking pays (and is exercised) only for real chunks: a copy of less than
+        # a MiB is latency-bound either way, and small numpy arrays share heap pages with other
+        # objects -- they are not worth a register/unregister round trip through the driver.
+        min_bytes = int(os.environ.get("MOMLEVEL_AMD_ASYNC_H2D_MIN_BYTES", str(1 << 20)))
+        if (self._copy_stream is not None and nbytes >= min_bytes
+                and os.environ.get("MOMLEVEL_AMD_ASYNC_H2D", "1") != "0"):
             try:
                 rc = torch.cuda.cudart().cudaHostRegister(ptr, nbytes, 0)
             except RuntimeError:

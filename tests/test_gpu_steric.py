@@ -415,6 +415,40 @@ def test_memory_mapped_inputs_stream_from_disk(tmp_path, monkeypatch):
     assert_bit_equal(gres["steric"].values, gbase["steric"].values)
 
 
+def test_async_uploads_of_page_locked_chunks(monkeypatch):
+    """chunks of >= 1 MiB are page-locked in place and uploaded on the copy stream while the
+    previous chunk's kernels run (engine.TimeChunks); smaller ones go through a plain copy.  Same
+    bits either way."""
+    from momlevel_amd import engine
+
+    d = _masked_dataset(nt=6, nz=12, ny=64, nx=96)  # 590 KB per step and field
+    registered = []
+    real_upload = engine.TimeChunks._upload
+
+    def spy(self, f, t0, t1):
+        before = len(self._registered)
+        out = real_upload(self, f, t0, t1)
+        registered.append(len(self._registered) > before)
+        return out
+
+    monkeypatch.setattr(engine.TimeChunks, "_upload", spy)
+    monkeypatch.setattr(engine, "chunk_steps", lambda nt, b, dev, budget_bytes=None: 2)
+    res, _ = steric(d)
+    assert registered and all(registered)  # 1.18 MB chunks: the asynchronous path
+    registered.clear()
+    monkeypatch.setenv("MOMLEVEL_AMD_ASYNC_H2D", "0")
+    plain, _ = steric(d)
+    assert registered and not any(registered)
+    assert_bit_equal(res["steric"].values, plain["steric"].values)
+    assert_bit_equal(res["delta_rho"].values, plain["delta_rho"].values)
+    registered.clear()
+    monkeypatch.delenv("MOMLEVEL_AMD_ASYNC_H2D")
+    monkeypatch.setattr(engine, "chunk_steps", lambda nt, b, dev, budget_bytes=None: 1)
+    small, _ = steric(d)  # 590 KB chunks stay below the 1 MiB threshold
+    assert registered and not any(registered)
+    assert_bit_equal(small["steric"].values, plain["steric"].values)
+
+
 @pytest.mark.parametrize("domain", ["local", "global"])
 def test_steric_variants_extension_matches_single_calls(domain, monkeypatch):
     """One upload of theta/S, three variants: each bit-identical to its own steric() call."""
