@@ -1,0 +1,180 @@
+"""ctypes binding of oracle/libmomlevel_host.so, the HOST build of the C ABI.  TEST INFRASTRUCTURE ONLY.
+
+Same symbols and argument lists as libmomlevel_hip.so (the table is the product's own
+``momlevel_amd._lib.SIGNATURES``), host pointers instead of device pointers.  The numpy wrappers
+below exist for the tests; nothing under momlevel_amd/ imports this module.
+"""
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from momlevel_amd import _lib as abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libmomlevel_host.so")
+_DT = {np.dtype("float64"): abi.DTYPE_F64, np.dtype("float32"): abi.DTYPE_F32}
+F32_MODES = {"faithful": abi.DTYPE_F32, "upcast": abi.DTYPE_F32_UPCAST}
+
+
+def build(force=False):
+    deps = [os.path.join(HERE, "host_abi.c"), os.path.join(HERE, "..", "include", "momlevel_hip.h")]
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(map(os.path.getmtime, deps)):
+        subprocess.run(["make", "-C", HERE, "-B", "libmomlevel_host.so"], check=True,
+                       capture_output=True)
+    return LIB
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        build()
+        lib = ctypes.CDLL(LIB)
+        for name, (restype, argtypes) in abi.SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError = the host build misses a symbol of the ABI
+            fn.restype, fn.argtypes = restype, argtypes
+        if lib.mlx_version() != abi.ABI_VERSION:
+            raise RuntimeError("host ABI build is out of date: make -C oracle -B")
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    load().mlx_last_error(buf, 512)
+    return buf.value.decode()
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data
+
+
+def _c(a, dtype=None):
+    return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+
+def _pair(T, S, f32_mode):
+    T, S = _c(T), _c(S)
+    assert T.dtype == S.dtype and T.dtype in _DT
+    nz, ny, nx = T.shape[-3:]
+    nt = max(T.shape[0] if T.ndim == 4 else 1, S.shape[0] if S.ndim == 4 else 1)
+    n3 = nz * ny * nx
+    sT = n3 if T.ndim == 4 else 0
+    sS = n3 if S.ndim == 4 else 0
+    dt = abi.DTYPE_F64 if T.dtype == np.float64 else F32_MODES[f32_mode]
+    return T, S, nt, nz, ny, nx, sT, sS, dt
+
+
+def _pressure(p, nt, nz, ny, nx):
+    p = np.asarray(p, dtype=np.float64)
+    if p.size == 1:
+        return _c(p.reshape(1)), abi.P_SCALAR
+    if p.shape in ((nz,), (nz, 1, 1)):
+        return _c(p.reshape(nz)), abi.P_ZPROF
+    if p.ndim <= 3:
+        return _c(np.broadcast_to(p, (nz, ny, nx))), abi.P_FULL3D
+    return _c(np.broadcast_to(p, (nt, nz, ny, nx))), abi.P_FULL4D
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} -> {rc}: {last_error()}")
+
+
+def eos_map(T, S, p, eos="wright", func="density", f32_mode="faithful"):
+    T, S, nt, nz, ny, nx, sT, sS, dt = _pair(T, S, f32_mode)
+    pp, pm = _pressure(p, nt, nz, ny, nx)
+    out = np.empty((nt, nz, ny, nx))
+    _check(load().mlx_eos_map(_p(T), _p(S), dt, _p(pp), pm, abi.EOS_IDS[eos], abi.FUNC_IDS[func],
+                              nt, nz, ny * nx, sT, sS, 0, _p(out), None), "mlx_eos_map")
+    return out
+
+
+def steric_global(T, S, vol0, p, eos="wright", f32_mode="faithful", flags=0):
+    T, S, nt, nz, ny, nx, sT, sS, dt = _pair(T, S, f32_mode)
+    pp, pm = _pressure(p, nt, nz, ny, nx)
+    vol0 = _c(vol0, np.float64)
+    out = np.empty(nt)
+    _check(load().mlx_steric_global(_p(T), _p(S), dt, _p(vol0), _p(pp), pm, abi.EOS_IDS[eos], nt, nz,
+                                    ny * nx, sT, sS, flags, _p(out), None, 0, None),
+           "mlx_steric_global")
+    return out
+
+
+def steric_global_decomp(T, S, T0, S0, vol0, p, eos="wright", f32_mode="faithful"):
+    T, S, nt, nz, ny, nx, sT, sS, dt = _pair(T, S, f32_mode)
+    pp, pm = _pressure(p, nt, nz, ny, nx)
+    vol0, T0, S0 = _c(vol0, np.float64), _c(T0, T.dtype), _c(S0, S.dtype)
+    out = np.empty((4, nt))
+    _check(load().mlx_steric_global_decomp(_p(T), _p(S), _p(T0), _p(S0), dt, _p(vol0), _p(pp), pm,
+                                           abi.EOS_IDS[eos], nt, nz, ny * nx, sT, sS, 0, _p(out),
+                                           None, 0, None), "mlx_steric_global_decomp")
+    return out
+
+
+def fold_mask(rho0, vol0):
+    rho0, vol0 = _c(rho0, np.float64), _c(vol0, np.float64)
+    out = np.empty_like(rho0)
+    _check(load().mlx_fold_mask(_p(rho0), _p(vol0), rho0.size, _p(out), None), "mlx_fold_mask")
+    return out
+
+
+def steric_local(T, S, rho0m, vol0_surface, p, neg_inv_rhozero, z_i=None, deptho=None, dz=None,
+                 eos="wright", f32_mode="faithful", want_delta_rho=True):
+    T, S, nt, nz, ny, nx, sT, sS, dt = _pair(T, S, f32_mode)
+    pp, pm = _pressure(p, nt, nz, ny, nx)
+    rho0m, surf = _c(rho0m, np.float64), _c(vol0_surface, np.float64)
+    dz, z_i, deptho = _c(dz, np.float64), _c(z_i, np.float64), _c(deptho, np.float64)
+    drho = np.empty((nt, nz, ny, nx)) if want_delta_rho else None
+    eta = np.empty((nt, ny, nx))
+    _check(load().mlx_steric_local(_p(T), _p(S), dt, _p(rho0m), _p(surf), _p(dz), _p(z_i), _p(deptho),
+                                   _p(pp), pm, abi.EOS_IDS[eos], float(neg_inv_rhozero), nt, nz,
+                                   ny * nx, sT, sS, 0, _p(drho), _p(eta), None), "mlx_steric_local")
+    return drho, eta
+
+
+def steric_local_decomp(T, S, T0, S0, rho0m, vol0_surface, p, neg_inv_rhozero, z_i=None,
+                        deptho=None, dz=None, eos="wright", f32_mode="faithful"):
+    T, S, nt, nz, ny, nx, sT, sS, dt = _pair(T, S, f32_mode)
+    pp, pm = _pressure(p, nt, nz, ny, nx)
+    rho0m, surf = _c(rho0m, np.float64), _c(vol0_surface, np.float64)
+    T0, S0 = _c(T0, T.dtype), _c(S0, S.dtype)
+    dz, z_i, deptho = _c(dz, np.float64), _c(z_i, np.float64), _c(deptho, np.float64)
+    drho = np.empty((3, nt, nz, ny, nx))
+    eta = np.empty((3, nt, ny, nx))
+    _check(load().mlx_steric_local_decomp(
+        _p(T), _p(S), _p(T0), _p(S0), dt, _p(rho0m), _p(surf), _p(dz), _p(z_i), _p(deptho), _p(pp),
+        pm, abi.EOS_IDS[eos], float(neg_inv_rhozero), nt, nz, ny * nx, sT, sS, 0, _p(drho),
+        drho[0].size, _p(eta), eta[0].size, None), "mlx_steric_local_decomp")
+    return drho, eta
+
+
+def nansum(x):
+    x = _c(x, np.float64)
+    out = np.empty(1)
+    _check(load().mlx_nansum(_p(x), x.size, _p(out), None, 0, None), "mlx_nansum")
+    return out[0]
+
+
+def calc_dz(z_i, depth, top=0.0, bottom=None, fraction=False):
+    z_i, depth = _c(z_i, np.float64), _c(depth, np.float64)
+    nz = z_i.size - 1
+    out = np.empty((nz,) + depth.shape)
+    _check(load().mlx_calc_dz(_p(z_i), _p(depth), nz, depth.size, float(top),
+                              0.0 if bottom is None else float(bottom), int(bottom is not None),
+                              int(bool(fraction)), _p(out), None), "mlx_calc_dz")
+    return out
+
+
+def group_weighted_mean(x, w, group_len):
+    x, w = _c(x, np.float64), _c(w, np.float64)
+    ngroups = x.shape[0] // group_len
+    out = np.empty((ngroups,) + x.shape[1:])
+    _check(load().mlx_group_weighted_mean(_p(x), _p(w), ngroups, group_len, x[0].size, _p(out), None),
+           "mlx_group_weighted_mean")
+    return out

@@ -23,7 +23,7 @@ MODULES = [
     "momlevel_amd.adapters", "momlevel_amd.synthetic", "momlevel_amd.test_data",
     "momlevel_amd.cftime_lite", "momlevel_amd.eos._dispatch", "momlevel_amd.eos.wright",
     "momlevel_amd.eos.linear", "momlevel_amd.csrc.build", "oracle.momlevel_numpy",
-    "oracle.wright_c", "oracle.cpu_worker",
+    "oracle.wright_c", "oracle.cpu_worker", "oracle.host_abi",
 ]
 FILES = ["bench.py", "__graft_entry__.py"]
 
