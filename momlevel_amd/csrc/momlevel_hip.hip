@@ -117,10 +117,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 // ------------------------------------------------------------------------------------
 // K1: fused EOS + rho*vol0 + per-time-step sum over the block's cells.
 //
-// Work item = (time chunk, z level, tile of kBlock*VEC*U cells); a persistent grid walks the list
-// (see the kernel body).  Within an item each thread owns U packs of VEC adjacent cells of ONE z
-// level, keeps their vol0 (and p, if FULL3D) in registers and loops over the time steps of the
-// chunk.  Per time step it parks its partial in LDS row
+// grid = (ceil(plane / (kBlock*VEC*U)), nz, ceil(nt/t_chunk)); each thread owns U packs of
+// VEC adjacent cells of ONE z level, keeps their vol0 (and p, if FULL3D) in registers and
+// loops over the time steps of its chunk.  Per time step it parks its partial in LDS row
 // (t - chunk start) % NTC; every NTC steps the block reduces the parked rows (fixed order) and
 // writes partials[t][block].  A second kernel (k_reduce_rows) sums partials[t][:] in a fixed
 // order -> masso[t].
@@ -148,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
     const TIn* __restrict__ T, const TIn* __restrict__ S, const TIn* __restrict__ T0,
     const TIn* __restrict__ S0, const double* __restrict__ vol0, const double* __restrict__ p,
     int p_mode, int eos, int nt, int t_chunk, int64_t plane, int64_t t_stride_T,
-    int64_t t_stride_S, double* __restrict__ partials, int64_t tiles_x, int nz) {
+    int64_t t_stride_S, double* __restrict__ partials, int64_t nblk_total) {
   constexpr int NOUT = (VAR == kVarAll) ? 4 : 1;
   constexpr int NTC = (VAR == kVarAll) ? kNTC / 2 : kNTC;  // LDS: NOUT*NTC*kBlock doubles
   constexpr bool STREAM_T = (VAR != kVarHalo), STREAM_S = (VAR != kVarThermo);
@@ -160,26 +159,15 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
   __shared__ double red[NOUT][NTC][kBlock];
 
   const int tid = threadIdx.x;
-  // PERSISTENT grid: as many blocks as the chip holds at once (CUs x resident blocks per CU), each
-  // walking the work list  w = chunk * (nz * tiles_x) + z * tiles_x + tile  with stride gridDim.x.
-  // Streaming kernels on this chip lose 5-10 % to block turnover when tens of thousands of short
-  // blocks are dispatched (scripts/tune_streams.hip: the same two-stream loop reads 5.8 TB/s as a
-  // 228k-block grid and 6.76 TB/s as 1024 persistent blocks).  Time chunks are the slowest index:
-  // the resident blocks all work inside one window of t_chunk time steps instead of drifting over
-  // the whole record, at the price of re-reading vol0 once per chunk.  Blocks of one XCD (b % 8)
-  // cover a contiguous eighth of every window of gridDim.x tiles (xcd_remap).  No block waits for
-  // another; every wave leaves the loop when the list is exhausted.
-  const int64_t ntiles = tiles_x * nz;
-  const int64_t nblk_total = ntiles;  // partial slot = tile position: results do not depend on
-                                      // which block processed which tile
-  const int64_t nwork = ntiles * ((nt + t_chunk - 1) / t_chunk);
-  for (int64_t w = xcd_remap(blockIdx.x, gridDim.x); w < nwork; w += gridDim.x) {
-  const int64_t chunk = w / ntiles;
-  const int64_t blk = w - chunk * ntiles;
-  const int z = (int)(blk / tiles_x);
-  const int64_t bx = blk - (int64_t)z * tiles_x;
-  const int tb = (int)chunk * t_chunk;
+  const int z = blockIdx.y;
+  const int nz = gridDim.y;
+  // blockIdx.z = time chunk (slowest grid dimension): the resident blocks all work inside one
+  // window of t_chunk time steps instead of drifting over the whole record (+3.7 % measured
+  // at nt=120, scripts/tune_k1.hip), at the price of re-reading vol0 once per chunk.
+  const int tb = blockIdx.z * t_chunk;
   const int te = (tb + t_chunk < nt) ? (tb + t_chunk) : nt;
+  const int64_t bx = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t blk = (int64_t)blockIdx.y * gridDim.x + bx;  // partial slot = tile position
   const int64_t tile0 = bx * (kBlock * VEC * U);
   const int64_t zoff = (int64_t)z * plane;
 
@@ -346,7 +334,6 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
       __syncthreads();
     }
   }
-  }  // work list
 }
 
 // partials[row][0..n) -> out[row]; one block per row, fixed order
@@ -512,8 +499,7 @@ __device__ __forceinline__ double dz_default(double depth, double ztop, double z
 // ------------------------------------------------------------------------------------
 // K2: fused EOS + delta_rho + dz-weighted column integral.
 //
-// Work item = (chunk of NTI time steps, tile of kBlock*VEC columns); persistent grid as in K1.
-// A thread owns VEC adjacent columns
+// grid = (ceil(plane/(kBlock*VEC)), ceil(nt/NTI)).  A thread owns VEC adjacent columns
 // and NTI consecutive time steps: z is the outer (sequential, as numpy's axis reduce)
 // loop, the NTI time steps are unrolled inside it with their column sums in registers,
 // so rho0m / dz are read once per z and reused NTI times.  NTI*VEC = 32 column sums per
@@ -535,8 +521,7 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
     const double* __restrict__ z_i, const double* __restrict__ deptho,
     const double* __restrict__ p, int p_mode, int eos, double neg_inv_rhozero, int nt, int nz,
     int64_t plane, int64_t t_stride_T, int64_t t_stride_S, double* __restrict__ drho_out,
-    int64_t drho_vstride, double* __restrict__ eta_out, int64_t eta_vstride, int64_t tiles_x,
-    int64_t nwork) {
+    int64_t drho_vstride, double* __restrict__ eta_out, int64_t eta_vstride) {
   constexpr int NOUT = (VAR == kVarAll) ? 3 : 1;
   constexpr bool STREAM_T = (VAR != kVarHalo), STREAM_S = (VAR != kVarThermo);
   constexpr bool HELD_T = (VAR == kVarHalo || VAR == kVarAll);
@@ -544,14 +529,10 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
   typedef typename PolyType<MODE>::type R;
   typedef typename std::conditional<FMA, FusedOps, ExactOps>::type Ops;
   static_assert(!FMA || MODE != kF32Faithful, "fused arithmetic is float64");
+  const int64_t col = (xcd_remap(blockIdx.x, gridDim.x) * kBlock + threadIdx.x) * VEC;
+  if (col + VEC > plane) return;  // whole packs only; no barrier below
+  const int t0 = blockIdx.y * NTI;
   const int64_t n3 = (int64_t)nz * plane;
-  // PERSISTENT grid (see K1): work item w = (time chunk of NTI steps) * tiles_x + column tile,
-  // column tiles fastest; no barrier anywhere, so a thread past the plane just skips the item
-  for (int64_t w = xcd_remap(blockIdx.x, gridDim.x); w < nwork; w += gridDim.x) {
-  const int64_t wt = w / tiles_x;
-  const int64_t col = ((w - wt * tiles_x) * kBlock + threadIdx.x) * VEC;
-  if (col + VEC > plane) continue;  // whole packs only
-  const int t0 = (int)wt * NTI;
 
   double acc[NOUT][NTI][VEC];
 #pragma unroll
@@ -692,7 +673,6 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
       }
     }
   }
-  }  // work list
 }
 
 // util.annual_average core (util.py:85-92): weighted mean over groups of L consecutive steps.
@@ -880,48 +860,22 @@ bool fast_layout(int dtype, int p_mode, int eos, int64_t plane, int64_t sT, int6
 
 // ---- K1 dispatch -------------------------------------------------------------------------
 struct K1Args {
+  dim3 grid;
   hipStream_t st;
   const void *T, *S, *T0, *S0;
   const double *vol0, *p;
   int p_mode, eos, nt, t_chunk;
   int64_t plane, sT, sS;
   double* partials;
-  int64_t tiles_x, nwork;
-  int nz;
+  int64_t nblk;
 };
-
-// CUs of the current device (256 on MI355X); 0 without a device (the launch then fails anyway)
-int device_cus() {
-  int dev = 0, n = 0;
-  if (hipGetDevice(&dev) != hipSuccess ||
-      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-    n = 0;
-  (void)hipGetLastError();
-  return n;
-}
-
-// persistent grid: blocks the chip holds at once for this kernel, capped by the work list
-template <typename Kernel>
-unsigned persistent_blocks(Kernel kernel, int64_t nwork, int fallback_per_cu) {
-  int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess ||
-      per_cu <= 0)
-    per_cu = fallback_per_cu;
-  (void)hipGetLastError();
-  int cus = device_cus();
-  if (cus <= 0) cus = 256;
-  const int64_t g = (int64_t)cus * per_cu;
-  return (unsigned)(nwork < g ? nwork : g);
-}
 
 template <typename TIn, int VEC, int U, int VAR, int MODE, bool GEN, bool SKIP, bool FMA>
 void k1_go(const K1Args& a) {
-  auto kernel = k_steric_global<TIn, VEC, U, VAR, MODE, GEN, SKIP, FMA>;
-  static const unsigned resident = persistent_blocks(kernel, INT64_MAX, 4);  // per instantiation
-  const unsigned grid = (unsigned)(a.nwork < (int64_t)resident ? a.nwork : resident);
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, a.st, (const TIn*)a.T, (const TIn*)a.S,
-                     (const TIn*)a.T0, (const TIn*)a.S0, a.vol0, a.p, a.p_mode, a.eos, a.nt,
-                     a.t_chunk, a.plane, a.sT, a.sS, a.partials, a.tiles_x, a.nz);
+  hipLaunchKernelGGL((k_steric_global<TIn, VEC, U, VAR, MODE, GEN, SKIP, FMA>), a.grid,
+                     dim3(kBlock), 0, a.st, (const TIn*)a.T, (const TIn*)a.S, (const TIn*)a.T0,
+                     (const TIn*)a.S0, a.vol0, a.p, a.p_mode, a.eos, a.nt, a.t_chunk, a.plane,
+                     a.sT, a.sS, a.partials, a.nblk);
 }
 
 template <typename TIn, int VEC, int U, int VAR, int MODE, bool GEN>
@@ -1007,26 +961,25 @@ int steric_global_impl(const void* T, const void* S, const void* T0, const void*
   K1Args a;
   const int64_t gx = k1_blocks(fast, dtype, plane);
   a.t_chunk = k1_time_chunk(flags, nt, var);
-  int64_t ntiles;
-  if (!mul_fits(gx, nz, &ntiles) || !mul_fits(ntiles, ceil_div(nt, a.t_chunk), &a.nwork))
-    return fail(MLX_E_SHAPE, "grid too large");
-  a.tiles_x = gx;
-  a.nz = (int)nz;
+  if (ceil_div(nt, a.t_chunk) > 65535) return fail(MLX_E_SHAPE, "nt too large for one call: chunk it");
+  if (gx > 2147483647LL) return fail(MLX_E_SHAPE, "plane too large");
+  a.grid = dim3((unsigned)gx, (unsigned)nz, (unsigned)ceil_div(nt, a.t_chunk));
   a.st = (hipStream_t)stream;
   a.T = T; a.S = S; a.T0 = T0 ? T0 : T; a.S0 = S0 ? S0 : S;
   a.vol0 = vol0; a.p = p ? p : vol0;  // p is never dereferenced for the linear EOS
   a.p_mode = p_mode; a.eos = eos; a.nt = (int)nt;
   a.plane = plane; a.sT = sT; a.sS = sS;
-  a.partials = (double*)workspace;
+  a.partials = (double*)workspace; a.nblk = gx * nz;
   k1_dispatch(a, dtype, fast, var, skip, fma);
   if (int rc = hip_status(hipGetLastError(), name)) return rc;
   hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)(nout * nt)), dim3(kBlock), 0, a.st,
-                     a.partials, ntiles, out);
+                     a.partials, a.nblk, out);
   return hip_status(hipGetLastError(), "k_reduce_rows launch");
 }
 
 // ---- K2 dispatch -------------------------------------------------------------------------
 struct K2Args {
+  dim3 grid;
   hipStream_t st;
   const void *T, *S, *T0, *S0;
   const double *rho0m, *surf, *dz, *z_i, *deptho, *p;
@@ -1035,18 +988,15 @@ struct K2Args {
   int64_t plane, sT, sS;
   double *drho, *eta;
   int64_t drho_vstride, eta_vstride;
-  int64_t tiles_x, nwork;
 };
 
 template <typename TIn, int VEC, int NTI, int VAR, int MODE, bool GEN, bool SKIP, bool FMA>
 void k2_go(const K2Args& a) {
-  auto kernel = k_steric_local<TIn, VEC, NTI, VAR, MODE, GEN, SKIP, FMA>;
-  static const unsigned resident = persistent_blocks(kernel, INT64_MAX, 2);  // per instantiation
-  const unsigned grid = (unsigned)(a.nwork < (int64_t)resident ? a.nwork : resident);
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, a.st, (const TIn*)a.T, (const TIn*)a.S,
-                     (const TIn*)a.T0, (const TIn*)a.S0, a.rho0m, a.surf, a.dz, a.z_i, a.deptho, a.p,
-                     a.p_mode, a.eos, a.neg_inv_rhozero, a.nt, a.nz, a.plane, a.sT, a.sS, a.drho,
-                     a.drho_vstride, a.eta, a.eta_vstride, a.tiles_x, a.nwork);
+  hipLaunchKernelGGL((k_steric_local<TIn, VEC, NTI, VAR, MODE, GEN, SKIP, FMA>), a.grid,
+                     dim3(kBlock), 0, a.st, (const TIn*)a.T, (const TIn*)a.S, (const TIn*)a.T0,
+                     (const TIn*)a.S0, a.rho0m, a.surf, a.dz, a.z_i, a.deptho, a.p, a.p_mode, a.eos,
+                     a.neg_inv_rhozero, a.nt, a.nz, a.plane, a.sT, a.sS, a.drho, a.drho_vstride,
+                     a.eta, a.eta_vstride);
 }
 
 template <typename TIn, int VEC, int NTI, int VAR, int MODE, bool GEN>
@@ -1123,10 +1073,11 @@ int steric_local_impl(const void* T, const void* S, const void* T0, const void* 
   const int v = !fast ? 1 : ((var == kVarAll && !f64) ? kVec32All : vec_of(dtype));
   const int nti = (var == kVarAll) ? (fast ? (f64 ? kNTI64All : kNTI32All) : kNTIGenAll)
                                    : (fast ? (f64 ? kNTI64 : kNTI32) : kNTIGen);
+  if (ceil_div(nt, nti) > 65535) return fail(MLX_E_SHAPE, "nt too large for one call: chunk it");
   const int64_t gx = ceil_div(plane, (int64_t)kBlock * v);
+  if (gx > 2147483647LL) return fail(MLX_E_SHAPE, "plane too large");
   K2Args a;
-  if (!mul_fits(gx, ceil_div(nt, nti), &a.nwork)) return fail(MLX_E_SHAPE, "grid too large");
-  a.tiles_x = gx;
+  a.grid = dim3((unsigned)gx, (unsigned)ceil_div(nt, nti));
   a.st = (hipStream_t)stream;
   a.T = T; a.S = S; a.T0 = T0 ? T0 : T; a.S0 = S0 ? S0 : S;
   a.rho0m = rho0m; a.surf = vol0_surface; a.dz = dz; a.z_i = z_i;
@@ -1318,11 +1269,9 @@ int mlx_steric_local_decomp(const void* T, const void* S, const void* T0, const 
 }
 
 // ---------------------------------------------------------------------------- sums
-// grid-stride sums stream fastest from about 8 blocks per CU (scripts/tune_streams.hip: one stream
-// reads 6.96 TB/s from 2048 blocks, 6.2 from 8192, 5.8 from 32768)
 static int64_t nansum_blocks(int64_t n) {
   const int64_t b = ceil_div(n, (int64_t)kBlock * 8);
-  return b < 1 ? 1 : (b > 2048 ? 2048 : b);
+  return b < 1 ? 1 : (b > 8192 ? 8192 : b);
 }
 
 size_t mlx_nansum_workspace_bytes(int64_t n) {
@@ -1407,7 +1356,7 @@ int mlx_stream_probe(const double* a, const double* b, int64_t n, double* out, v
   if (!aligned(a, 16) || !aligned(b, 16) || !aligned(out, 16))
     return fail(MLX_E_ALIGN, "operands must be 16-byte aligned");
   const int64_t want = ceil_div(n / 2, kBlock);
-  hipLaunchKernelGGL(k_stream_probe, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(kBlock), 0,
+  hipLaunchKernelGGL(k_stream_probe, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(kBlock), 0,
                      (hipStream_t)stream, a, b, n / 2, out);
   return hip_status(hipGetLastError(), "k_stream_probe launch");
 }

@@ -96,11 +96,22 @@ __global__ __launch_bounds__(256) void kE(const double* T, const double* S, int 
   }
   c = wsum(c); if ((threadIdx.x & 63) == 0) atomicAdd(out, c);
 }
-int main() {
+__global__ void kfill(double* x, int64_t n, unsigned long long seed) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    unsigned long long z = seed + (unsigned long long)i * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; z ^= z >> 31;
+    x[i] = -2.0 + 34.0 * ((double)(z >> 11) * 0x1.0p-53);
+  }
+}
+int main(int argc, char** argv) {
+  const bool zeros = argc > 1 && argv[1][0] == 'z';
   const int nt = 56, nz = 75; const int64_t plane = 1080 * 1440, n3 = nz * plane, n = (int64_t)nt * n3;
   double *T, *S, *out;
   CK(hipMalloc(&T, n * 8)); CK(hipMalloc(&S, n * 8)); CK(hipMalloc(&out, 8));
-  CK(hipMemset(T, 0, n * 8)); CK(hipMemset(S, 0, n * 8)); CK(hipMemset(out, 0, 8));
+  CK(hipMemset(out, 0, 8));
+  if (zeros) { CK(hipMemset(T, 0, n * 8)); CK(hipMemset(S, 0, n * 8)); }
+  else { hipLaunchKernelGGL(kfill, dim3(16384), dim3(256), 0, 0, T, n, 1ULL); hipLaunchKernelGGL(kfill, dim3(16384), dim3(256), 0, 0, S, n, 2ULL); CK(hipDeviceSynchronize()); }
+  printf("# data: %s\n", zeros ? "all zeros" : "random doubles");
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto run = [&](const char* name, double bytes, auto launch) {
     float best = 1e30f;
