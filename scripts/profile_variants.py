@@ -42,7 +42,8 @@ def main():
     dep = torch.from_numpy(g["deptho"]).cuda()
     drho = torch.empty(shape, dtype=torch.float64, device="cuda")
     eta = torch.empty((nt, ny, nx), dtype=torch.float64, device="cuda")
-    rho = drho  # K0 output buffer (same size)
+    d3 = torch.empty((3,) + shape, dtype=torch.float64, device="cuda")
+    e3 = torch.empty((3, nt, ny, nx), dtype=torch.float64, device="cuda")
     cells = nt * nz * ny * nx
     k1 = lambda a, b, **kw: core.steric_global_masso(a, b, vol0, pres, skip_dry=False, **kw)  # noqa: E731
     dec = lambda **kw: core.steric_global_decomp(T, S, T[0], S[0], vol0, pres, skip_dry=False, **kw)  # noqa: E731
@@ -67,6 +68,10 @@ def main():
          lambda: dec(arith="fused")),
         ("K2 local eta only", 2 * B, "k_steric_local", lambda: k2(False)),
         ("K2 local + delta_rho", 2 * B + 8, "k_steric_local", lambda: k2(True)),
+        ("K2 all variants, one pass (3 x delta_rho + eta)", 2 * B + 24, "k_steric_local",
+         lambda: core.steric_local_decomp(T, S, T[0], S[0], rho0m, vol0[0], pres, -1.0 / 1035.0,
+                                          z_i=zi, deptho=dep, delta_rho_out=d3, eta_out=e3,
+                                          skip_dry=False)),
         ("K1 steric, dry lines skipped", 2 * B, "k_steric_global",
          lambda: core.steric_global_masso(T, S, vol0, pres, skip_dry=True)),
         ("K2 local + delta_rho, dry lines skipped", 2 * B + 8, "k_steric_local",
