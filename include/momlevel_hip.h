@@ -98,7 +98,8 @@ int mlx_last_error(char *buf, size_t n);
 
 /* ---------------------------------------------------------------------------------
  * K0  pointwise EOS map.  Replaces eos.wright.density/drho_dtemp/drho_dsal/alpha/beta
- * (src/momlevel/eos/wright.py:23-165), eos.linear.density (eos/linear.py:26-58) and
+ * (src/momlevel/eos/wright.py:23-165), eos.linear.density/alpha/beta and its constant
+ * derivatives (eos/linear.py:26-162) and
  * the apply_ufunc in derived.calc_rho (src/momlevel/derived.py:621-630).
  * out[t,z,i] = f(T[t*t_stride_T + z*plane + i], S[t*t_stride_S + z*plane + i], p).
  * t_stride_* == 0 broadcasts a (z,y,x) field over time (the held field of the

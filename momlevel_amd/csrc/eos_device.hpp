@@ -250,6 +250,25 @@ __device__ __forceinline__ double linear_density(TIn Tin, TIn Sin) {
   }
 }
 
+// the linear EOS's other functions, eos/linear.py:61-162: the derivatives are the constants
+// DRHO_DT = -0.2 and DRHO_DS = 0.8; alpha = -1.0 * (full_like(T, DRHO_DT) / density),
+// beta = full_like(T, DRHO_DS) / density -- full_like(T) takes T's dtype, so on float32 input the
+// whole quotient is float32 (correctly rounded float32 division: hipcc's default)
+template <int MODE, typename TIn>
+__device__ __forceinline__ double linear_func(int func, TIn Tin, TIn Sin) {
+  if (func == kDrhoDtemp) return -0.2;
+  if (func == kDrhoDsal) return 0.8;
+  if constexpr (MODE == kF32Faithful) {
+    const float rho = 1000.0f + ((-0.2f * Tin) + (0.8f * Sin));
+    if (func == kAlpha) return (double)(-1.0f * (-0.2f / rho));
+    return (double)(0.8f / rho);
+  } else {
+    const double rho = linear_density<MODE, TIn>(Tin, Sin);
+    if (func == kAlpha) return -1.0 * (-0.2 / rho);
+    return 0.8 / rho;
+  }
+}
+
 // runtime-dispatched EOS function (generic kernels; eos/func are wave-uniform)
 // Ops applies to the Wright DENSITY only (the one function on the steric path); the derivatives
 // and the linear EOS are always evaluated exactly.
@@ -262,7 +281,8 @@ __device__ __forceinline__ double eos_eval(int eos, int func, TIn T, TIn S, doub
     return p * (-1.0 / (rho * aux));
   }
   if (eos == kLinear) {
-    return linear_density<MODE, TIn>(T, S);
+    if (func == kDensity) return linear_density<MODE, TIn>(T, S);
+    return linear_func<MODE, TIn>(func, T, S);
   }
   switch (func) {
     case kDensity:

@@ -1121,8 +1121,6 @@ static int eos_map_impl(const void* T, const void* S, int dtype, const double* p
   if (!out) return fail(MLX_E_NULL, "out must not be NULL");
   if (!aligned(out, 8)) return fail(MLX_E_ALIGN, "out not 8-byte aligned");
   if (func < MLX_FUNC_DENSITY || func > MLX_FUNC_IBH) return fail(MLX_E_ENUM, "unknown func");
-  if (eos == MLX_EOS_LINEAR && func != MLX_FUNC_DENSITY && func != MLX_FUNC_IBH)
-    return fail(MLX_E_ENUM, "the linear EOS kernel provides density only");
   if (func == MLX_FUNC_IBH && !p) return fail(MLX_E_NULL, "p must not be NULL");
   const bool fma = (flags & MLX_FLAG_FMA) != 0;
   if (fma && func != MLX_FUNC_DENSITY)

@@ -140,7 +140,17 @@ static inline double eos_eval(int eos, int func, Val T, Val S, double p, double 
     const double rho = (eos == MLX_EOS_LINEAR) ? linear_density(T, S) : density(T, S, p);
     return p * (-1.0 / (rho * aux));
   }
-  if (eos == MLX_EOS_LINEAR) return linear_density(T, S);
+  if (eos == MLX_EOS_LINEAR) { /* eos/linear.py:61-162 */
+    if (func == MLX_FUNC_DENSITY) return linear_density(T, S);
+    if (func == MLX_FUNC_DRHO_DTEMP) return -0.2;
+    if (func == MLX_FUNC_DRHO_DSAL) return 0.8;
+    if (T.is_f32_faithful) { /* full_like(T) is float32: the whole quotient stays float32 */
+      const float rho = 1000.0f + ((-0.2f * T.f) + (0.8f * S.f));
+      return (func == MLX_FUNC_ALPHA) ? (double)(-1.0f * (-0.2f / rho)) : (double)(0.8f / rho);
+    }
+    const double rho = linear_density(T, S);
+    return (func == MLX_FUNC_ALPHA) ? -1.0 * (-0.2 / rho) : 0.8 / rho;
+  }
   switch (func) {
     case MLX_FUNC_DENSITY: return density(T, S, p);
     case MLX_FUNC_DRHO_DTEMP: return drho_dtemp(T, S, p);
@@ -194,8 +204,6 @@ static int eos_map_impl(const void *T, const void *S, int dtype, const double *p
   if (rc) return rc;
   if (!out) return fail(MLX_E_NULL, "out must not be NULL");
   if (func < MLX_FUNC_DENSITY || func > MLX_FUNC_IBH) return fail(MLX_E_ENUM, "unknown func");
-  if (eos == MLX_EOS_LINEAR && func != MLX_FUNC_DENSITY && func != MLX_FUNC_IBH)
-    return fail(MLX_E_ENUM, "the linear EOS kernel provides density only");
   const double zero = 0.0;
   const double *pp = p ? p : &zero;
   const int pm = p ? p_mode : MLX_P_SCALAR;

@@ -99,6 +99,26 @@ def linear_density(T, S, p=None):
     return rho + ((LIN_DRHO_DT * T) + (LIN_DRHO_DS * S))
 
 
+def linear_drho_dtemp(T=None, S=None, p=None):
+    """src/momlevel/eos/linear.py:61-84: the constant DRHO_DT."""
+    return LIN_DRHO_DT
+
+
+def linear_drho_dsal(T=None, S=None, p=None):
+    """src/momlevel/eos/linear.py:87-110: the constant DRHO_DS."""
+    return LIN_DRHO_DS
+
+
+def linear_alpha(T, S, p=None):
+    """src/momlevel/eos/linear.py:113-136."""
+    return -1.0 * (np.full_like(T, fill_value=LIN_DRHO_DT) / linear_density(T, S, p))
+
+
+def linear_beta(T, S, p=None):
+    """src/momlevel/eos/linear.py:139-162."""
+    return np.full_like(T, fill_value=LIN_DRHO_DS) / linear_density(T, S, p)
+
+
 _EOS = {
     "wright": {
         "density": wright_density,
@@ -107,7 +127,13 @@ _EOS = {
         "alpha": wright_alpha,
         "beta": wright_beta,
     },
-    "linear": {"density": linear_density},
+    "linear": {
+        "density": linear_density,
+        "drho_dtemp": linear_drho_dtemp,
+        "drho_dsal": linear_drho_dsal,
+        "alpha": linear_alpha,
+        "beta": linear_beta,
+    },
 }
 
 

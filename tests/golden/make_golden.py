@@ -33,10 +33,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 REF_WRIGHT = "/root/reference/src/momlevel/eos/wright.py"
+REF_LINEAR = "/root/reference/src/momlevel/eos/linear.py"  # imports numpy only
 
 
 def load_reference_wright():
     spec = importlib.util.spec_from_file_location("ref_wright", REF_WRIGHT)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_reference_linear():
+    spec = importlib.util.spec_from_file_location("ref_linear", REF_LINEAR)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
@@ -98,6 +106,17 @@ def main():
     out["f64_density_heldT"] = ref.density(out["blk_T"][0], out["blk_S"], out["blk_p"])
     for k in ("f32_density_heldS", "f32_density_heldT", "f64_density_heldS", "f64_density_heldT"):
         assert out[k].dtype == np.float64 and out[k].shape == T32.shape
+
+    # (6) the linear EOS (src/momlevel/eos/linear.py:26-162) on the same inputs, float64 and float32
+    lin = load_reference_linear()
+    for tag, (T, S) in {"tw": (out["tw_T"], out["tw_S"]), "blk": (out["blk_T"], out["blk_S"]),
+                        "f32": (T32, S32)}.items():
+        out[f"lin_{tag}_density"] = lin.density(T, S)
+        out[f"lin_{tag}_alpha"] = lin.alpha(T, S, None)
+        out[f"lin_{tag}_beta"] = lin.beta(T, S, None)
+    assert out["lin_f32_alpha"].dtype == np.float32  # full_like(T) / density(T, S): float32 throughout
+    out["lin_scalar_out"] = np.array([lin.density(18.0, 35.0), lin.drho_dtemp(), lin.drho_dsal(),
+                                      lin.alpha(18.0, 35.0, None), lin.beta(18.0, 35.0, None)])
 
     # scalars of tests/test_wright.py:11-12,30-31,50-51,70-71,120-121
     out["scalar_args"] = np.array([18.0, 35.0, 200000.0])

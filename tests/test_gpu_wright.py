@@ -205,3 +205,42 @@ def test_4d_z_profile_takes_the_profile_kernel(monkeypatch):
     T = torch.rand((2, 3, 4, 8), dtype=torch.float64, device="cuda")
     pt, mode = core._pressure(np.arange(3.0).reshape(1, 3, 1, 1), 2, 3, 4, 8, T.device, True)
     assert mode == _lib.P_ZPROF and tuple(pt.shape) == (3,)
+
+
+# ---- the linear EOS, complete (reference tests/test_linear.py + the reference module's vectors) --
+def test_linear_eos_reference_tests(goldens):
+    g = goldens["linear"]
+    assert np.allclose(linear.density(18.0, 35.0, 200000.0), 1024.4)
+    assert np.allclose(linear.density(thetao, so, pressure), np.array(g["density_5x5"]))
+    assert np.allclose(linear.drho_dtemp(18.0, 35.0, 200000.0), -0.2)
+    assert np.allclose(linear.drho_dtemp(thetao, so, pressure), -0.2)
+    assert np.allclose(linear.drho_dsal(18.0, 35.0, 200000.0), 0.8)
+    assert np.allclose(linear.alpha(18.0, 35.0, 200000.0), 0.0001952362358453729)
+    assert np.allclose(linear.alpha(thetao, so, pressure), np.array(g["alpha_5x5"]))
+    assert np.allclose(linear.beta(18.0, 35.0, 200000.0), 0.0007809449433814916)
+    assert np.allclose(linear.beta(thetao, so, pressure), np.array(g["beta_5x5"]))
+
+
+@pytest.mark.parametrize("tag", ["tw", "blk", "f32"])
+@pytest.mark.parametrize("func", ["density", "alpha", "beta"])
+def test_linear_eos_bit_exact(wright_vectors, tag, func):
+    """bit for bit against the outputs of the reference's eos/linear.py, float64 and float32
+    (numpy: full_like(T) / density(T, S) stays float32; the kernel returns it widened)"""
+    v = wright_vectors
+    T, S = {"tw": ("tw_T", "tw_S"), "blk": ("blk_T", "blk_S"), "f32": ("f32_T", "f32_S")}[tag]
+    got = getattr(linear, func)(v[T], v[S], None)
+    assert_bit_equal(got, v[f"lin_{tag}_{func}"].astype(np.float64), f"linear {tag}/{func}")
+
+
+def test_calc_alpha_beta_with_the_linear_eos():
+    from momlevel_amd import derived
+    from momlevel_amd.labeled import DataArray
+
+    r = np.random.default_rng(2)
+    T = DataArray(r.uniform(0, 30, (3, 4, 5, 6)), ("time", "z_l", "yh", "xh"))
+    S = DataArray(r.uniform(30, 40, (3, 4, 5, 6)), ("time", "z_l", "yh", "xh"))
+    p = DataArray(np.linspace(1e5, 4e7, 4), ("z_l",))
+    a = derived.calc_alpha(T, S, p, eos="linear")
+    b = derived.calc_beta(T, S, p, eos="linear")
+    assert_bit_equal(a.values, o.linear_alpha(T.values, S.values))
+    assert_bit_equal(b.values, o.linear_beta(T.values, S.values))

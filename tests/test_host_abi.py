@@ -59,6 +59,17 @@ def test_float32_mixed_precision_and_held_fields(wright_vectors, func):
                                               v["blk_p"]))
 
 
+@pytest.mark.parametrize("func", ["density", "alpha", "beta", "drho_dtemp", "drho_dsal"])
+def test_linear_eos_bit_identical_to_reference_vectors(wright_vectors, func):
+    v = wright_vectors
+    for tag, (T, S) in {"blk": (v["blk_T"], v["blk_S"]), "f32": (v["f32_T"], v["f32_S"])}.items():
+        got = h.eos_map(T, S, 0.0, eos="linear", func=func)
+        if func in ("drho_dtemp", "drho_dsal"):
+            assert np.all(got == (-0.2 if func == "drho_dtemp" else 0.8))
+        else:
+            assert_bit_equal(got, v[f"lin_{tag}_{func}"].astype(np.float64), f"host linear {tag}/{func}")
+
+
 def _case(shape, dtype, seed=3):
     nt, nz, ny, nx = shape
     g = synthetic.make_grid(ny, nx, nz)

@@ -67,14 +67,16 @@ def test_validate_dataset_8():
 
 
 def test_eos_func_from_str_errors():
-    """unknown EOS -> ValueError (util.py:247); a function the EOS module lacks (linear alpha/beta,
-    eos/linear.py:61-162 is out of scope here) -> ValueError naming it, not a bare KeyError"""
+    """unknown EOS -> ValueError (util.py:247); a function the EOS module lacks -> ValueError
+    naming it, not the bare KeyError of the reference's __dict__ lookup"""
     with pytest.raises(ValueError, match="Unknown equation of state: teos10"):
         util.eos_func_from_str("TEOS10")
     with pytest.raises(ValueError, match="Unknown equation of state"):
         util.eos_func_from_str("_dispatch")
-    with pytest.raises(ValueError, match="linear.*alpha"):
-        util.eos_func_from_str("linear", func_name="alpha")
+    with pytest.raises(ValueError, match="linear.*speed_of_sound"):
+        util.eos_func_from_str("linear", func_name="speed_of_sound")
+    assert util.eos_func_from_str("linear", func_name="alpha") is m.eos.linear.alpha
+    assert m.eos.linear.drho_dtemp() == -0.2 and m.eos.linear.drho_dsal(1.0, 2.0, 3.0) == 0.8
     with pytest.raises(AssertionError):
         util.eos_func_from_str(3)
     with pytest.raises(AssertionError):
