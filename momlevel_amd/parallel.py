@@ -28,6 +28,7 @@ import torch
 import torch.distributed as dist
 
 from . import engine
+from .adapters import accepts_xarray
 
 
 def init_from_env(backend=None):
@@ -291,3 +292,76 @@ def steric_local_tile(T, S, vol0, pres, z_i, deptho, rhozero=1035.0, variant="st
     rho0 = core.eos_map(T[0], S[0], pres, eos=eos, f32_mode=f32_mode)
     return engine.local_steric(Tv, Sv, rho0, vol0, pres, rhozero, z_i=z_i, deptho=deptho, eos=eos,
                                f32_mode=f32_mode, want_delta_rho=want_delta_rho, out_host=False)
+
+
+# ---------------------------------------------------------------------------------------------
+# the public, labelled API on ONE RANK'S TILE: same signatures as momlevel_amd.steric & co.
+# ---------------------------------------------------------------------------------------------
+def _sum_over_ranks(group=None):
+    """-> callable summing a float64 numpy vector over the ranks (identity without a group)."""
+
+    def exchange(vec):
+        vec = np.ascontiguousarray(vec, dtype=np.float64)
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+            return vec
+        t = torch.from_numpy(vec.copy())
+        if dist.get_backend(group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t.cpu().numpy()
+
+    return exchange
+
+
+@accepts_xarray
+def steric(dset, reference=None, coord_names=None, varname_map=None, rhozero=1035.0,
+           patm=101325.0, equation_of_state="Wright", variant="steric", domain="local",
+           dtype="float32", strict=True, annual=False, verbose=False, group=None):
+    """``momlevel_amd.steric`` for a horizontally TILED dataset: call it on every rank with the
+    rank's own ``(yh, xh)`` tile of thetao / so / volcello / areacello (/ deptho).  Arguments and
+    the ``(result, reference)`` return value are those of ``steric`` (src/momlevel/steric.py:17-31).
+
+    ``domain="local"`` needs no communication: the result is the tile's part of the field.
+    ``domain="global"``: the tile sums [masso(t)..., volo] are all-reduced ONCE per call (RCCL over
+    xGMI; nt+1 doubles), every rank returns the same global ``reference_height`` and height time
+    series, and the scalars volo / masso / rhoga of the returned reference state are the GLOBAL
+    ones.  The areacello range check applies to the sum over all tiles.
+    """
+    from . import steric as _steric
+
+    results, reference = _steric._steric_many(
+        dset, (variant,), reference, coord_names, varname_map,
+        rhozero, patm, equation_of_state, domain, dtype, strict, annual, verbose,
+        exchange=_sum_over_ranks(group))
+    return results[variant], reference
+
+
+@accepts_xarray
+def steric_variants(dset, variants=("steric", "thermosteric", "halosteric"), reference=None,
+                    coord_names=None, varname_map=None, rhozero=1035.0, patm=101325.0,
+                    equation_of_state="Wright", domain="local", dtype="float32", strict=True,
+                    annual=False, verbose=False, heat_content=False, cp=None, group=None):
+    """``momlevel_amd.steric_variants`` on one rank's tile (see ``parallel.steric``): all variants
+    (and the heat content) from one pass and ONE all-reduce."""
+    from . import steric as _steric
+
+    results, reference = _steric._steric_many(
+        dset, tuple(variants), reference, coord_names, varname_map,
+        rhozero, patm, equation_of_state, domain, dtype, strict, annual, verbose,
+        heat_cp=(_steric.OHC_CP if cp is None else cp) if heat_content else None,
+        exchange=_sum_over_ranks(group))
+    return results, reference
+
+
+@accepts_xarray
+def setup_reference_state(dset, patm=101325.0, eos="Wright", coord_names=None, time_index=0,
+                          group=None):
+    """``momlevel_amd.setup_reference_state`` on one rank's tile: thetao / so / volcello / rho are
+    the tile's, volo / masso / rhoga the all-reduced global values."""
+    from . import reference as _reference
+    from . import steric as _steric
+
+    ref = _reference._setup(dset, patm, eos, coord_names, time_index,
+                            defer_masso=False)
+    _steric.globalise_reference(ref, _sum_over_ranks(group))
+    return ref

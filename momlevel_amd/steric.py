@@ -68,13 +68,23 @@ OHC_CP = 3992.0  # J kg-1 K-1
 
 
 def _global_results(ops, reference, variants, dtype, tcoord, coords_for, deferred,
-                    heat=None):
+                    heat=None, exchange=None, area_total=None):
     """steric.py:134-147 -- masso(t) from K1, then the Boussinesq offline approximation.
-    ``heat=(rhozero, cp)``: also the ocean-heat-content extension (key "heat")."""
+    ``heat=(rhozero, cp)``: also the ocean-heat-content extension (key "heat").
+    ``exchange`` (tiled multi-GPU runs, momlevel_amd.parallel): sums a float64 vector over the
+    ranks -- the path's ONE collective: [masso rows of this tile..., volo of this tile]."""
     T, S, T0, S0, vol0, p, eos = ops
     masso = engine.global_masso_variants(T, S, T0, S0, vol0, p, variants, eos=eos,
                                          f32_mode=_f32_mode(), with_heat=heat is not None)
     masso = {v: m.cpu().numpy() for v, m in masso.items()}
+    if exchange is not None:
+        names = list(masso)
+        nt = masso[names[0]].shape[0]
+        vec = np.concatenate([masso[v] for v in names] + [[np.float64(reference["volo"].values)]])
+        vec = exchange(vec)
+        masso = {v: vec[i * nt:(i + 1) * nt] for i, v in enumerate(names)}
+        if deferred:  # a self-made reference state: its volo was this tile's
+            reference["volo"].data[...] = vec[-1]
     if deferred:  # the self-generated reference is time index 0 of this very record: every
         # variant sees (theta0, S0) there, so any of them carries masso0 (same kernel, same bits)
         set_reference_masso(reference, masso[variants[0]][0])
@@ -84,7 +94,7 @@ def _global_results(ops, reference, variants, dtype, tcoord, coords_for, deferre
             masso[v],
             np.float64(reference["volo"].values),
             np.float64(reference["rhoga"].values),
-            np.float64(reference["areacello"].sum().values),
+            np.float64(reference["areacello"].sum().values if area_total is None else area_total),
         )
         result = Dataset()
         result["reference_height"] = DataArray(
@@ -148,16 +158,37 @@ def _local_results(ops, dset, reference, variants, dtype, rhozero, names, cdims3
     return out
 
 
+def globalise_reference(reference, exchange):
+    """Replace the tile sums volo / masso of a reference state made from ONE RANK'S tile by the
+    sums over all ranks (rhoga follows); scalar reference states only."""
+    if reference["masso"].dims:
+        return  # the time-dependent state of a patm(time) run: rejected by validation anyway
+    vec = exchange(np.array([np.float64(reference["volo"].values),
+                             np.float64(reference["masso"].values)]))
+    reference["volo"].data[...] = vec[0]
+    set_reference_masso(reference, vec[1])
+
+
 def _steric_many(dset, variants, reference, coord_names, varname_map, rhozero, patm,
-                 equation_of_state, domain, dtype, strict, annual, verbose, heat_cp=None):
+                 equation_of_state, domain, dtype, strict, annual, verbose, heat_cp=None,
+                 exchange=None):
     """The body of steric() for one or several variants sharing one reference state and one
-    pass of theta/S through the device.  Returns ({variant: result}, reference)."""
+    pass of theta/S through the device.  Returns ({variant: result}, reference).
+    ``exchange``: None, or -- when ``dset`` is ONE RANK'S horizontal tile of a multi-GPU run
+    (momlevel_amd.parallel.steric) -- a callable summing a float64 vector over the ranks; the
+    global sums (sum of areacello, volo, masso) then go through it, everything else is local."""
     dset = dset.rename(varname_map)
     names = default_coords(coord_names)
     tcoord, zcoord, zbounds = names
 
+    area_total = None
+    if exchange is not None and "areacello" in dset.variables:
+        from .util import _area_sum
+
+        area_total = float(exchange(np.array([_area_sum(dset["areacello"])]))[0])
     validate_dataset(
-        dset, strict=strict, additional_vars=None if domain == "global" else [zbounds, "deptho"]
+        dset, strict=strict, additional_vars=None if domain == "global" else [zbounds, "deptho"],
+        area_total=area_total,
     )
     pres = pressure_field(dset, zcoord, patm)  # 1 m of depth ~ 1 dbar = 1e4 Pa, plus patm
 
@@ -167,13 +198,15 @@ def _steric_many(dset, variants, reference, coord_names, varname_map, rhozero, p
     if reference is None:
         # domain="global": masso0 is masso(t=0) of the K1 launch below (same kernel, same bits)
         reference = _setup(dset, patm, equation_of_state, coord_names, 0, defer_masso=deferred)
+        if exchange is not None and not deferred:
+            globalise_reference(reference, exchange)
         if verbose:
             print("Generating reference state from first timestep")
     else:
         assert isinstance(reference, Dataset), "`reference` must be an xarray Dataset"
         if verbose:
             print("Using supplied reference state")
-    validate_dataset(reference, reference=True, strict=strict)
+    validate_dataset(reference, reference=True, strict=strict, area_total=area_total)
 
     _check_variants(variants)
     eos_func_from_str(equation_of_state)  # unknown EOS -> ValueError (util.py:247)
@@ -201,7 +234,8 @@ def _steric_many(dset, variants, reference, coord_names, varname_map, rhozero, p
             plan = None  # unusual time axis: average on the host afterwards
     if domain == "global":
         results = _global_results(ops, reference, variants, dtype, tcoord, coords_for, deferred,
-                                  heat=None if heat_cp is None else (rhozero, heat_cp))
+                                  heat=None if heat_cp is None else (rhozero, heat_cp),
+                                  exchange=exchange, area_total=area_total)
     else:
         if heat_cp is not None:
             raise ValueError("heat_content is a global integral: use domain='global'")

@@ -65,10 +65,13 @@ def _area_sum(areacello):
     return float(np.nansum(np.asarray(areacello)))
 
 
-def validate_areacello(areacello, reference=3.6111092e14, tolerance=0.02):
+def validate_areacello(areacello, reference=3.6111092e14, tolerance=0.02, total=None):
     """Does ``areacello`` sum to the real ocean's surface (3.6111092e14 m2) within a relative
-    ``tolerance``?  Catches an unmasked field, e.g. the whole globe's area (util.py:669-694)."""
-    relative_error = (_area_sum(areacello) - reference) / reference
+    ``tolerance``?  Catches an unmasked field, e.g. the whole globe's area (util.py:669-694).
+    ``total`` (not in momlevel): the sum over ALL horizontal tiles when ``areacello`` is one rank's
+    tile of a multi-GPU run (momlevel_amd.parallel) -- the check is about the whole ocean."""
+    area = _area_sum(areacello) if total is None else float(total)
+    relative_error = (area - reference) / reference
     return bool(abs(relative_error) < tolerance)
 
 
@@ -79,7 +82,7 @@ _REQUIRED = ("thetao", "so", "volcello", "areacello")
 _REQUIRED_IN_REFERENCE = ("rho", "volo", "masso", "rhoga")
 
 
-def _dataset_findings(dset, reference, additional_vars):
+def _dataset_findings(dset, reference, additional_vars, area_total=None):
     """Yield ``(severity, message)`` for every requirement ``dset`` does not meet, in the order
     util.py:697-814 reports them.  severity "area" marks the one finding ``strict=False`` turns
     into a warning."""
@@ -103,7 +106,7 @@ def _dataset_findings(dset, reference, additional_vars):
         if name in present and len(dset[name].dims) != rank:
             yield "error", message
 
-    if "areacello" in present and not validate_areacello(dset["areacello"]):
+    if "areacello" in present and not validate_areacello(dset["areacello"], total=area_total):
         yield "area", "Variable `areacello` field is out of range. It may not be masked."
 
     if reference:
@@ -116,16 +119,17 @@ def _dataset_findings(dset, reference, additional_vars):
                 yield "error", f"Variable {name} must be a scalar"
 
 
-def validate_dataset(dset, reference=False, strict=True, additional_vars=None):
+def validate_dataset(dset, reference=False, strict=True, additional_vars=None, area_total=None):
     """Is ``dset`` a usable input (or, ``reference=True``, reference-state) dataset?
 
     Same observable behaviour as util.py:697-814: required variables present, fields of the right
     rank, ``areacello`` summing to the real ocean's area.  All findings are printed, then ONE
     ``ValueError("Errors found in dataset.")`` is raised; ``strict=False`` downgrades only the
-    areacello range finding to a ``UserWarning``.  Returns None.
+    areacello range finding to a ``UserWarning``.  Returns None.  ``area_total``: see
+    validate_areacello (tiled multi-GPU runs only).
     """
     fatal = []
-    for severity, message in _dataset_findings(dset, reference, additional_vars):
+    for severity, message in _dataset_findings(dset, reference, additional_vars, area_total):
         if severity == "area" and not strict:
             warnings.warn(message)
         else:

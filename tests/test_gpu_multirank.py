@@ -80,3 +80,68 @@ def test_tiled_streamed_global_steric_under_several_ranks(tmp_path, mode, dtype,
     assert np.max(np.abs(ranks[0]["heat"] - heat) / np.abs(heat)) <= 1e-12
     # the one-pass decomposition and a single-variant run agree bit for bit across the exchange
     assert np.array_equal(ranks[0]["thermo_single_masso"], ranks[0]["thermosteric_masso"])
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("dtype,world", [("f64", 2), ("f32", 4)])
+def test_labelled_tiled_api_matches_the_single_domain_call(tmp_path, dtype, world):
+    """momlevel_amd.parallel.steric / steric_variants / setup_reference_state: the reference's
+    signatures on ONE RANK'S TILE.  Global results (every rank, bit-identical across ranks) equal
+    momlevel_amd.steric on the whole dataset to <= 1e-12 on masso and 1e-12 abs on the expansion
+    coefficient; local results are the tile of the whole-domain field, bit for bit."""
+    import torch  # noqa: F401  (the parent computes the single-domain answer on the same GPU)
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from rank_worker_labelled import tile_dataset
+
+    import momlevel_amd
+
+    nt, nz, ny, nx = 6, 5, 16, 24
+    port = _free_port()
+    procs, outs = [], []
+    for rank in range(world):
+        out = str(tmp_path / f"lab{rank}.npz")
+        outs.append(out)
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MOMLEVEL_AMD_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "tests", "rank_worker_labelled.py"), out, str(nt),
+             str(nz), str(ny), str(nx), dtype], env=env, stdout=subprocess.PIPE,
+            stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=300)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-3000:]
+    ranks = [dict(np.load(f)) for f in outs]
+    whole, _ = tile_dataset(nt, nz, ny, nx, np.float32 if dtype == "f32" else np.float64, 0, 1)
+    for variant in ("steric", "thermosteric"):
+        res, ref = momlevel_amd.steric(whole, variant=variant, domain="global")
+        h = float(res["reference_height"])
+        for r in ranks:
+            assert r[f"global_{variant}"][0] == 0.0
+            assert abs(float(r[f"global_{variant}_masso"]) - float(ref["masso"])) <= 1e-12 * float(ref["masso"])
+            assert abs(float(r[f"global_{variant}_volo"]) - float(ref["volo"])) <= 1e-12 * float(ref["volo"])
+            assert abs(float(r[f"global_{variant}_href"]) - h) <= 1e-12 * h
+            assert np.allclose(r[f"global_{variant}"] / h, res[variant].values / h, rtol=0, atol=1e-12)
+            assert np.array_equal(r[f"global_{variant}"], ranks[0][f"global_{variant}"])
+            assert bool(r["untiled_call_raises"])  # a tile alone is not a valid ocean
+    lres, lref = momlevel_amd.steric(whole, domain="local")
+    vres, _ = momlevel_amd.steric_variants(whole, domain="global", heat_content=True)
+    for r in ranks:
+        y0, y1, x0, x1 = r["bounds"]
+        tile = lres["steric"].values[:, y0:y1, x0:x1]
+        assert np.array_equal(np.isnan(r["local_eta"]), np.isnan(tile))
+        assert np.array_equal(np.nan_to_num(r["local_eta"]), np.nan_to_num(tile))
+        assert abs(float(r["local_ref_masso"]) - float(lref["masso"])) <= 1e-12 * float(lref["masso"])
+        assert abs(float(r["setup_masso"]) - float(lref["masso"])) <= 1e-12 * float(lref["masso"])
+        hv = float(vres["steric"]["reference_height"])
+        for v in ("steric", "thermosteric", "halosteric"):
+            assert np.allclose(r[f"variants_{v}"] / hv, vres[v][v].values / hv, rtol=0, atol=1e-12)
+        ohc = vres["heat"]["ohc"].values
+        assert np.max(np.abs(r["variants_ohc"] - ohc) / np.abs(ohc)) <= 1e-12
