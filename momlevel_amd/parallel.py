@@ -327,9 +327,9 @@ def steric(dset, reference=None, coord_names=None, varname_map=None, rhozero=103
     series, and the scalars volo / masso / rhoga of the returned reference state are the GLOBAL
     ones.  The areacello range check applies to the sum over all tiles.
     """
-    from . import steric as _steric
+    from .steric import _steric_many  # (momlevel_amd.steric the attribute is the function)
 
-    results, reference = _steric._steric_many(
+    results, reference = _steric_many(
         dset, (variant,), reference, coord_names, varname_map,
         rhozero, patm, equation_of_state, domain, dtype, strict, annual, verbose,
         exchange=_sum_over_ranks(group))
@@ -343,12 +343,12 @@ def steric_variants(dset, variants=("steric", "thermosteric", "halosteric"), ref
                     annual=False, verbose=False, heat_content=False, cp=None, group=None):
     """``momlevel_amd.steric_variants`` on one rank's tile (see ``parallel.steric``): all variants
     (and the heat content) from one pass and ONE all-reduce."""
-    from . import steric as _steric
+    from .steric import OHC_CP, _steric_many
 
-    results, reference = _steric._steric_many(
+    results, reference = _steric_many(
         dset, tuple(variants), reference, coord_names, varname_map,
         rhozero, patm, equation_of_state, domain, dtype, strict, annual, verbose,
-        heat_cp=(_steric.OHC_CP if cp is None else cp) if heat_content else None,
+        heat_cp=(OHC_CP if cp is None else cp) if heat_content else None,
         exchange=_sum_over_ranks(group))
     return results, reference
 
@@ -358,10 +358,9 @@ def setup_reference_state(dset, patm=101325.0, eos="Wright", coord_names=None, t
                           group=None):
     """``momlevel_amd.setup_reference_state`` on one rank's tile: thetao / so / volcello / rho are
     the tile's, volo / masso / rhoga the all-reduced global values."""
-    from . import reference as _reference
-    from . import steric as _steric
+    from .reference import _setup
+    from .steric import globalise_reference
 
-    ref = _reference._setup(dset, patm, eos, coord_names, time_index,
-                            defer_masso=False)
-    _steric.globalise_reference(ref, _sum_over_ranks(group))
+    ref = _setup(dset, patm, eos, coord_names, time_index, defer_masso=False)
+    globalise_reference(ref, _sum_over_ranks(group))
     return ref
