@@ -241,6 +241,14 @@ def test_product_fails_loudly_without_a_gpu():
         m.eos.wright.density(18.0, 35.0, 2.0e5)
     with pytest.raises(m.MomlevelHipError):
         m.derived.calc_volo(dset["volcello"].isel(time=0))
+    # the tiled (multi-GPU) front end resolves its imports and fails just as loudly
+    from momlevel_amd import parallel
+
+    for call in (lambda: parallel.steric(dset, domain="global"),
+                 lambda: parallel.steric_variants(dset, domain="global", heat_content=True),
+                 lambda: parallel.setup_reference_state(dset)):
+        with pytest.raises(m.MomlevelHipError):
+            call()
 
 
 def test_product_never_imports_the_oracle():
