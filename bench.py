@@ -522,6 +522,17 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
                 "GB/s": round(24 * done / pms / 1e6, 1), "ms": round(pms, 3),
                 "note": "mlx_stream_probe: out = a + b, 16 B read + 8 B written per element"}
             out["local_with_delta_rho"]["frac_of_read_write_probe"] = round(pms / ms, 4)
+        # K0 (derived.calc_rho: the pointwise EOS map, 16 B read + 8 B written per cell), in the
+        # same 16-step chunks, against the same read+write probe
+        def run_k0():
+            for t0 in starts:
+                rho = core.eos_map(T[t0:t0 + chunk], S[t0:t0 + chunk], pres)
+                del rho
+
+        kms = _time(run_k0, reps=2)
+        out["calc_rho_map"] = rate(kms, 2 * B1 + 8, done)
+        if B1 == 8:
+            out["calc_rho_map"]["frac_of_read_write_probe"] = round(pms / kms, 4)
         ms_skip = _time(lambda: run(True), reps=2)
         out["land_skipping"]["local_with_delta_rho_Mcells/s"] = round(done / ms_skip / 1e3, 1)
 
