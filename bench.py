@@ -168,7 +168,7 @@ def cpu_baseline(T, S, g, pres, target_s, gpu_masso):
         "note": "first/last step of K1 time chunks (32 steps each): the whole launch is covered"}
 
 
-def cpu_baseline_processes(g, nz, ny, nx, nt, gpu_masso, procs, reps=2, timeout=420):
+def cpu_baseline_processes(g, nz, ny, nx, nt, gpu_masso, procs, reps=2, timeout=240):
     """The P-process line of BASELINE.md section 4: P independent oracle processes, one time slab
     each, all timed together (how dask's chunks={"time": 1} spreads momlevel over a host).  Every
     worker regenerates its slab in numpy (no GPU, no shared memory) -- oracle/cpu_worker.py."""
@@ -185,14 +185,33 @@ def cpu_baseline_processes(g, nz, ny, nx, nt, gpu_masso, procs, reps=2, timeout=
                  str(reps)], cwd=here, env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE,
                 text=True))
         deadline = time.time() + timeout
+
+        def line_from(w):
+            """one stdout line of a worker, or a RuntimeError once the overall deadline has passed
+            (a worker that died or hangs must never hang the bench)"""
+            import select
+
+            while True:
+                left = deadline - time.time()
+                if left <= 0:
+                    raise RuntimeError("CPU worker timed out")
+                ready, _, _ = select.select([w.stdout], [], [], min(left, 5.0))
+                if ready:
+                    text = w.stdout.readline()
+                    if text == "":
+                        raise RuntimeError(f"CPU worker exited with code {w.poll()}")
+                    return text
+                if w.poll() is not None:
+                    raise RuntimeError(f"CPU worker exited with code {w.poll()}")
+
         for w in workers:
-            if w.stdout.readline().strip() != "ready" or time.time() > deadline:
+            if line_from(w).strip() != "ready":
                 raise RuntimeError("worker failed to start")
         t0 = time.perf_counter()
         for w in workers:
             w.stdin.write("go\n")
             w.stdin.flush()
-        outs = [w.stdout.readline().split() for w in workers]
+        outs = [line_from(w).split() for w in workers]
         wall = time.perf_counter() - t0
         per_slab = [float(o_[0]) for o_ in outs]
         err = max(abs(float(o_[1]) - gpu_masso[t]) / abs(float(o_[1])) for o_, t in zip(outs, steps))

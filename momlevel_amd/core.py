@@ -196,7 +196,7 @@ def skip_dry_default():
     return os.environ.get("MOMLEVEL_AMD_SKIP_DRY", "1") != "0"
 
 
-def _k1_flags(skip_dry, arith, t_chunk):
+def _launch_flags(skip_dry, arith, t_chunk):
     if skip_dry is None:
         skip_dry = skip_dry_default()
     flags = (_lib.FLAG_SKIP_DRY if skip_dry else 0) | _arith_flag(arith)
@@ -217,7 +217,7 @@ def steric_global_masso(T, S, vol0, p, eos="wright", f32_mode="faithful", events
     ``p`` may be time dependent, (nt,nz,ny,nx)-broadcastable (a DataArray ``patm``).
     """
     require_device()
-    flags = _k1_flags(skip_dry, arith, t_chunk)
+    flags = _launch_flags(skip_dry, arith, t_chunk)
     T, S, nt, nz, ny, nx, sT, sS, dt, _ = _pair(T, S, f32_mode)
     vol0 = _f64(vol0, T.device)
     if tuple(vol0.shape) != (nz, ny, nx):
@@ -252,7 +252,7 @@ def steric_global_decomp(T, S, T0, S0, vol0, p, eos="wright", f32_mode="faithful
     sum(theta*vol0) (the heat-content integrand; an extension, not in momlevel).  Rows 0-2 are
     bit-identical to three steric_global_masso calls."""
     require_device()
-    flags = _k1_flags(skip_dry, arith, t_chunk)
+    flags = _launch_flags(skip_dry, arith, t_chunk)
     T, S, nt, nz, ny, nx, sT, sS, dt, _ = _pair(T, S, f32_mode)
     if T.dim() != 4 or S.dim() != 4:
         raise ValueError("steric_global_decomp streams both fields: thetao and so must be 4-D")
@@ -316,7 +316,7 @@ def steric_local(T, S, rho0m, vol0_surface, p, neg_inv_rhozero, dz=None, z_i=Non
     """K2: (delta_rho (nt,nz,ny,nx) or None, eta (nt,ny,nx)).  ``skip_dry``, ``arith``: see
     steric_global_masso.  ``p`` may be time dependent (4-D)."""
     require_device()
-    flags = _k1_flags(skip_dry, arith, 0)
+    flags = _launch_flags(skip_dry, arith, 0)
     T, S, nt, nz, ny, nx, sT, sS, dt, _ = _pair(T, S, f32_mode)
     dev = T.device
     rho0m = _f64(rho0m, dev)
@@ -363,7 +363,7 @@ def steric_local_decomp(T, S, T0, S0, rho0m, vol0_surface, p, neg_inv_rhozero, d
     steric_local call.  ``delta_rho_out`` / ``eta_out``: optional (3, nt, ...) float64 device
     tensors (or views whose variant axis has any stride, e.g. ``full[:, t0:t1]``)."""
     require_device()
-    flags = _k1_flags(skip_dry, arith, 0)
+    flags = _launch_flags(skip_dry, arith, 0)
     T, S, nt, nz, ny, nx, sT, sS, dt, _ = _pair(T, S, f32_mode)
     if T.dim() != 4 or S.dim() != 4:
         raise ValueError("steric_local_decomp streams both fields: thetao and so must be 4-D")
