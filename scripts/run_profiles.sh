@@ -26,4 +26,16 @@ echo "== variants: SQ";                rocprofv3 --output-format csv --kernel-tr
 find $B $V -name "*_agent_info.csv" -delete
 python3 scripts/summarize_rocprof.py $B profiles/${TAG}
 python3 scripts/summarize_variants.py $V profiles/${TAG}
-echo "profiles done"
+echo "profiles done (f64)"
+# --- float32 theta/S (BASELINE.json configs[4]): the same variants, half the bytes per cell
+W=gpurun_out/prof_${TAG}v32
+mkdir -p $W
+VAR32="python3 scripts/profile_variants.py --nt 40 --reps 2 --dtype f32"
+echo "== f32 variants: plain";        $VAR32 --plan-out $W/plan.json > $W/plain.log 2>&1
+echo "== f32 variants: kernel trace"; rocprofv3 --output-format csv --kernel-trace --stats -d $W/trace -o run -- $VAR32 > $W/trace.log 2>&1
+echo "== f32 variants: FETCH_SIZE";   rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $W/pmc_fetch -o run -- $VAR32 > $W/pmc_fetch.log 2>&1
+echo "== f32 variants: WRITE_SIZE";   rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $W/pmc_write -o run -- $VAR32 > $W/pmc_write.log 2>&1
+echo "== f32 variants: SQ";           rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -d $W/pmc_sq -o run -- $VAR32 > $W/pmc_sq.log 2>&1
+find $W -name "*_agent_info.csv" -delete
+python3 scripts/summarize_variants.py $W profiles/${TAG}_f32
+echo "f32 profiles done"
