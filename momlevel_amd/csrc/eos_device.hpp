@@ -53,6 +53,34 @@ struct WrightC {
   static constexpr R C5 = R(-3.079464);
 };
 
+// Two cells per arithmetic instruction for the float32 polynomial: gfx950 issues v_pk_mul_f32 /
+// v_pk_add_f32 on float2 at the rate of one scalar op, each lane rounded exactly like the scalar
+// instruction.  The faithful float32 mode (numpy's mixed precision) evaluates TPart / SPart /
+// al0, p0, lam on float2; everything float64 (p + p0, the division) stays per cell.
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <>
+struct WrightC<f2> : WrightC<float> {};  // scalar constants: they splat in vector arithmetic
+
+template <typename R>
+struct Lanes {  // cells per value of arithmetic type R
+  static constexpr int n = 1;
+  static __device__ __forceinline__ double get(R v, int) { return (double)v; }
+  template <typename TIn>
+  static __device__ __forceinline__ R make(const TIn* v) { return (R)v[0]; }
+};
+template <>
+struct Lanes<f2> {
+  static constexpr int n = 2;
+  static __device__ __forceinline__ double get(f2 v, int i) { return (double)(i ? v.y : v.x); }
+  template <typename TIn>
+  static __device__ __forceinline__ f2 make(const TIn* v) {
+    f2 r;
+    r.x = (float)v[0];
+    r.y = (float)v[1];
+    return r;
+  }
+};
+
 // ---- arithmetic policies -----------------------------------------------------------------------
 // ExactOps: numpy's evaluation -- every + - * / is ONE correctly rounded IEEE operation, in the
 //   reference's operator order; results are bit-identical to eos/wright.py on the host.
@@ -63,8 +91,9 @@ struct WrightC {
 //   Always float64, also for float32 theta/S (upcast first).
 struct ExactOps {
   static constexpr bool fused = false;
-  template <typename R>
-  static __device__ __forceinline__ R mad(R a, R b, R c) {
+  // (operands may be a float2 vector mixed with scalar constants: the scalars splat)
+  template <typename A, typename B, typename C>
+  static __device__ __forceinline__ auto mad(A a, B b, C c) -> decltype(a * b + c) {
     return a * b + c;  // two roundings: this file is compiled with contraction off
   }
   // eos/wright.py:47-48: I_denom = 1.0 / den; return (p + p0) * I_denom
@@ -134,17 +163,29 @@ __device__ __forceinline__ SPart<R> s_part(R S, R p_fold) {
   return h;
 }
 
-// rho from the two parts: eos/wright.py:44-48
+// rho from the two parts: eos/wright.py:44-48.  out[i] = density of lane i (Lanes<R>::n cells)
 template <typename Ops, typename R>
-__device__ __forceinline__ double wright_combine(const TPart<R>& a, const SPart<R>& b, double p) {
+__device__ __forceinline__ void wright_combine_lanes(const TPart<R>& a, const SPart<R>& b, double p,
+                                                     double* out) {
   const R al0 = a.a01 + b.a2s;
   const R p0 = Ops::mad(a.t, a.tb + b.b5s, b.b04);
   const R lam = Ops::mad(a.t, a.tc + b.c5s, b.c04);
-  double pp0;
-  if constexpr (Ops::fused) pp0 = (double)p0;  // p is inside b04
-  else pp0 = p + (double)p0;
-  const double den = Ops::mad((double)al0, pp0, (double)lam);  // lam + al0*(p + p0)
-  return Ops::quotient(pp0, den);
+#pragma unroll
+  for (int i = 0; i < Lanes<R>::n; ++i) {
+    double pp0;
+    if constexpr (Ops::fused) pp0 = Lanes<R>::get(p0, i);  // p is inside b04
+    else pp0 = p + Lanes<R>::get(p0, i);
+    const double den = Ops::mad(Lanes<R>::get(al0, i), pp0, Lanes<R>::get(lam, i));  // lam + al0*(p+p0)
+    out[i] = Ops::quotient(pp0, den);
+  }
+}
+
+template <typename Ops, typename R>
+__device__ __forceinline__ double wright_combine(const TPart<R>& a, const SPart<R>& b, double p) {
+  static_assert(Lanes<R>::n == 1, "scalar form");
+  double rho;
+  wright_combine_lanes<Ops, R>(a, b, p, &rho);
+  return rho;
 }
 
 // al0, p0, lam in precision R (double, or float for numpy's float32 inputs: the python-float
@@ -166,6 +207,20 @@ struct PolyType {
 template <>
 struct PolyType<kF32Faithful> {
   typedef float type;
+};
+
+// arithmetic type of the polynomial when the kernel holds PAIRS of adjacent cells
+template <int MODE, int VEC>
+struct PolyVec {
+  typedef typename PolyType<MODE>::type type;
+};
+template <>
+struct PolyVec<kF32Faithful, 2> {
+  typedef f2 type;
+};
+template <>
+struct PolyVec<kF32Faithful, 4> {
+  typedef f2 type;
 };
 
 // in-situ density, eos/wright.py:44-48.  MODE selects how float32 inputs are treated.

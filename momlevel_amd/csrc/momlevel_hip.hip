@@ -154,6 +154,10 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
   constexpr bool HELD_T = (VAR == kVarHalo || VAR == kVarAll);
   constexpr bool HELD_S = (VAR == kVarThermo || VAR == kVarAll);
   typedef typename PolyType<MODE>::type R;
+  // arithmetic groups: pairs of adjacent cells on float2 in the faithful float32 fast path
+  // (eos_device.hpp, PolyVec), single cells otherwise
+  typedef typename PolyVec<MODE, GENERIC ? 1 : VEC>::type RV;
+  constexpr int W = Lanes<RV>::n, G = VEC / W;
   typedef typename std::conditional<FMA, FusedOps, ExactOps>::type Ops;
   static_assert(!FMA || MODE != kF32Faithful, "fused arithmetic is float64");
   __shared__ double red[NOUT][NTC][kBlock];
@@ -198,11 +202,12 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
   double pz = 0.0;
   if (!GENERIC || p_mode == MLX_P_ZPROF) pz = p[z];
   if (GENERIC && p_mode == MLX_P_SCALAR) pz = p[0];
-  const R pfold = FMA ? (R)pz : R(0);  // FusedOps folds the level's pressure into B0
+  RV pfold = RV{};  // FusedOps (float64 only) folds the level's pressure into B0
+  if constexpr (FMA) pfold = (R)pz;
 
   // held fields: read once; fast path keeps their PART of the polynomial, generic the values
-  TPart<R> t0p[(HELD_T && !GENERIC) ? U : 1][VEC];
-  SPart<R> s0p[(HELD_S && !GENERIC) ? U : 1][VEC];
+  TPart<RV> t0p[(HELD_T && !GENERIC) ? U : 1][G];
+  SPart<RV> s0p[(HELD_S && !GENERIC) ? U : 1][G];
   TIn t0v[(HELD_T && GENERIC) ? U : 1][VEC], s0v[(HELD_S && GENERIC) ? U : 1][VEC];
   if constexpr (HELD_T) {
 #pragma unroll
@@ -212,7 +217,10 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         if constexpr (GENERIC) t0v[u][k] = h.v[k];
-        else t0p[u][k] = t_part<Ops, R>((R)h.v[k]);
+      }
+      if constexpr (!GENERIC) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) t0p[u][g] = t_part<Ops, RV>(Lanes<RV>::make(&h.v[g * W]));
       }
     }
   }
@@ -224,7 +232,10 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         if constexpr (GENERIC) s0v[u][k] = h.v[k];
-        else s0p[u][k] = s_part<Ops, R>((R)h.v[k], pfold);
+      }
+      if constexpr (!GENERIC) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) s0p[u][g] = s_part<Ops, RV>(Lanes<RV>::make(&h.v[g * W]), pfold);
       }
     }
   }
@@ -280,41 +291,47 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
     for (int u = 0; u < U; ++u) {
       if (SKIP && !alive[u]) continue;  // adds exactly nothing: c + 0.0 == c
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) {
-        double rho[NOUT > 1 ? 3 : 1];
-        if constexpr (GENERIC) {
+      for (int g = 0; g < G; ++g) {
+        constexpr int NR = NOUT > 1 ? 3 : 1;
+        double rho[NR][W];
+        if constexpr (GENERIC) {  // W == 1
+          const int k = g;
           double pp = pz;
           if (p_mode == MLX_P_FULL3D) pp = pc[u][k];
           if (p_mode == MLX_P_FULL4D) pp = p[((int64_t)t * nz) * plane + off[u] + k];
           const TIn tv = STREAM_T ? curT[u].v[k] : t0v[u][k];
           const TIn sv = STREAM_S ? curS[u].v[k] : s0v[u][k];
-          rho[0] = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, sv, pp);
+          rho[0][0] = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, sv, pp);
           if constexpr (VAR == kVarAll) {
-            rho[1] = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, s0v[u][k], pp);
-            rho[2] = eos_eval<MODE, TIn, Ops>(eos, kDensity, t0v[u][k], sv, pp);
+            rho[1][0] = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, s0v[u][k], pp);
+            rho[2][0] = eos_eval<MODE, TIn, Ops>(eos, kDensity, t0v[u][k], sv, pp);
           }
         } else {
-          TPart<R> a;
-          SPart<R> b;
-          if constexpr (STREAM_T) a = t_part<Ops, R>((R)curT[u].v[k]);
-          if constexpr (STREAM_S) b = s_part<Ops, R>((R)curS[u].v[k], pfold);
-          if constexpr (VAR == kVarSteric) rho[0] = wright_combine<Ops, R>(a, b, pz);
-          if constexpr (VAR == kVarHalo) rho[0] = wright_combine<Ops, R>(t0p[u][k], b, pz);
-          if constexpr (VAR == kVarThermo) rho[0] = wright_combine<Ops, R>(a, s0p[u][k], pz);
+          TPart<RV> a;
+          SPart<RV> b;
+          if constexpr (STREAM_T) a = t_part<Ops, RV>(Lanes<RV>::make(&curT[u].v[g * W]));
+          if constexpr (STREAM_S) b = s_part<Ops, RV>(Lanes<RV>::make(&curS[u].v[g * W]), pfold);
+          if constexpr (VAR == kVarSteric) wright_combine_lanes<Ops, RV>(a, b, pz, rho[0]);
+          if constexpr (VAR == kVarHalo) wright_combine_lanes<Ops, RV>(t0p[u][g], b, pz, rho[0]);
+          if constexpr (VAR == kVarThermo) wright_combine_lanes<Ops, RV>(a, s0p[u][g], pz, rho[0]);
           if constexpr (VAR == kVarAll) {
-            rho[0] = wright_combine<Ops, R>(a, b, pz);
-            rho[1] = wright_combine<Ops, R>(a, s0p[u][k], pz);
-            rho[2] = wright_combine<Ops, R>(t0p[u][k], b, pz);
+            wright_combine_lanes<Ops, RV>(a, b, pz, rho[0]);
+            wright_combine_lanes<Ops, RV>(a, s0p[u][g], pz, rho[1]);
+            wright_combine_lanes<Ops, RV>(t0p[u][g], b, pz, rho[2]);
           }
         }
 #pragma unroll
-        for (int o = 0; o < (NOUT > 1 ? 3 : 1); ++o) {
-          const double term = rho[o] * vol[u][k];  // derived.py:435
-          c[o] += is_nan(term) ? 0.0 : term;       // skipna
-        }
-        if constexpr (VAR == kVarAll) {  // extension: heat-content integrand theta*vol0
-          const double term = (double)curT[u].v[k] * vol[u][k];
-          c[3] += is_nan(term) ? 0.0 : term;
+        for (int w = 0; w < W; ++w) {  // cells in ascending order: the order of summation is fixed
+          const int k = g * W + w;
+#pragma unroll
+          for (int o = 0; o < NR; ++o) {
+            const double term = rho[o][w] * vol[u][k];  // derived.py:435
+            c[o] += is_nan(term) ? 0.0 : term;          // skipna
+          }
+          if constexpr (VAR == kVarAll) {  // extension: heat-content integrand theta*vol0
+            const double term = (double)curT[u].v[k] * vol[u][k];
+            c[3] += is_nan(term) ? 0.0 : term;
+          }
         }
       }
     }
@@ -466,6 +483,15 @@ __global__ __launch_bounds__(kBlock) void k_eos_map(const TIn* __restrict__ T,
         if (p_mode == MLX_P_FULL3D) pp = p[off[u] + k];
         if (p_mode == MLX_P_FULL4D) pp = p[t * nz * plane + off[u] + k];
         r.v[k] = eos_eval<MODE, TIn, Ops>(eos, func, a[u].v[k], b[u].v[k], pp, aux);
+      } else if constexpr (FUNC == kDensity && MODE == kF32Faithful) {
+        if (k % 2 == 0) {  // the float32 polynomial on float2 pairs (see K1)
+          double two[2];
+          wright_combine_lanes<ExactOps, f2>(t_part<ExactOps, f2>(Lanes<f2>::make(&a[u].v[k])),
+                                            s_part<ExactOps, f2>(Lanes<f2>::make(&b[u].v[k]), f2{}),
+                                            pz, two);
+          r.v[k] = two[0];
+          r.v[k + 1] = two[1];
+        }
       } else {
         r.v[k] = eos_eval<MODE, TIn, Ops>(kWright, FUNC, a[u].v[k], b[u].v[k], pz);
       }
@@ -527,6 +553,8 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
   constexpr bool HELD_T = (VAR == kVarHalo || VAR == kVarAll);
   constexpr bool HELD_S = (VAR == kVarThermo || VAR == kVarAll);
   typedef typename PolyType<MODE>::type R;
+  typedef typename PolyVec<MODE, GENERIC ? 1 : VEC>::type RV;  // float2 pairs: see K1
+  constexpr int W = Lanes<RV>::n, G = VEC / W;
   typedef typename std::conditional<FMA, FusedOps, ExactOps>::type Ops;
   static_assert(!FMA || MODE != kF32Faithful, "fused arithmetic is float64");
   const int64_t col = (xcd_remap(blockIdx.x, gridDim.x) * kBlock + threadIdx.x) * VEC;
@@ -582,16 +610,17 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
       if (HELD_T) hT = load_pack<TIn, VEC>((VAR == kVarAll ? T0 : T) + off);
       if (HELD_S) hS = load_pack<TIn, VEC>((VAR == kVarAll ? S0 : S) + off);
     }
-    const R pfold = FMA ? (R)pz : R(0);
-    TPart<R> hTp[VEC];
-    SPart<R> hSp[VEC];
+    RV pfold = RV{};
+    if constexpr (FMA) pfold = (R)pz;
+    TPart<RV> hTp[G];
+    SPart<RV> hSp[G];
     if constexpr (!GENERIC && HELD_T) {
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) hTp[k] = t_part<Ops, R>((R)hT.v[k]);
+      for (int g = 0; g < G; ++g) hTp[g] = t_part<Ops, RV>(Lanes<RV>::make(&hT.v[g * W]));
     }
     if constexpr (!GENERIC && HELD_S) {
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) hSp[k] = s_part<Ops, R>((R)hS.v[k], pfold);
+      for (int g = 0; g < G; ++g) hSp[g] = s_part<Ops, RV>(Lanes<RV>::make(&hS.v[g * W]), pfold);
     }
 
     Pack<TIn, VEC> a[NTI], b[NTI];
@@ -613,38 +642,43 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
         // skipped, exactly as if theta/S had been loaded.  Only their LOADS are masked -- a
         // divergent store path would split every partly-dry line into two transactions.
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-          const TIn tv = STREAM_T ? a[j].v[k] : hT.v[k];
-          const TIn sv = STREAM_S ? b[j].v[k] : hS.v[k];
-          double rho[NOUT];
-          if constexpr (GENERIC) {
+        for (int g = 0; g < G; ++g) {
+          double rho[NOUT][W];
+          if constexpr (GENERIC) {  // W == 1
+            const int k = g;
+            const TIn tv = STREAM_T ? a[j].v[k] : hT.v[k];
+            const TIn sv = STREAM_S ? b[j].v[k] : hS.v[k];
             double pp = (p_mode == MLX_P_FULL3D) ? pfull.v[k] : pz;
             if (p_mode == MLX_P_FULL4D) pp = p[(int64_t)(t0 + j) * n3 + off + k];
-            rho[0] = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, sv, pp);
+            rho[0][0] = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, sv, pp);
             if constexpr (VAR == kVarAll) {
-              rho[1] = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, hS.v[k], pp);
-              rho[2] = eos_eval<MODE, TIn, Ops>(eos, kDensity, hT.v[k], sv, pp);
+              rho[1][0] = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, hS.v[k], pp);
+              rho[2][0] = eos_eval<MODE, TIn, Ops>(eos, kDensity, hT.v[k], sv, pp);
             }
           } else {
-            TPart<R> tp;
-            SPart<R> sp;
-            if constexpr (STREAM_T) tp = t_part<Ops, R>((R)tv);
-            if constexpr (STREAM_S) sp = s_part<Ops, R>((R)sv, pfold);
-            if constexpr (VAR == kVarSteric) rho[0] = wright_combine<Ops, R>(tp, sp, pz);
-            if constexpr (VAR == kVarHalo) rho[0] = wright_combine<Ops, R>(hTp[k], sp, pz);
-            if constexpr (VAR == kVarThermo) rho[0] = wright_combine<Ops, R>(tp, hSp[k], pz);
+            TPart<RV> tp;
+            SPart<RV> sp;
+            if constexpr (STREAM_T) tp = t_part<Ops, RV>(Lanes<RV>::make(&a[j].v[g * W]));
+            if constexpr (STREAM_S) sp = s_part<Ops, RV>(Lanes<RV>::make(&b[j].v[g * W]), pfold);
+            if constexpr (VAR == kVarSteric) wright_combine_lanes<Ops, RV>(tp, sp, pz, rho[0]);
+            if constexpr (VAR == kVarHalo) wright_combine_lanes<Ops, RV>(hTp[g], sp, pz, rho[0]);
+            if constexpr (VAR == kVarThermo) wright_combine_lanes<Ops, RV>(tp, hSp[g], pz, rho[0]);
             if constexpr (VAR == kVarAll) {
-              rho[0] = wright_combine<Ops, R>(tp, sp, pz);
-              rho[1] = wright_combine<Ops, R>(tp, hSp[k], pz);
-              rho[2] = wright_combine<Ops, R>(hTp[k], sp, pz);
+              wright_combine_lanes<Ops, RV>(tp, sp, pz, rho[0]);
+              wright_combine_lanes<Ops, RV>(tp, hSp[g], pz, rho[1]);
+              wright_combine_lanes<Ops, RV>(hTp[g], sp, pz, rho[2]);
             }
           }
 #pragma unroll
-          for (int o = 0; o < NOUT; ++o) {
-            const double dr = rho[o] - r0.v[k];  // steric.py:152 (NaN where vol0 is NaN)
-            d[o].v[k] = dr;
-            const double term = dzv.v[k] * dr;          // steric.py:163
-            acc[o][j][k] += is_nan(term) ? 0.0 : term;  // skipna, z ascending like numpy
+          for (int w = 0; w < W; ++w) {
+            const int k = g * W + w;
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+              const double dr = rho[o][w] - r0.v[k];  // steric.py:152 (NaN where vol0 is NaN)
+              d[o].v[k] = dr;
+              const double term = dzv.v[k] * dr;          // steric.py:163
+              acc[o][j][k] += is_nan(term) ? 0.0 : term;  // skipna, z ascending like numpy
+            }
           }
         }
         if (drho_out != nullptr) {  // wave-uniform: the eta-only mode skips payload fix and store
