@@ -10,17 +10,23 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 # MOMLEVEL_AMD_LIB: bind another build of the SAME library (scripts/sanitize_host.py points it at
-# the host-sanitized build); the default is the in-tree libmomlevel_hip.so
+# the host-sanitized build of the HIP sources); the default is the in-tree libmomlevel_hip.so.
+# load() refuses anything that is not a HIP build of the ABI (mlx_build_kind) or that lives under
+# the checker's directory oracle/: the CPU restatement exports the same symbols and must never
+# stand in for the device library.
 LIB_PATH = os.environ.get("MOMLEVEL_AMD_LIB") or os.path.join(HERE, "libmomlevel_hip.so")
+_ORACLE_DIR = os.path.join(os.path.dirname(HERE), "oracle")
 
 # ---- constants mirrored from include/momlevel_hip.h --------------------------------
-ABI_VERSION = 2
+ABI_VERSION = 3
 EOS_WRIGHT, EOS_LINEAR = 0, 1
 FUNC_DENSITY, FUNC_DRHO_DTEMP, FUNC_DRHO_DSAL, FUNC_ALPHA, FUNC_BETA = 0, 1, 2, 3, 4
 P_SCALAR, P_ZPROF, P_FULL3D, P_FULL4D = 0, 1, 2, 3
 DTYPE_F64, DTYPE_F32, DTYPE_F32_UPCAST = 0, 1, 2
 FLAG_SKIP_DRY = 1
 FLAG_FMA = 2
+BUILD_HIP, BUILD_HOST = 1, 2
+HOST_PAGE = 4096
 
 
 def flag_tchunk(steps):
@@ -48,6 +54,9 @@ _u64 = ctypes.c_uint64
 SIGNATURES = {
     "mlx_version": (_int, []),
     "mlx_last_error": (_int, [ctypes.c_char_p, _sz]),
+    "mlx_build_kind": (_int, []),
+    "mlx_host_pin": (_int, [_vp, _sz]),
+    "mlx_host_unpin": (_int, [_vp]),
     "mlx_eos_map": (
         _int,
         [_vp, _vp, _int, _vp, _int, _int, _int, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp],
@@ -110,6 +119,11 @@ def load():
             f"{LIB_PATH} not found: momlevel_amd has no CPU fallback. Build the HIP "
             "library with `python -m momlevel_amd.csrc.build` (needs hipcc)."
         )
+    real = os.path.realpath(LIB_PATH)
+    if os.path.commonpath([real, os.path.realpath(_ORACLE_DIR)]) == os.path.realpath(_ORACLE_DIR):
+        raise MomlevelHipError(
+            f"{LIB_PATH} is under oracle/ (the CPU checker): momlevel_amd binds the HIP library only"
+        )
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as exc:  # pragma: no cover - depends on the host
@@ -124,6 +138,11 @@ def load():
     if lib.mlx_version() != ABI_VERSION:
         raise MomlevelHipError(
             f"ABI mismatch: library {lib.mlx_version()} vs binding {ABI_VERSION}; rebuild"
+        )
+    if lib.mlx_build_kind() != BUILD_HIP:
+        raise MomlevelHipError(
+            f"{LIB_PATH} is build kind {lib.mlx_build_kind()}, not the HIP build "
+            f"({BUILD_HIP}): momlevel_amd has no CPU backend"
         )
     _lib = lib
     return lib

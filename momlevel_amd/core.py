@@ -30,22 +30,40 @@ F32_MODES = {"faithful": DTYPE_F32, "upcast": DTYPE_F32_UPCAST}
 ARITH_FLAGS = {"exact": 0, "fused": _lib.FLAG_FMA}
 
 
-def arith_default():
-    """Arithmetic of the Wright density.  "exact" (default): numpy's operator-for-operator
-    evaluation, bit-identical to the reference.  "fused" (opt-in, MOMLEVEL_AMD_ARITH=fused):
-    MLX_FLAG_FMA -- contracted multiply-adds and a Newton reciprocal, a few ulp from numpy
-    (<= 1e-10 relative), about half the VALU work per cell."""
+def arith_default(kernel="k0", dtype=None):
+    """Arithmetic of the Wright density when the caller does not choose (``arith=None``).
+
+    "exact": numpy's operator-for-operator evaluation, bit-identical to the reference.
+    "fused": MLX_FLAG_FMA -- contracted multiply-adds and a Newton reciprocal in float64, <= 2 ulp
+    from numpy on rho (parity gate 1e-10 relative), about two thirds of the VALU work per cell.
+
+    Default policy (MOMLEVEL_AMD_ARITH unset):
+      * K1, the global sums (``domain="global"``: masso(t), src/momlevel/steric.py:134-147), on
+        float64 theta/S -> "fused".  No global result was ever bit-identical to numpy -- the order
+        of summation over (z,y,x) already differs at the 1e-15 level -- so exact arithmetic bought
+        nothing there and kept the held-field variants and the one-pass decomposition on the fp64
+        VALU bound (0.48-0.68 of the HBM roofline instead of 0.6-0.8).  masso(t=0) == masso0 and
+        steric[t=0] == 0.0 hold exactly in this mode too (one expression tree in every kernel).
+      * K0 / K2, the pointwise outputs (rho, delta_rho, local eta) -> "exact": those ARE
+        bit-identical to numpy and stay so.
+      * float32 theta/S -> "exact" in every kernel: the fused policy computes in float64 (float32
+        inputs are upcast), which is ~1e-7 relative away from numpy's own float32 polynomial --
+        further from the reference, not closer.  Ask for it explicitly (arith="fused") if wanted.
+    MOMLEVEL_AMD_ARITH=exact|fused overrides the policy for every kernel and dtype.
+    """
     import os
 
-    mode = os.environ.get("MOMLEVEL_AMD_ARITH", "exact")
+    mode = os.environ.get("MOMLEVEL_AMD_ARITH")
+    if mode is None:
+        return "fused" if (kernel == "k1" and dtype == torch.float64) else "exact"
     if mode not in ARITH_FLAGS:
         raise ValueError(f"MOMLEVEL_AMD_ARITH must be 'exact' or 'fused', got '{mode}'")
     return mode
 
 
-def _arith_flag(arith):
+def _arith_flag(arith, kernel="k0", dtype=None):
     if arith is None:
-        arith = arith_default()
+        arith = arith_default(kernel, dtype)
     try:
         return ARITH_FLAGS[arith]
     except KeyError:
@@ -159,10 +177,12 @@ def _pressure(p, nt, nz, ny, nx, device, allow4d):
 
 def eos_map(T, S, p, eos="wright", func="density", f32_mode="faithful", arith=None):
     """K0: pointwise EOS function over a (nt,nz,ny,nx) or (nz,ny,nx) grid -> float64.
-    ``arith``: "exact" | "fused" | None = arith_default(); applies to the Wright density only."""
+    ``arith``: "exact" | "fused" | None = arith_default("k0", dtype) = exact; applies to the Wright
+    density only."""
     require_device()
-    flags = _arith_flag(arith) if (func == "density" and eos.lower() == "wright") else 0
     T, S, nt, nz, ny, nx, sT, sS, dt, squeeze = _pair(T, S, f32_mode)
+    flags = (_arith_flag(arith, "k0", T.dtype)
+             if (func == "density" and eos.lower() == "wright") else 0)
     pt, p_mode = _pressure(p, nt, nz, ny, nx, T.device, allow4d=True)
     out = torch.empty((nt, nz, ny, nx), dtype=torch.float64, device=T.device)
     with _on(T.device):
@@ -196,10 +216,10 @@ def skip_dry_default():
     return os.environ.get("MOMLEVEL_AMD_SKIP_DRY", "1") != "0"
 
 
-def _launch_flags(skip_dry, arith, t_chunk):
+def _launch_flags(skip_dry, arith, t_chunk, kernel, dtype):
     if skip_dry is None:
         skip_dry = skip_dry_default()
-    flags = (_lib.FLAG_SKIP_DRY if skip_dry else 0) | _arith_flag(arith)
+    flags = (_lib.FLAG_SKIP_DRY if skip_dry else 0) | _arith_flag(arith, kernel, dtype)
     if t_chunk:
         flags |= _lib.flag_tchunk(t_chunk)
     return flags
@@ -212,13 +232,14 @@ def steric_global_masso(T, S, vol0, p, eos="wright", f32_mode="faithful", events
     ``events=(start, end)``: two ``torch.cuda.Event(enable_timing=True)`` recorded on the
     launch stream immediately around the kernel launches (bench.py's per-launch timing).
     ``skip_dry``: MLX_FLAG_SKIP_DRY (None = the default policy, on); results are bit-identical
-    either way.  ``arith``: "exact" | "fused" (None = arith_default()).  ``t_chunk``: tuning
+    either way.  ``arith``: "exact" | "fused" (None = arith_default("k1", dtype): fused for
+    float64 theta/S, exact for float32).  ``t_chunk``: tuning
     hint, time steps per block (multiple of 8; 0 = library default); never changes a result.
     ``p`` may be time dependent, (nt,nz,ny,nx)-broadcastable (a DataArray ``patm``).
     """
     require_device()
-    flags = _launch_flags(skip_dry, arith, t_chunk)
     T, S, nt, nz, ny, nx, sT, sS, dt, _ = _pair(T, S, f32_mode)
+    flags = _launch_flags(skip_dry, arith, t_chunk, "k1", T.dtype)
     vol0 = _f64(vol0, T.device)
     if tuple(vol0.shape) != (nz, ny, nx):
         raise ValueError(f"vol0 has shape {tuple(vol0.shape)}, expected {(nz, ny, nx)}")
@@ -252,8 +273,8 @@ def steric_global_decomp(T, S, T0, S0, vol0, p, eos="wright", f32_mode="faithful
     sum(theta*vol0) (the heat-content integrand; an extension, not in momlevel).  Rows 0-2 are
     bit-identical to three steric_global_masso calls."""
     require_device()
-    flags = _launch_flags(skip_dry, arith, t_chunk)
     T, S, nt, nz, ny, nx, sT, sS, dt, _ = _pair(T, S, f32_mode)
+    flags = _launch_flags(skip_dry, arith, t_chunk, "k1", T.dtype)
     if T.dim() != 4 or S.dim() != 4:
         raise ValueError("steric_global_decomp streams both fields: thetao and so must be 4-D")
     dev = T.device
@@ -316,8 +337,8 @@ def steric_local(T, S, rho0m, vol0_surface, p, neg_inv_rhozero, dz=None, z_i=Non
     """K2: (delta_rho (nt,nz,ny,nx) or None, eta (nt,ny,nx)).  ``skip_dry``, ``arith``: see
     steric_global_masso.  ``p`` may be time dependent (4-D)."""
     require_device()
-    flags = _launch_flags(skip_dry, arith, 0)
     T, S, nt, nz, ny, nx, sT, sS, dt, _ = _pair(T, S, f32_mode)
+    flags = _launch_flags(skip_dry, arith, 0, "k2", T.dtype)
     dev = T.device
     rho0m = _f64(rho0m, dev)
     vol0_surface = _f64(vol0_surface, dev)
@@ -363,8 +384,8 @@ def steric_local_decomp(T, S, T0, S0, rho0m, vol0_surface, p, neg_inv_rhozero, d
     steric_local call.  ``delta_rho_out`` / ``eta_out``: optional (3, nt, ...) float64 device
     tensors (or views whose variant axis has any stride, e.g. ``full[:, t0:t1]``)."""
     require_device()
-    flags = _launch_flags(skip_dry, arith, 0)
     T, S, nt, nz, ny, nx, sT, sS, dt, _ = _pair(T, S, f32_mode)
+    flags = _launch_flags(skip_dry, arith, 0, "k2", T.dtype)
     if T.dim() != 4 or S.dim() != 4:
         raise ValueError("steric_local_decomp streams both fields: thetao and so must be 4-D")
     dev = T.device

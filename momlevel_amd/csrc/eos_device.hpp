@@ -89,32 +89,162 @@ struct Lanes<f2> {
 //   residual correction; the Wright denominator lives near 2^19, far from over/underflow).  Not
 //   bit-identical to numpy: |rho_fused - rho_numpy| <= a few ulp (parity gate 1e-10 relative).
 //   Always float64, also for float32 theta/S (upcast first).
+// ---- the reciprocal ------------------------------------------------------------------------------
+// hipcc expands the IEEE f64 division 1.0/den into
+//     d' = v_div_scale(den)   y = v_rcp_f64(d')   2 x { e = fma(-d',y,1); y = fma(y,e,y) }
+//     n' = v_div_scale(1.0)   q = n'*y   r = fma(-d',q,n')   v_div_fmas(r,y,q)   v_div_fixup
+// (11 VALU instructions of a density's ~45).  The scale instructions multiply by a power of two
+// ONLY when an operand or the quotient is near the ends of the exponent range; the fix-up only
+// patches 0 / inf / NaN operands.  With both scale factors equal to one, q = 1.0*y is y itself
+// and the sequence is the seven instructions of rcp_scale_free() below -- bit-identical to the
+// IEEE expansion for 2^-1000 < |den| < 2^1000 and trivially equivalent (NaN) for a NaN den, i.e.
+// on land.  scripts/check_div.hip measured where it is NOT (profiles/r03_check_div.log): denormal
+// den (v_rcp_f64 of a denormal differs from the scaled sequence), |den| within a few binades of
+// 2^-1024 and of 2^1022 -- so a class test of the seed alone (is it 0, inf, denormal?) is not
+// enough, the guard has to be a two-sided window with a margin.  Two forms:
+//   * window on den, two ordered compares (a NaN den passes both): any float64 operands;
+//   * ONE v_cmp_class on the seed (0 / inf / denormal?) where the window's margins hold by
+//     construction: numpy's float32 polynomial.  There al0, p0, lam are float32 VALUES, so a
+//     non-zero den = lam + al0*(p + p0) lies in [2^-462, 2^930] as soon as the level's pressure is 0
+//     or 2^-200 <= |p| <= 2^800 (a scalar test per level, p_unsafe()); den == 0 and a float32
+//     overflow to inf are what the class test catches.
+typedef unsigned long long lanemask_t;  // one bit per lane, in an SGPR pair
+
+// v_cmp_class_f64 mask of what the seed must NOT be: +-inf, +-denormal, +-0
+constexpr int kClassNotNanNorNormal = 0x004 | 0x010 | 0x020 | 0x040 | 0x080 | 0x200;
+
+// The guard's state is a LANE MASK in scalar registers: a compare writes its result straight into
+// an SGPR pair, the masks of a batch are OR-ed on the scalar unit and the branch is one s_cmp --
+// no VALU work beyond the compares themselves.  Written as the instructions they are: through
+// __builtin_amdgcn_ballot_w64(...) this compiler (ROCm 7.2 clang) round-trips every lane mask
+// through a v_cndmask / v_cmp_ne pair.
+__device__ __forceinline__ lanemask_t lanes_not_nan_nor_normal(double y) {
+  lanemask_t m;
+  asm("v_cmp_class_f64 %0, %1, %2" : "=s"(m) : "v"(y), "s"(kClassNotNanNorNormal));
+  return m;
+}
+// lanes whose |x| is outside (2^-1000, 2^1000); NaN is inside (ordered compares are false on NaN)
+__device__ __forceinline__ lanemask_t lanes_outside_window(double x) {
+  lanemask_t hi, lo;
+  asm("v_cmp_ge_f64 %0, |%1|, %2" : "=s"(hi) : "v"(x), "s"(0x1p+1000));
+  asm("v_cmp_le_f64 %0, |%1|, %2" : "=s"(lo) : "v"(x), "s"(0x1p-1000));
+  return hi | lo;
+}
+
+// -> 1/den by the scale-free sequence (the seed is returned too: the class guard tests it)
+__device__ __forceinline__ double rcp_scale_free(double den, double& seed) {
+  double y = __builtin_amdgcn_rcp(den);
+  seed = y;
+  double e = __builtin_fma(-den, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-den, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-den, y, 1.0);  // r = fma(-d', q, n') with q = y, n' = 1
+  return __builtin_fma(e, y, y);    // v_div_fmas without the rescale
+}
+
 struct ExactOps {
   static constexpr bool fused = false;
+  static constexpr bool guarded = false;
   // (operands may be a float2 vector mixed with scalar constants: the scalars splat)
   template <typename A, typename B, typename C>
   static __device__ __forceinline__ auto mad(A a, B b, C c) -> decltype(a * b + c) {
     return a * b + c;  // two roundings: this file is compiled with contraction off
   }
   // eos/wright.py:47-48: I_denom = 1.0 / den; return (p + p0) * I_denom
-  static __device__ __forceinline__ double quotient(double num, double den) {
+  static __device__ __forceinline__ double quotient(double num, double den, lanemask_t&) {
     const double I_denom = 1.0 / den;
     return num * I_denom;
+  }
+  // lanes that must not take this policy's fast quotient at pressure p (a wave-uniform property)
+  static __device__ __forceinline__ lanemask_t p_unsafe(double) { return 0; }
+};
+
+// ExactOps with the scale-free reciprocal: the SAME bits as ExactOps while no lane objects.  The
+// kernels evaluate a batch of quotients with this policy (quotients<> below), test the objections
+// of the whole wave once (a lane mask in SGPRs) and, if any lane objected, redo the batch with
+// ExactOps -- so no lane ever keeps a result the guard did not vouch for.
+struct ExactFastOps : ExactOps {  // float64 operands: the window on den
+  static constexpr bool guarded = true;
+  static __device__ __forceinline__ double quotient(double num, double den, lanemask_t& unsafe) {
+    unsafe |= lanes_outside_window(den);
+    double seed;
+    return num * rcp_scale_free(den, seed);
+  }
+};
+struct ExactFastF32Ops : ExactOps {  // float32-valued al0, p0, lam: the class of the seed
+  static constexpr bool guarded = true;
+  static __device__ __forceinline__ double quotient(double num, double den, lanemask_t& unsafe) {
+    double seed;
+    const double r = rcp_scale_free(den, seed);
+    unsafe |= lanes_not_nan_nor_normal(seed);
+    return num * r;
+  }
+  static __device__ __forceinline__ lanemask_t p_unsafe(double p) {
+    const double a = __builtin_fabs(p);
+    const bool ok = !(a > 0x1p+800) && !(a < 0x1p-200 && p != 0.0);  // NaN: every result is NaN anyway
+    return ok ? 0 : ~(lanemask_t)0;
   }
 };
 
 struct FusedOps {
   static constexpr bool fused = true;
+  static constexpr bool guarded = true;
   template <typename R>
   static __device__ __forceinline__ R mad(R a, R b, R c) {
     return __builtin_fma(a, b, c);
   }
-  static __device__ __forceinline__ double quotient(double num, double den) {
+  // Nothing here has to match numpy's bits, so the guard only has to keep the quotient SANE: the
+  // class of the seed sends 0, inf and huge denominators (seed inf / 0 / denormal) to the IEEE
+  // division of FusedSlowOps, which then yields numpy's inf / 0 instead of a NaN.
+  static __device__ __forceinline__ double quotient(double num, double den, lanemask_t& unsafe) {
     double r = __builtin_amdgcn_rcp(den);           // ~2^-23 relative
+    unsafe |= lanes_not_nan_nor_normal(r);
     r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);  // ~2^-45
     const double q = num * r;
     return __builtin_fma(__builtin_fma(-den, q, num), r, q);  // exact residual: <= 1 ulp
   }
+  static __device__ __forceinline__ lanemask_t p_unsafe(double) { return 0; }
+};
+
+// FusedOps' arithmetic with the IEEE division: what a wave falls back to when FusedOps' guard
+// objects, so that 0 / inf / denormal denominators behave as in numpy (inf, 0, ...) in fused mode
+struct FusedSlowOps : FusedOps {
+  static constexpr bool guarded = false;
+  static __device__ __forceinline__ double quotient(double num, double den, lanemask_t&) {
+    return num / den;
+  }
+};
+
+// FusedOps without the guard, for the one kernel that has no register to spare for it (K1's
+// all-variants pass): identical bits wherever FusedOps' guard stays quiet, i.e. on any ocean data;
+// a 0 / inf / denormal denominator yields NaN (skipped by the sums) instead of numpy's inf / 0.
+struct FusedUnguardedOps : FusedOps {
+  static constexpr bool guarded = false;
+  static __device__ __forceinline__ double quotient(double num, double den, lanemask_t&) {
+    double r = __builtin_amdgcn_rcp(den);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    const double q = num * r;
+    return __builtin_fma(__builtin_fma(-den, q, num), r, q);
+  }
+};
+
+// the unguarded twin of a policy: what the kernels rerun a wave's work with after an objection
+template <typename Ops>
+struct SlowOf {
+  typedef Ops type;
+};
+template <>
+struct SlowOf<ExactFastOps> {
+  typedef ExactOps type;
+};
+template <>
+struct SlowOf<ExactFastF32Ops> {
+  typedef ExactOps type;
+};
+template <>
+struct SlowOf<FusedOps> {
+  typedef FusedSlowOps type;
 };
 
 // ---- the Wright polynomial, split into the part that depends on T only, the part that depends
@@ -163,22 +293,63 @@ __device__ __forceinline__ SPart<R> s_part(R S, R p_fold) {
   return h;
 }
 
-// rho from the two parts: eos/wright.py:44-48.  out[i] = density of lane i (Lanes<R>::n cells)
+// numerator (p + p0) and denominator (lam + al0*(p + p0)) of the density from the two parts,
+// eos/wright.py:44-47, for the Lanes<R>::n cells of one arithmetic group
 template <typename Ops, typename R>
-__device__ __forceinline__ void wright_combine_lanes(const TPart<R>& a, const SPart<R>& b, double p,
-                                                     double* out) {
+__device__ __forceinline__ void wright_numden_lanes(const TPart<R>& a, const SPart<R>& b, double p,
+                                                    double* num, double* den) {
   const R al0 = a.a01 + b.a2s;
   const R p0 = Ops::mad(a.t, a.tb + b.b5s, b.b04);
   const R lam = Ops::mad(a.t, a.tc + b.c5s, b.c04);
 #pragma unroll
   for (int i = 0; i < Lanes<R>::n; ++i) {
-    double pp0;
-    if constexpr (Ops::fused) pp0 = Lanes<R>::get(p0, i);  // p is inside b04
-    else pp0 = p + Lanes<R>::get(p0, i);
-    const double den = Ops::mad(Lanes<R>::get(al0, i), pp0, Lanes<R>::get(lam, i));  // lam + al0*(p+p0)
-    out[i] = Ops::quotient(pp0, den);
+    if constexpr (Ops::fused) num[i] = Lanes<R>::get(p0, i);  // p is inside b04
+    else num[i] = p + Lanes<R>::get(p0, i);
+    den[i] = Ops::mad(Lanes<R>::get(al0, i), num[i], Lanes<R>::get(lam, i));  // lam + al0*(p+p0)
   }
 }
+
+// out[i] = num[i] * (1/den[i]) (eos/wright.py:47-48) for a batch of N cells of one thread.  A
+// guarded policy (ExactFastOps, FusedOps) takes the scale-free reciprocal, tests the seeds' class
+// flags of the WHOLE WAVE once and, if any lane objected, redoes the batch with the IEEE division
+// (SlowOf<Ops>): a wave-uniform scalar branch around eleven instructions per cell that is never
+// taken on ocean data.  The volatile asm keeps the compiler from turning the branch into selects
+// (it would then evaluate both sides).  Nothing but num/den -- live until the end of the batch
+// anyway -- is needed by the fallback, so the guard costs no registers.
+template <typename Ops, int N>
+__device__ __forceinline__ void quotients(const double* num, const double* den, double* out,
+                                          lanemask_t preset = 0) {
+  lanemask_t unsafe = preset;  // Ops::p_unsafe(p) of the level: all lanes, or none
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[i] = Ops::quotient(num[i], den[i], unsafe);
+  if constexpr (Ops::guarded) {
+    if (__builtin_expect(unsafe != 0, 0)) {
+      asm volatile("; IEEE-division fallback" ::);
+#pragma unroll
+      for (int i = 0; i < N; ++i) out[i] = SlowOf<Ops>::type::quotient(num[i], den[i], unsafe);
+      asm volatile("; end of fallback" ::);
+    }
+  }
+}
+
+// rho from the two parts: eos/wright.py:44-48.  out[i] = density of lane i (Lanes<R>::n cells)
+template <typename Ops, typename R>
+__device__ __forceinline__ void wright_combine_lanes(const TPart<R>& a, const SPart<R>& b, double p,
+                                                     double* out) {
+  double num[Lanes<R>::n], den[Lanes<R>::n];
+  wright_numden_lanes<Ops, R>(a, b, p, num, den);
+  quotients<Ops, Lanes<R>::n>(num, den, out, Ops::p_unsafe(p));
+}
+
+// the guarded exact policy for a dtype mode: see "the reciprocal" above
+template <int MODE>
+struct ExactFastFor {
+  typedef ExactFastOps type;
+};
+template <>
+struct ExactFastFor<kF32Faithful> {
+  typedef ExactFastF32Ops type;
+};
 
 template <typename Ops, typename R>
 __device__ __forceinline__ double wright_combine(const TPart<R>& a, const SPart<R>& b, double p) {

@@ -158,7 +158,16 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
   // (eos_device.hpp, PolyVec), single cells otherwise
   typedef typename PolyVec<MODE, GENERIC ? 1 : VEC>::type RV;
   constexpr int W = Lanes<RV>::n, G = VEC / W;
-  typedef typename std::conditional<FMA, FusedOps, ExactOps>::type Ops;
+  // guarded policies in the fast kernels: the scale-free reciprocal with a per-wave fallback to
+  // the IEEE division (eos_device.hpp, quotients<>); same bits as ExactOps in exact mode.  The
+  // all-variants kernel sits at the 256-VGPR / 2-waves-per-SIMD edge and every form of the guard
+  // measured (per batch, per step with reloaded operands) pushed it over: it keeps the IEEE
+  // division (exact) and the unguarded Newton quotient (fused) -- the same bits as the guarded
+  // single-variant launches wherever their guard stays quiet.
+  constexpr bool GUARD = !GENERIC && VAR != kVarAll;
+  typedef typename std::conditional<
+      FMA, typename std::conditional<GUARD || GENERIC, FusedOps, FusedUnguardedOps>::type,
+      typename std::conditional<GUARD, typename ExactFastFor<MODE>::type, ExactOps>::type>::type Ops;
   static_assert(!FMA || MODE != kF32Faithful, "fused arithmetic is float64");
   __shared__ double red[NOUT][NTC][kBlock];
 
@@ -204,6 +213,7 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
   if (GENERIC && p_mode == MLX_P_SCALAR) pz = p[0];
   RV pfold = RV{};  // FusedOps (float64 only) folds the level's pressure into B0
   if constexpr (FMA) pfold = (R)pz;
+  const lanemask_t pbad = Ops::p_unsafe(pz);  // the level's pressure vetoes the fast quotient?
 
   // held fields: read once; fast path keeps their PART of the polynomial, generic the values
   TPart<RV> t0p[(HELD_T && !GENERIC) ? U : 1][G];
@@ -290,48 +300,74 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (SKIP && !alive[u]) continue;  // adds exactly nothing: c + 0.0 == c
+      constexpr int NR = NOUT > 1 ? 3 : 1;
+      double rho[NR][VEC];
+      if constexpr (GENERIC) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        constexpr int NR = NOUT > 1 ? 3 : 1;
-        double rho[NR][W];
-        if constexpr (GENERIC) {  // W == 1
-          const int k = g;
+        for (int k = 0; k < VEC; ++k) {
           double pp = pz;
           if (p_mode == MLX_P_FULL3D) pp = pc[u][k];
           if (p_mode == MLX_P_FULL4D) pp = p[((int64_t)t * nz) * plane + off[u] + k];
           const TIn tv = STREAM_T ? curT[u].v[k] : t0v[u][k];
           const TIn sv = STREAM_S ? curS[u].v[k] : s0v[u][k];
-          rho[0][0] = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, sv, pp);
+          rho[0][k] = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, sv, pp);
           if constexpr (VAR == kVarAll) {
-            rho[1][0] = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, s0v[u][k], pp);
-            rho[2][0] = eos_eval<MODE, TIn, Ops>(eos, kDensity, t0v[u][k], sv, pp);
+            rho[1][k] = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, s0v[u][k], pp);
+            rho[2][k] = eos_eval<MODE, TIn, Ops>(eos, kDensity, t0v[u][k], sv, pp);
           }
-        } else {
+        }
+      } else if constexpr (VAR == kVarAll) {
+        // three quotients per cell (unguarded policies in this kernel, see Ops above); summed group
+        // by group -- the same cell order as below, fewer densities live at a time
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const TPart<RV> a = t_part<Ops, RV>(Lanes<RV>::make(&curT[u].v[g * W]));
+          const SPart<RV> b = s_part<Ops, RV>(Lanes<RV>::make(&curS[u].v[g * W]), pfold);
+          double r3[3][W];
+          wright_combine_lanes<Ops, RV>(a, b, pz, r3[0]);
+          wright_combine_lanes<Ops, RV>(a, s0p[u][g], pz, r3[1]);
+          wright_combine_lanes<Ops, RV>(t0p[u][g], b, pz, r3[2]);
+#pragma unroll
+          for (int w = 0; w < W; ++w) {
+            const int k = g * W + w;
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+              const double term = r3[o][w] * vol[u][k];
+              c[o] += is_nan(term) ? 0.0 : term;
+            }
+            const double term = (double)curT[u].v[k] * vol[u][k];  // extension: heat content
+            c[3] += is_nan(term) ? 0.0 : term;
+          }
+        }
+        continue;
+      } else {
+        // one guarded batch of quotients per pack (VEC cells)
+        double num[VEC], den[VEC];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
           TPart<RV> a;
           SPart<RV> b;
           if constexpr (STREAM_T) a = t_part<Ops, RV>(Lanes<RV>::make(&curT[u].v[g * W]));
           if constexpr (STREAM_S) b = s_part<Ops, RV>(Lanes<RV>::make(&curS[u].v[g * W]), pfold);
-          if constexpr (VAR == kVarSteric) wright_combine_lanes<Ops, RV>(a, b, pz, rho[0]);
-          if constexpr (VAR == kVarHalo) wright_combine_lanes<Ops, RV>(t0p[u][g], b, pz, rho[0]);
-          if constexpr (VAR == kVarThermo) wright_combine_lanes<Ops, RV>(a, s0p[u][g], pz, rho[0]);
-          if constexpr (VAR == kVarAll) {
-            wright_combine_lanes<Ops, RV>(a, b, pz, rho[0]);
-            wright_combine_lanes<Ops, RV>(a, s0p[u][g], pz, rho[1]);
-            wright_combine_lanes<Ops, RV>(t0p[u][g], b, pz, rho[2]);
-          }
+          if constexpr (VAR == kVarSteric)
+            wright_numden_lanes<Ops, RV>(a, b, pz, &num[g * W], &den[g * W]);
+          if constexpr (VAR == kVarHalo)
+            wright_numden_lanes<Ops, RV>(t0p[u][g], b, pz, &num[g * W], &den[g * W]);
+          if constexpr (VAR == kVarThermo)
+            wright_numden_lanes<Ops, RV>(a, s0p[u][g], pz, &num[g * W], &den[g * W]);
         }
+        quotients<Ops, VEC>(num, den, rho[0], pbad);
+      }
 #pragma unroll
-        for (int w = 0; w < W; ++w) {  // cells in ascending order: the order of summation is fixed
-          const int k = g * W + w;
+      for (int k = 0; k < VEC; ++k) {  // cells in ascending order: the order of summation is fixed
 #pragma unroll
-          for (int o = 0; o < NR; ++o) {
-            const double term = rho[o][w] * vol[u][k];  // derived.py:435
-            c[o] += is_nan(term) ? 0.0 : term;          // skipna
-          }
-          if constexpr (VAR == kVarAll) {  // extension: heat-content integrand theta*vol0
-            const double term = (double)curT[u].v[k] * vol[u][k];
-            c[3] += is_nan(term) ? 0.0 : term;
-          }
+        for (int o = 0; o < NR; ++o) {
+          const double term = rho[o][k] * vol[u][k];  // derived.py:435
+          c[o] += is_nan(term) ? 0.0 : term;          // skipna
+        }
+        if constexpr (VAR == kVarAll) {  // extension: heat-content integrand theta*vol0
+          const double term = (double)curT[u].v[k] * vol[u][k];
+          c[3] += is_nan(term) ? 0.0 : term;
         }
       }
     }
@@ -454,7 +490,11 @@ __global__ __launch_bounds__(kBlock) void k_eos_map(const TIn* __restrict__ T,
                                                     int64_t t_stride_T, int64_t t_stride_S,
                                                     int64_t t_base, double aux,
                                                     double* __restrict__ out) {
-  typedef typename std::conditional<FMA, FusedOps, ExactOps>::type Ops;
+  // the fast density kernels use the guarded policies (scale-free reciprocal, eos_device.hpp)
+  typedef typename std::conditional<
+      FMA, FusedOps,
+      typename std::conditional<!GENERIC && FUNC == kDensity, typename ExactFastFor<MODE>::type,
+                                ExactOps>::type>::type Ops;
   const int z = blockIdx.y;
   const int64_t t = t_base + blockIdx.z;
   const int64_t tile0 = (int64_t)blockIdx.x * (kBlock * VEC * U);
@@ -476,25 +516,33 @@ __global__ __launch_bounds__(kBlock) void k_eos_map(const TIn* __restrict__ T,
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     Pack<double, VEC> r;
+    if constexpr (GENERIC) {
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-      if constexpr (GENERIC) {
+      for (int k = 0; k < VEC; ++k) {
         double pp = pz;
         if (p_mode == MLX_P_FULL3D) pp = p[off[u] + k];
         if (p_mode == MLX_P_FULL4D) pp = p[t * nz * plane + off[u] + k];
         r.v[k] = eos_eval<MODE, TIn, Ops>(eos, func, a[u].v[k], b[u].v[k], pp, aux);
-      } else if constexpr (FUNC == kDensity && MODE == kF32Faithful) {
-        if (k % 2 == 0) {  // the float32 polynomial on float2 pairs (see K1)
-          double two[2];
-          wright_combine_lanes<ExactOps, f2>(t_part<ExactOps, f2>(Lanes<f2>::make(&a[u].v[k])),
-                                            s_part<ExactOps, f2>(Lanes<f2>::make(&b[u].v[k]), f2{}),
-                                            pz, two);
-          r.v[k] = two[0];
-          r.v[k + 1] = two[1];
-        }
-      } else {
-        r.v[k] = eos_eval<MODE, TIn, Ops>(kWright, FUNC, a[u].v[k], b[u].v[k], pz);
       }
+    } else if constexpr (FUNC == kDensity) {
+      // float32 faithful: the polynomial on float2 pairs (see K1), otherwise cell by cell; one
+      // guarded batch of quotients per pack
+      typedef typename PolyType<MODE>::type R;
+      typedef typename PolyVec<MODE, VEC>::type RV;
+      constexpr int W = Lanes<RV>::n;
+      RV pfold = RV{};
+      if constexpr (Ops::fused) pfold = (R)pz;
+      double num[VEC], den[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; k += W)
+        wright_numden_lanes<Ops, RV>(t_part<Ops, RV>(Lanes<RV>::make(&a[u].v[k])),
+                                     s_part<Ops, RV>(Lanes<RV>::make(&b[u].v[k]), pfold), pz,
+                                     &num[k], &den[k]);
+      quotients<Ops, VEC>(num, den, r.v, Ops::p_unsafe(pz));
+    } else {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k)
+        r.v[k] = eos_eval<MODE, TIn, Ops>(kWright, FUNC, a[u].v[k], b[u].v[k], pz);
     }
     if (valid[u]) store_pack<VEC, true>(out + t * nz * plane + off[u], r);
   }
@@ -555,7 +603,9 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
   typedef typename PolyType<MODE>::type R;
   typedef typename PolyVec<MODE, GENERIC ? 1 : VEC>::type RV;  // float2 pairs: see K1
   constexpr int W = Lanes<RV>::n, G = VEC / W;
-  typedef typename std::conditional<FMA, FusedOps, ExactOps>::type Ops;
+  typedef typename std::conditional<
+      FMA, FusedOps,
+      typename std::conditional<GENERIC, ExactOps, typename ExactFastFor<MODE>::type>::type>::type Ops;
   static_assert(!FMA || MODE != kF32Faithful, "fused arithmetic is float64");
   const int64_t col = (xcd_remap(blockIdx.x, gridDim.x) * kBlock + threadIdx.x) * VEC;
   if (col + VEC > plane) return;  // whole packs only; no barrier below
@@ -641,44 +691,51 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
         // dry lanes (SKIP) run the same arithmetic on zeros: rho - NaN is NaN and the NaN term is
         // skipped, exactly as if theta/S had been loaded.  Only their LOADS are masked -- a
         // divergent store path would split every partly-dry line into two transactions.
+        double rho[NOUT][VEC];
+        if constexpr (GENERIC) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-          double rho[NOUT][W];
-          if constexpr (GENERIC) {  // W == 1
-            const int k = g;
+          for (int k = 0; k < VEC; ++k) {
             const TIn tv = STREAM_T ? a[j].v[k] : hT.v[k];
             const TIn sv = STREAM_S ? b[j].v[k] : hS.v[k];
             double pp = (p_mode == MLX_P_FULL3D) ? pfull.v[k] : pz;
             if (p_mode == MLX_P_FULL4D) pp = p[(int64_t)(t0 + j) * n3 + off + k];
-            rho[0][0] = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, sv, pp);
+            rho[0][k] = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, sv, pp);
             if constexpr (VAR == kVarAll) {
-              rho[1][0] = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, hS.v[k], pp);
-              rho[2][0] = eos_eval<MODE, TIn, Ops>(eos, kDensity, hT.v[k], sv, pp);
+              rho[1][k] = eos_eval<MODE, TIn, Ops>(eos, kDensity, tv, hS.v[k], pp);
+              rho[2][k] = eos_eval<MODE, TIn, Ops>(eos, kDensity, hT.v[k], sv, pp);
             }
-          } else {
+          }
+        } else {
+          // one guarded batch of quotients (eos_device.hpp) per pack and time step: VEC cells x
+          // NOUT variants
+          double num[NOUT][VEC], den[NOUT][VEC];
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
             TPart<RV> tp;
             SPart<RV> sp;
             if constexpr (STREAM_T) tp = t_part<Ops, RV>(Lanes<RV>::make(&a[j].v[g * W]));
             if constexpr (STREAM_S) sp = s_part<Ops, RV>(Lanes<RV>::make(&b[j].v[g * W]), pfold);
-            if constexpr (VAR == kVarSteric) wright_combine_lanes<Ops, RV>(tp, sp, pz, rho[0]);
-            if constexpr (VAR == kVarHalo) wright_combine_lanes<Ops, RV>(hTp[g], sp, pz, rho[0]);
-            if constexpr (VAR == kVarThermo) wright_combine_lanes<Ops, RV>(tp, hSp[g], pz, rho[0]);
+            double* const n0 = &num[0][g * W];
+            double* const d0 = &den[0][g * W];
+            if constexpr (VAR == kVarSteric) wright_numden_lanes<Ops, RV>(tp, sp, pz, n0, d0);
+            if constexpr (VAR == kVarHalo) wright_numden_lanes<Ops, RV>(hTp[g], sp, pz, n0, d0);
+            if constexpr (VAR == kVarThermo) wright_numden_lanes<Ops, RV>(tp, hSp[g], pz, n0, d0);
             if constexpr (VAR == kVarAll) {
-              wright_combine_lanes<Ops, RV>(tp, sp, pz, rho[0]);
-              wright_combine_lanes<Ops, RV>(tp, hSp[g], pz, rho[1]);
-              wright_combine_lanes<Ops, RV>(hTp[g], sp, pz, rho[2]);
+              wright_numden_lanes<Ops, RV>(tp, sp, pz, n0, d0);
+              wright_numden_lanes<Ops, RV>(tp, hSp[g], pz, &num[1][g * W], &den[1][g * W]);
+              wright_numden_lanes<Ops, RV>(hTp[g], sp, pz, &num[2][g * W], &den[2][g * W]);
             }
           }
+          quotients<Ops, NOUT * VEC>(&num[0][0], &den[0][0], &rho[0][0], Ops::p_unsafe(pz));
+        }
 #pragma unroll
-          for (int w = 0; w < W; ++w) {
-            const int k = g * W + w;
+        for (int k = 0; k < VEC; ++k) {
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o) {
-              const double dr = rho[o][w] - r0.v[k];  // steric.py:152 (NaN where vol0 is NaN)
-              d[o].v[k] = dr;
-              const double term = dzv.v[k] * dr;          // steric.py:163
-              acc[o][j][k] += is_nan(term) ? 0.0 : term;  // skipna, z ascending like numpy
-            }
+          for (int o = 0; o < NOUT; ++o) {
+            const double dr = rho[o][k] - r0.v[k];  // steric.py:152 (NaN where vol0 is NaN)
+            d[o].v[k] = dr;
+            const double term = dzv.v[k] * dr;          // steric.py:163
+            acc[o][j][k] += is_nan(term) ? 0.0 : term;  // skipna, z ascending like numpy
           }
         }
         if (drho_out != nullptr) {  // wave-uniform: the eta-only mode skips payload fix and store
@@ -862,6 +919,9 @@ int check_common(const void* T, const void* S, int dtype, const double* p, int p
   if (eos != MLX_EOS_WRIGHT && eos != MLX_EOS_LINEAR) return fail(MLX_E_ENUM, "unknown eos");
   if (p_mode < MLX_P_SCALAR || p_mode > MLX_P_FULL4D) return fail(MLX_E_ENUM, "unknown p_mode");
   if (!p && eos == MLX_EOS_WRIGHT) return fail(MLX_E_NULL, "p must not be NULL for the Wright EOS");
+  // a NULL p (linear EOS) is replaced by a placeholder pointer the kernels never dereference -- which
+  // holds for MLX_P_SCALAR only: the array modes would index the placeholder
+  if (!p && p_mode != MLX_P_SCALAR) return fail(MLX_E_NULL, "a NULL p requires p_mode MLX_P_SCALAR");
   if (nt <= 0 || nz <= 0 || plane <= 0) return fail(MLX_E_SHAPE, "nt, nz, plane must be > 0");
   if (nz > 65535) return fail(MLX_E_SHAPE, "nz must be <= 65535");
   if (nt > 2147483647LL) return fail(MLX_E_SHAPE, "nt too large");
@@ -1144,6 +1204,30 @@ int mlx_last_error(char* buf, size_t n) {
     buf[n - 1] = 0;
   }
   return (int)strlen(g_err);
+}
+
+int mlx_build_kind(void) { return MLX_BUILD_HIP; }
+
+// ---------------------------------------------------------------------------- host pinning
+// A failed hipHostRegister / hipHostUnregister leaves a sticky error that the NEXT unrelated
+// hipGetLastError() (e.g. torch's kernel-launch check) would report: fetch it here.
+static int host_pin_status(hipError_t e, const char* what) {
+  if (e == hipSuccess) return 0;
+  (void)hipGetLastError();
+  return hip_status(e, what);
+}
+
+int mlx_host_pin(void* ptr, size_t nbytes) {
+  if (!ptr) return fail(MLX_E_NULL, "ptr must not be NULL");
+  if (nbytes == 0) return fail(MLX_E_SHAPE, "nbytes must be > 0");
+  if (!aligned(ptr, MLX_HOST_PAGE) || nbytes % MLX_HOST_PAGE)
+    return fail(MLX_E_ALIGN, "mlx_host_pin: ptr and nbytes must be multiples of the 4 KiB page");
+  return host_pin_status(hipHostRegister(ptr, nbytes, hipHostRegisterDefault), "hipHostRegister");
+}
+
+int mlx_host_unpin(void* ptr) {
+  if (!ptr) return fail(MLX_E_NULL, "ptr must not be NULL");
+  return host_pin_status(hipHostUnregister(ptr), "hipHostUnregister");
 }
 
 // ---------------------------------------------------------------------------- K0

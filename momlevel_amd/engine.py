@@ -15,7 +15,7 @@ import warnings
 import numpy as np
 import torch
 
-from . import core
+from . import _lib, core
 
 _GIB = 1 << 30
 
@@ -57,6 +57,54 @@ def chunk_steps(nt, bytes_per_step, device, budget_bytes=None):
         free, _total = torch.cuda.mem_get_info(device)
         budget_bytes = min(free // 3, 4 * _GIB)  # small chunks: deeper H2D|compute|D2H overlap
     return int(max(1, min(nt, budget_bytes // max(1, 2 * bytes_per_step))))
+
+
+# ---------------------------------------------------------------------------------------
+# in-place page-locking of the caller's arrays (C ABI: mlx_host_pin / mlx_host_unpin)
+# ---------------------------------------------------------------------------------------
+_PAGE = _lib.HOST_PAGE
+_LIVE_PINS = {}  # page-aligned start -> end of every range this process currently has pinned
+
+
+def page_interior(ptr, nbytes, page=_PAGE):
+    """The largest page-aligned range inside [ptr, ptr+nbytes): -> (lo, hi), hi <= lo when the
+    buffer holds no whole page.  Only this interior is ever page-locked: a page that the buffer
+    merely touches may hold other heap objects (numpy arrays below glibc's mmap threshold live in
+    the brk heap) or the neighbouring time chunk's first bytes, and must not be registered."""
+    lo = -(-ptr // page) * page
+    hi = ((ptr + nbytes) // page) * page
+    return lo, hi
+
+
+def _overlaps_live_pin(lo, hi):
+    return any(lo < e and s < hi for s, e in _LIVE_PINS.items())
+
+
+def pin_interior(lo, hi):
+    """Page-lock [lo, hi) unless some page of it is pinned already -> True when pinned.  A refusal
+    by the runtime (locked-memory limit, foreign registration, ...) is not an error: nothing was
+    registered, and the caller copies synchronously instead."""
+    if hi <= lo or _overlaps_live_pin(lo, hi):
+        return False
+    rc = _lib.load().mlx_host_pin(lo, hi - lo)
+    if rc != 0:
+        warnings.warn(f"asynchronous upload disabled for this chunk: {_lib.last_error()} "
+                      f"(status {rc}); copying synchronously", RuntimeWarning, stacklevel=3)
+        return False
+    _LIVE_PINS[lo] = hi
+    return True
+
+
+def unpin_interior(lo):
+    """Release a range pinned by pin_interior.  A failure here is NOT survivable: the range would
+    stay registered while its memory goes back to the allocator, and the next pageable copy from
+    recycled memory would be treated as pinned -- raise."""
+    rc = _lib.load().mlx_host_unpin(lo)
+    _LIVE_PINS.pop(lo, None)
+    if rc != 0:
+        raise core.MomlevelHipError(
+            f"hipHostUnregister failed for the upload buffer at {lo:#x} (status {rc}): "
+            f"{_lib.last_error()}")
 
 
 def _host_tensor(a, dtype=None):
@@ -105,22 +153,22 @@ class TimeChunks:
         self._held = [
             to_device(f, device, _stream_dtype(f)) if f.ndim == 3 else None for f in self.fields
         ]
-        # asynchronous uploads: the caller's pages are page-locked in place for the duration of
-        # the copy (hipHostRegister), so the H2D of a chunk runs on its own stream and overlaps
-        # the previous chunk's kernels and result download; any failure falls back to a blocking copy
+        # asynchronous uploads: the page-aligned interior of the caller's chunk is page-locked in
+        # place for the duration of the copy (page_interior / pin_interior), so the H2D of a chunk
+        # runs on its own stream and overlaps the previous chunk's kernels and result download
         self._copy_stream = None if all(self.resident) else torch.cuda.Stream(device=device)
-        self._registered = []  # (pointer, completion event, keep-alive tensor)
+        self._registered = []  # (pinned range start or None, completion event, keep-alive objects)
 
     def _release(self, wait=False):
-        cudart = torch.cuda.cudart()
         keep = []
-        for ptr, ev, host in self._registered:
+        for lo, ev, alive in self._registered:
             if wait:
                 ev.synchronize()
             if ev.query():
-                cudart.cudaHostUnregister(ptr)
+                if lo is not None:
+                    unpin_interior(lo)  # raises if the runtime refuses: never leave a stale pin
             else:
-                keep.append((ptr, ev, host))
+                keep.append((lo, ev, alive))
         self._registered = keep
 
     def _upload(self, f, t0, t1):
@@ -131,28 +179,42 @@ class TimeChunks:
         host = _host_tensor(src, np.float32 if dt == torch.float32 else np.float64)
         dev = torch.empty(host.shape, dtype=dt, device=self.device)
         ptr, nbytes = host.data_ptr(), host.numel() * host.element_size()
-        # In-place page-locking pays (and is exercised) only for real chunks: a copy of less than
-        # a MiB is latency-bound either way, and small numpy arrays share heap pages with other
-        # objects -- they are not worth a register/unregister round trip through the driver.
+        # In-place page-locking pays only for real chunks: a copy of less than a MiB is
+        # latency-bound either way.
         min_bytes = int(os.environ.get("MOMLEVEL_AMD_ASYNC_H2D_MIN_BYTES", str(1 << 20)))
-        if (self._copy_stream is not None and nbytes >= min_bytes
-                and os.environ.get("MOMLEVEL_AMD_ASYNC_H2D", "1") != "0"):
-            try:
-                rc = torch.cuda.cudart().cudaHostRegister(ptr, nbytes, 0)
-            except RuntimeError:
-                rc = 1
-            if int(rc) == 0:
-                main = torch.cuda.current_stream(self.device)
-                self._copy_stream.wait_stream(main)  # `dev` may reuse memory main is done with
-                with torch.cuda.stream(self._copy_stream):
-                    dev.copy_(host, non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record(self._copy_stream)
-                dev.record_stream(self._copy_stream)
-                main.wait_event(ev)
-                self._registered.append((ptr, ev, host))
-                return dev
-        dev.copy_(host)
+        lo, hi = page_interior(ptr, nbytes)
+        if (self._copy_stream is None or hi - lo < max(min_bytes, _PAGE)
+                or os.environ.get("MOMLEVEL_AMD_ASYNC_H2D", "1") == "0"):
+            dev.copy_(host)
+            return dev
+        already = host.is_pinned()  # e.g. the caller's array lives in a torch pinned tensor
+        pinned = (not already) and pin_interior(lo, hi)
+        if not (already or pinned):
+            dev.copy_(host)
+            return dev
+        hb, db = host.view(torch.uint8).reshape(-1), dev.view(torch.uint8).reshape(-1)
+        head, tail = (0, 0) if already else (lo - ptr, ptr + nbytes - hi)
+        # the ragged head and tail (< one page each) travel through a small page-locked staging
+        # buffer of our own, so that the whole upload is asynchronous and no page of the caller's
+        # that we did not register is ever handed to the DMA engine
+        frag = None
+        if head or tail:
+            frag = torch.empty(head + tail, dtype=torch.uint8, pin_memory=True)
+            frag[:head] = hb[:head]
+            frag[head:] = hb[nbytes - tail:]
+        main = torch.cuda.current_stream(self.device)
+        self._copy_stream.wait_stream(main)  # `dev` may reuse memory main is done with
+        with torch.cuda.stream(self._copy_stream):
+            db[head:nbytes - tail].copy_(hb[head:nbytes - tail], non_blocking=True)
+            if head:
+                db[:head].copy_(frag[:head], non_blocking=True)
+            if tail:
+                db[nbytes - tail:].copy_(frag[head:], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._copy_stream)
+        dev.record_stream(self._copy_stream)
+        main.wait_event(ev)
+        self._registered.append((lo if pinned else None, ev, (host, frag)))
         return dev
 
     def _stage(self, t0, t1):
@@ -178,12 +240,13 @@ class TimeChunks:
                 self._release()
         finally:
             self._release(wait=True)
+            assert self._registered == [], "an upload buffer is still page-locked"
 
 
 def time_dependent(pres):
     """True for a pressure that carries the time axis: (nt, nz|1, ny|1, nx|1) -- ``patm`` given as
     a DataArray with a time dimension (steric.py:58-60,96)."""
-    return getattr(pres, "ndim", 0) == 4
+    return getattr(pres, "ndim", 0) == 4 and pres.shape[0] != 1  # (1,nz,1,1): a z profile
 
 
 def pressure_chunk(pres, t0, t1, device):

@@ -179,12 +179,29 @@ static int check_common(const void *T, const void *S, int dtype, const double *p
   if (eos != MLX_EOS_WRIGHT && eos != MLX_EOS_LINEAR) return fail(MLX_E_ENUM, "unknown eos");
   if (p_mode < MLX_P_SCALAR || p_mode > MLX_P_FULL4D) return fail(MLX_E_ENUM, "unknown p_mode");
   if (!p && eos == MLX_EOS_WRIGHT) return fail(MLX_E_NULL, "p must not be NULL for the Wright EOS");
+  if (!p && p_mode != MLX_P_SCALAR) return fail(MLX_E_NULL, "a NULL p requires p_mode MLX_P_SCALAR");
   if (nt <= 0 || nz <= 0 || plane <= 0) return fail(MLX_E_SHAPE, "nt, nz, plane must be > 0");
   if (sT < 0 || sS < 0) return fail(MLX_E_SHAPE, "time strides must be >= 0");
   return 0;
 }
 
 int mlx_version(void) { return MLX_ABI_VERSION; }
+
+int mlx_build_kind(void) { return MLX_BUILD_HOST; } /* the product refuses to bind this build */
+
+/* nothing to page-lock on the host: argument checks only (the same as the device library's) */
+int mlx_host_pin(void *ptr, size_t nbytes) {
+  if (!ptr) return fail(MLX_E_NULL, "ptr must not be NULL");
+  if (nbytes == 0) return fail(MLX_E_SHAPE, "nbytes must be > 0");
+  if ((uintptr_t)ptr % MLX_HOST_PAGE || nbytes % MLX_HOST_PAGE)
+    return fail(MLX_E_ALIGN, "mlx_host_pin: ptr and nbytes must be multiples of the 4 KiB page");
+  return 0;
+}
+
+int mlx_host_unpin(void *ptr) {
+  if (!ptr) return fail(MLX_E_NULL, "ptr must not be NULL");
+  return 0;
+}
 
 int mlx_last_error(char *buf, size_t n) {
   if (buf && n) {

@@ -55,15 +55,16 @@ def main():
 
     B = T.element_size()
     cases = [
-        ("K1 steric", 2 * B, "k_steric_global", lambda: k1(T, S)),
-        ("K1 thermosteric", B, "k_steric_global", lambda: k1(T, S[0])),
-        ("K1 halosteric", B, "k_steric_global", lambda: k1(T[0], S)),
+        ("K1 steric", 2 * B, "k_steric_global", lambda: k1(T, S, arith="exact")),
+        ("K1 thermosteric", B, "k_steric_global", lambda: k1(T, S[0], arith="exact")),
+        ("K1 halosteric", B, "k_steric_global", lambda: k1(T[0], S, arith="exact")),
         ("K1 steric, fused arithmetic", 2 * B, "k_steric_global", lambda: k1(T, S, arith="fused")),
         ("K1 thermosteric, fused arithmetic", B, "k_steric_global",
          lambda: k1(T, S[0], arith="fused")),
         ("K1 halosteric, fused arithmetic", B, "k_steric_global",
          lambda: k1(T[0], S, arith="fused")),
-        ("K1 all variants + heat, one pass", 2 * B, "k_steric_global", lambda: dec()),
+        ("K1 all variants + heat, one pass", 2 * B, "k_steric_global",
+         lambda: dec(arith="exact")),
         ("K1 all variants + heat, one pass, fused arithmetic", 2 * B, "k_steric_global",
          lambda: dec(arith="fused")),
         ("K2 local eta only", 2 * B, "k_steric_local", lambda: k2(False)),
@@ -73,7 +74,7 @@ def main():
                                           z_i=zi, deptho=dep, delta_rho_out=d3, eta_out=e3,
                                           skip_dry=False)),
         ("K1 steric, dry lines skipped", 2 * B, "k_steric_global",
-         lambda: core.steric_global_masso(T, S, vol0, pres, skip_dry=True)),
+         lambda: core.steric_global_masso(T, S, vol0, pres, skip_dry=True, arith="exact")),
         ("K2 local + delta_rho, dry lines skipped", 2 * B + 8, "k_steric_local",
          lambda: k2(True, skip=True)),
     ]

@@ -59,3 +59,32 @@ def test_argument_errors_need_no_gpu():
     assert lib.mlx_nansum(None, 0, None, None, 0, None) == -1
     assert lib.mlx_steric_global_workspace_bytes(0, 1, 1) == 0
     assert lib.mlx_steric_global_workspace_bytes(120, 75, 1080 * 1440) > 0
+
+
+def test_null_pressure_requires_scalar_mode():
+    """with p == NULL (allowed for the linear EOS) the array pressure modes would index a
+    placeholder pointer; every entry point rejects them before any launch (fake, never dereferenced
+    pointers: the check precedes all HIP calls)."""
+    lib = _lib.load()
+    fake = 1 << 20  # 16-byte aligned, non-NULL
+    for p_mode in (_lib.P_ZPROF, _lib.P_FULL3D, _lib.P_FULL4D):
+        rc = lib.mlx_steric_global(fake, fake, 0, fake, None, p_mode, _lib.EOS_LINEAR, 2, 3, 32, 96,
+                                   96, 0, fake, fake, 1 << 20, None)
+        assert rc == -1 and "MLX_P_SCALAR" in _lib.last_error()
+        rc = lib.mlx_eos_map(fake, fake, 0, None, p_mode, _lib.EOS_LINEAR, 0, 2, 3, 32, 96, 96, 0,
+                             fake, None)
+        assert rc == -1
+        rc = lib.mlx_steric_local(fake, fake, 0, fake, fake, fake, None, None, None, p_mode,
+                                  _lib.EOS_LINEAR, -1.0 / 1035.0, 2, 3, 32, 96, 96, 0, None, fake,
+                                  None)
+        assert rc == -1
+
+
+def test_build_kind_and_host_pin_argument_checks():
+    lib = _lib.load()
+    assert lib.mlx_build_kind() == _lib.BUILD_HIP
+    assert lib.mlx_host_pin(None, 4096) == -1
+    assert lib.mlx_host_pin(4096, 0) == -2
+    assert lib.mlx_host_pin(4096 + 8, 4096) == -5 and "4 KiB" in _lib.last_error()
+    assert lib.mlx_host_pin(4096, 100) == -5
+    assert lib.mlx_host_unpin(None) == -1

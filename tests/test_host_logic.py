@@ -251,6 +251,31 @@ def test_product_fails_loudly_without_a_gpu():
             call()
 
 
+def test_product_refuses_to_bind_the_host_build(tmp_path):
+    """MOMLEVEL_AMD_LIB must not be a way to run the product on the CPU
+    restatement -- oracle/libmomlevel_host.so exports every symbol of the ABI.  Refused by location
+    (under oracle/) and, for a copy placed elsewhere, by mlx_build_kind()."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+
+    from oracle import host_abi
+
+    host = host_abi.build()
+    copy = tmp_path / "libmomlevel_hip.so"  # renamed and moved: only the build kind gives it away
+    shutil.copy(host, copy)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(m.__file__)))
+    code = ("from momlevel_amd import _lib\n"
+            "try:\n    _lib.load()\nexcept _lib.MomlevelHipError as e:\n    print('REFUSED', e)\n"
+            "else:\n    print('BOUND')\n")
+    for path, why in ((host, "under oracle/"), (str(copy), "not the HIP build")):
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True,
+                             env=dict(os.environ, MOMLEVEL_AMD_LIB=path))
+        assert out.stdout.startswith("REFUSED"), out.stdout + out.stderr
+        assert why in out.stdout, out.stdout
+
+
 def test_product_never_imports_the_oracle():
     import os
     import re
