@@ -25,7 +25,12 @@ Besides the contract fields the JSON line carries
   cpu_baseline -- the numpy oracle (op-for-op restatement of the reference's CPU path) timed
                   on this host, one thread, on a bounded sample of the same fields (rank 0,
                   N=1 only) -- a reported baseline, not the target;
-  parity       -- max relative difference GPU vs oracle on that sample (masso per slab).
+  parity       -- max relative difference GPU vs oracle on that sample (masso per slab);
+  config5_f32  -- BASELINE.json configs[4]: after the float64 extras the record is replaced by
+                  float32 theta/S (112 GB) and the global variants, the one-pass decomposition and
+                  the local eta pass are timed on it (faithful = numpy's float32 polynomial, the
+                  product default; upcast and fused beside it), with one oracle slab in numpy
+                  float32 as the check.
 """
 
 import argparse
@@ -88,7 +93,7 @@ def measured_traffic(cells_per_launch):
     were taken on this workload AND on these kernel sources; bench.py itself cannot read
     hardware counters.  A stale profile (sources changed since) yields null, not an old number."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ("r02_summary.json",):
+    for name in ("r03_summary.json", "r02_summary.json"):
         try:
             with open(os.path.join(here, "profiles", name)) as f:
                 s = json.load(f)
@@ -289,6 +294,7 @@ def main():
     nt = fit_nt(nt_req, nz, th, tw, dev, itemsize=4 if f32 else 8)
     if world > 1:  # every rank must run the same number of steps
         nt = int(allreduce_scalar(nt, dist.ReduceOp.MIN, torch.int64))
+    shrunk = nt < nt_req  # free HBM did not hold the requested record: said so in the JSON line
 
     vol0 = torch.from_numpy(g["volcello"]).to(dev)
     area = torch.from_numpy(g["areacello"]).to(dev)
@@ -373,6 +379,12 @@ def main():
             if procs > 0:
                 cpu_procs = cpu_baseline_processes(g, nz, ny, nx, nt, out["masso"], procs)
 
+    if not a.no_extras and world == 1 and not f32:
+        # BASELINE.json configs[4] in the driver-timed line: the float64 record makes room for the
+        # float32 one (outputs of the float64 run are host-side by now)
+        del T, S
+        extras["config5_f32"] = f32_timings(vol0, pres, g, dev, nt, kw)
+
     if rank == 0:
         layout = {1: "1x1", 2: "1x2", 4: "2x2", 8: "2x4"}.get(world, f"1x{world}")
         line = {
@@ -392,16 +404,21 @@ def main():
                 "workload": (
                     f"OM4 0.25deg synthetic grid {nx}x{ny}x{nz}, {nt} time steps, "
                     f"{'fp32 theta/S (BASELINE.json configs[4])' if f32 else 'fp64'}, global "
-                    "steric (BASELINE.json configs[2])" if world == 1 else
+                    + ("steric (shortened to fit free HBM: NOT BASELINE.json configs[2], see nt_requested)"
+                       if shrunk else "steric (BASELINE.json configs[2])") if world == 1 else
                     f"OM4 0.25deg synthetic grid {nx}x{ny}x{nz} tiled {layout} (yh x xh), {nt} time "
                     f"steps, fp64, global steric: every GPU holds all {nt} steps of its "
                     f"{tw}x{th} tile resident = the cells of {nt / world:g} full-grid steps, walked "
                     f"in {n_launches} time chunks of <= {chunk_steps} steps with one RCCL all-reduce "
-                    "per chunk (BASELINE.json configs[3]; weak scaling: bytes per GPU are fixed, "
-                    "the record grows with N)"),
+                    "per chunk ("
+                    + ("NOT BASELINE.json configs[3]: the record was shortened to fit free HBM, see "
+                       "nt_requested; " if shrunk else "BASELINE.json configs[3]; ")
+                    + "weak scaling: bytes per GPU are fixed, the record grows with N)"),
                 "grid_xyz": [nx, ny, nz],
                 "nt_per_gpu_resident": nt,
                 "nt_total": nt,
+                "nt_requested": nt_req,
+                "record_shortened_to_fit_hbm": shrunk,
                 "tile_layout_yx": layout,
                 "tile_xy": [tw, th],
                 "variant": "steric",
@@ -414,8 +431,9 @@ def main():
                 "hbm_resident_gb": round(2 * cells_rank * (4 if f32 else 8) / 1e9, 1),
             },
             "roofline": {
-                "kernel": ("k_steric_global<float,4,2,0,1,false,false>" if f32
-                           else "k_steric_global<double,2,4,0,0,false,false>"),
+                "kernel": ("k_steric_global<float,4,2,0,1,false,false,false>" if f32
+                           else "k_steric_global<double,2,4,0,0,false,false,true>"),
+                "arith": core.arith_default("k1", tdtype) + " (the product default for this dtype)",
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
@@ -429,7 +447,8 @@ def main():
                 "algorithmic_bytes_per_cell": bytes_per_cell,
                 "algorithmic_gb_per_launch": round(bytes_per_cell * cells_rank / 1e9, 2),
                 "cells_per_launch": cells_rank,
-                "time_loop_steps_per_block": 32,
+                "time_loop_steps_per_block": min(nt if world == 1 else chunk_steps,
+                                                 core.K1_TCHUNK["steric"]),
                 "kernel_source_sha": kernel_source_sha(),
             },
             "cpu_baseline": cpu,
@@ -471,25 +490,32 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
                 f"GB/s_at_{bytes_per_cell}B_per_cell": round(bytes_per_cell * n / ms / 1e6, 1),
                 "frac_of_8TBs": round(bytes_per_cell * n / ms / 1e6 / HBM_PEAK_GBS, 4)}
 
-    # the 8 B/cell variants: exact (numpy's arithmetic, the default) and MLX_FLAG_FMA (opt-in)
-    for arith in ("exact", "fused"):
-        tag = "" if arith == "exact" else "_fused"
+    # K1's arithmetic: the product default for this dtype (fused on float64, exact on float32;
+    # core.arith_default) carries the plain key, the other policy its name as a suffix
+    default = core.arith_default("k1", T.dtype)
+    out["k1_default_arith"] = default
+
+    def tag(arith):
+        return "" if arith == default else "_" + arith
+
+    for arith in ("fused", "exact"):
         ms = _time(lambda: core.steric_global_masso(T, S[0], vol0, pres, skip_dry=False,
                                                     arith=arith))
-        out["thermosteric_global" + tag] = rate(ms, B1)
+        out["thermosteric_global" + tag(arith)] = rate(ms, B1)
         ms = _time(lambda: core.steric_global_masso(T[0], S, vol0, pres, skip_dry=False,
                                                     arith=arith))
-        out["halosteric_global" + tag] = rate(ms, B1)
-    ms = _time(lambda: core.steric_global_masso(T, S, vol0, pres, skip_dry=False, arith="fused"))
-    out["steric_global_fused"] = rate(ms, 2 * B1)
+        out["halosteric_global" + tag(arith)] = rate(ms, B1)
+    other = "exact" if default == "fused" else "fused"
+    ms = _time(lambda: core.steric_global_masso(T, S, vol0, pres, skip_dry=False, arith=other))
+    out["steric_global" + tag(other)] = rate(ms, 2 * B1)
     # BASELINE.json configs[4]: steric + thermosteric + halosteric (+ heat content) from ONE pass
     # over theta/S, against the sum of the three single-variant launches
-    for arith in ("exact", "fused"):
+    for arith in ("fused", "exact"):
         ms = _time(lambda: core.steric_global_decomp(T, S, T[0], S[0], vol0, pres, skip_dry=False,
                                                      arith=arith))
         r = rate(ms, 2 * B1)
         r["note"] = "all three variants + sum(theta*vol0) per step, theta/S read once"
-        out["decomposition_one_pass" + ("" if arith == "exact" else "_fused")] = r
+        out["decomposition_one_pass" + tag(arith)] = r
     # calibration: this box's plain streaming-read rate through the same 16-byte nt loads
     # (skipna sum of the theta record) -- the practical ceiling K1's 16 B/cell runs against
     if B1 == 8:
@@ -513,6 +539,38 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
                                          deptho=dep, want_delta_rho=False, eta_out=eta,
                                          skip_dry=False))
     out["local_eta_only"] = rate(ms, 2 * B1)
+    # K2 with delta_rho: the 8 B/cell output does not fit beside the record, so it is produced in
+    # time chunks into one reused buffer.  Two chunk sizes: 16 steps (the K2 thread's own time
+    # block: one occupancy round per launch, 7 launches) and the largest the free HBM holds
+    # (few launches: ramp and tail paid less often) -- VERDICT r2 weak #5.
+    free, _ = torch.cuda.mem_get_info(dev)
+    big = int(min(nt, max(0, free - (6 << 30)) // (nz * ny * nx * 8)) // 16 * 16)
+    if big >= 32:
+        dbig = torch.empty((big, nz, ny, nx), dtype=torch.float64, device=dev)
+        starts_b = range(0, nt - big + 1, big)
+        done_b = len(starts_b) * big * nz * ny * nx
+
+        def run_big():
+            for t0 in starts_b:
+                core.steric_local(T[t0:t0 + big], S[t0:t0 + big], rho0m, vol0[0], pres,
+                                  -1.0 / 1035.0, z_i=zi, deptho=dep, delta_rho_out=dbig,
+                                  eta_out=eta[t0:t0 + big], skip_dry=False)
+
+        def probe_big():
+            for t0 in starts_b:
+                core.stream_probe(T[t0:t0 + big], S[t0:t0 + big], out=dbig)
+
+        ms_b = _time(run_big, reps=2)
+        r = rate(ms_b, 2 * B1 + 8, done_b)
+        r["delta_rho_chunk_steps"] = big
+        r["launches"] = len(starts_b)
+        if B1 == 8:
+            pms_b = _time(probe_big, reps=2)
+            r["frac_of_read_write_probe"] = round(pms_b / ms_b, 4)
+            r["read_write_probe_GB/s"] = round(24 * done_b / pms_b / 1e6, 1)
+        out["local_with_delta_rho_large_chunks"] = r
+        del dbig
+        torch.cuda.empty_cache()
     chunk = min(nt, 16)
     free, _ = torch.cuda.mem_get_info(dev)
     if free > chunk * nz * ny * nx * 8 + (2 << 30):
@@ -528,6 +586,8 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
 
         ms = _time(lambda: run(False), reps=2)
         out["local_with_delta_rho"] = rate(ms, 2 * B1 + 8, done)
+        out["local_with_delta_rho"]["delta_rho_chunk_steps"] = chunk
+        out["local_with_delta_rho"]["launches"] = len(starts)
 
         # the same traffic with no arithmetic: 16 B read + 8 B written per cell through the same
         # 16-byte nt loads/stores -- this box's ceiling for the pass above
@@ -588,6 +648,77 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
             r["note"] = "steric + thermosteric + halosteric delta_rho and eta, theta/S read once"
             out["local_decomposition_one_pass"] = r
             del d3, e3
+    return out
+
+
+def f32_timings(vol0, pres, g, dev, nt, synth_kw):
+    """BASELINE.json configs[4]: float32 theta/S (what MOM6 writes) at the roofline grid, resident;
+    global variants, the one-pass decomposition (+ heat) and the local eta pass.  "faithful" =
+    numpy's own mixed precision (float32 polynomial), bit-identical to the reference pointwise and
+    the product default; "upcast" = float64 arithmetic on the float32 values; "fused" = upcast with
+    MLX_FLAG_FMA.  Algorithmic bytes: 4 B per streamed field and cell."""
+    from oracle import momlevel_numpy as o  # the checker: one slab in numpy float32
+
+    torch.cuda.empty_cache()
+    nz, ny, nx = vol0.shape
+    shape = (nt, nz, ny, nx)
+    T = core.synth_field(shape, torch.float32, field_id=synthetic.FIELD_THETAO,
+                         lo=synthetic.THETA_LO, scale=synthetic.THETA_SCALE, **synth_kw)
+    S = core.synth_field(shape, torch.float32, field_id=synthetic.FIELD_SO,
+                         lo=synthetic.SO_LO, scale=synthetic.SO_SCALE, **synth_kw)
+    cells = nt * nz * ny * nx
+
+    def rate(ms, bpc):
+        return {"ms": round(ms, 3), "Mcells/s": round(cells / ms / 1e3, 1),
+                "GB/s": round(bpc * cells / ms / 1e6, 1),
+                "frac_of_8TBs": round(bpc * cells / ms / 1e6 / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_cell": bpc}
+
+    modes = {"faithful": dict(f32_mode="faithful", arith="exact"),
+             "upcast": dict(f32_mode="upcast", arith="exact"),
+             "fused": dict(f32_mode="upcast", arith="fused")}
+    out = {"note": ("float32 theta/S resident (%.0f GB), %d steps; faithful = numpy's float32 "
+                    "polynomial = the product default on float32 input" % (2 * cells * 4 / 1e9, nt))}
+    for mode, kw in modes.items():
+        r = {}
+        r["steric"] = rate(_time(lambda: core.steric_global_masso(T, S, vol0, pres, skip_dry=False,
+                                                                  **kw)), 8)
+        r["thermosteric"] = rate(_time(lambda: core.steric_global_masso(
+            T, S[0], vol0, pres, skip_dry=False, **kw)), 4)
+        r["halosteric"] = rate(_time(lambda: core.steric_global_masso(
+            T[0], S, vol0, pres, skip_dry=False, **kw)), 4)
+        r["one_pass"] = rate(_time(lambda: core.steric_global_decomp(
+            T, S, T[0], S[0], vol0, pres, skip_dry=False, **kw)), 8)
+        r["one_pass"]["three_launches_ms"] = round(
+            r["steric"]["ms"] + r["thermosteric"]["ms"] + r["halosteric"]["ms"], 3)
+        out[mode] = r
+    rho0m = core.fold_mask(core.eos_map(T[0], S[0], pres), vol0)
+    zi = torch.from_numpy(g["z_i"]).to(dev)
+    dep = torch.from_numpy(g["deptho"]).to(dev)
+    eta = torch.empty((nt, ny, nx), dtype=torch.float64, device=dev)
+    for mode, kw in modes.items():
+        out[mode]["local_eta_only"] = rate(_time(lambda: core.steric_local(
+            T, S, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=zi, deptho=dep, want_delta_rho=False,
+            eta_out=eta, skip_dry=False, **kw)), 8)
+    # the default call (no mode arguments) is the faithful one, and one whole slab agrees with
+    # numpy evaluated on the float32 arrays (= what momlevel computes on float32 input)
+    t = nt // 2
+    rows = core.steric_global_decomp(T, S, T[0], S[0], vol0, pres, skip_dry=False)
+    faithful = core.steric_global_decomp(T, S, T[0], S[0], vol0, pres, skip_dry=False,
+                                         **modes["faithful"])
+    Tn, Sn, T0n, S0n = (x.cpu().numpy() for x in (T[t], S[t], T[0], S[0]))
+    pn = pres.cpu().numpy()
+    errs = {}
+    for name, row, (a_, b_) in zip(("steric", "thermosteric", "halosteric"), rows.cpu().numpy(),
+                                   ((Tn, Sn), (Tn, S0n), (T0n, Sn))):
+        ref = o.calc_masso(o.calc_rho(a_, b_, pn), g["volcello"])
+        errs[name] = float(abs(row[t] - ref) / abs(ref))
+    out["parity"] = {"default_is_faithful": bool(torch.equal(rows, faithful)),
+                     "time_step_checked": t,
+                     "masso_rel_err_vs_numpy_float32_oracle": errs,
+                     "masso0_equals_masso_t0": bool(rows[0, 0] == rows[1, 0] == rows[2, 0])}
+    del T, S
+    torch.cuda.empty_cache()
     return out
 
 

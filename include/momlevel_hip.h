@@ -41,8 +41,7 @@ extern "C" {
 #define MLX_ABI_VERSION 3 /* 2: mlx_eos_map takes flags; mlx_steric_global_decomp, mlx_steric_local_decomp,
                              mlx_stream_probe;
                              MLX_FLAG_FMA, MLX_FLAG_TCHUNK; MLX_P_FULL4D in K1/K2
-                             3: mlx_build_kind, mlx_host_pin / mlx_host_unpin; a NULL p (linear EOS)
-                             requires p_mode MLX_P_SCALAR */
+                             3: mlx_build_kind; a NULL p (linear EOS) requires p_mode MLX_P_SCALAR */
 
 /* argument-error codes (negative) */
 #define MLX_E_NULL     (-1) /* a required pointer is NULL                      */
@@ -104,21 +103,6 @@ int mlx_last_error(char *buf, size_t n);
 #define MLX_BUILD_HIP  1
 #define MLX_BUILD_HOST 2
 int mlx_build_kind(void);
-
-/* ---------------------------------------------------------------------------------
- * Page-locking of CALLER-OWNED host memory for asynchronous uploads (the step before the path,
- * momlevel hands steric() numpy-backed arrays; momlevel_amd/engine.py streams
- * them to HBM in time chunks).  mlx_host_pin page-locks [ptr, ptr+nbytes) in place
- * (hipHostRegister); ptr and nbytes MUST be multiples of the 4 KiB page (MLX_E_ALIGN otherwise), so
- * that a registration never shares a page with a foreign heap object or with a neighbouring
- * registration -- the caller registers only the page-aligned interior of an array and moves the
- * ragged head and tail through its own staging.  mlx_host_unpin releases a range by the pointer it
- * was pinned with.  Both return 0, MLX_E_*, or the hipError_t (and leave no sticky HIP error
- * behind on failure).  The host build pins nothing and returns 0.
- * ------------------------------------------------------------------------------- */
-#define MLX_HOST_PAGE 4096
-int mlx_host_pin(void *ptr, size_t nbytes);
-int mlx_host_unpin(void *ptr);
 
 /* ---------------------------------------------------------------------------------
  * K0  pointwise EOS map.  Replaces eos.wright.density/drho_dtemp/drho_dsal/alpha/beta

@@ -26,7 +26,6 @@ DTYPE_F64, DTYPE_F32, DTYPE_F32_UPCAST = 0, 1, 2
 FLAG_SKIP_DRY = 1
 FLAG_FMA = 2
 BUILD_HIP, BUILD_HOST = 1, 2
-HOST_PAGE = 4096
 
 
 def flag_tchunk(steps):
@@ -55,8 +54,6 @@ SIGNATURES = {
     "mlx_version": (_int, []),
     "mlx_last_error": (_int, [ctypes.c_char_p, _sz]),
     "mlx_build_kind": (_int, []),
-    "mlx_host_pin": (_int, [_vp, _sz]),
-    "mlx_host_unpin": (_int, [_vp]),
     "mlx_eos_map": (
         _int,
         [_vp, _vp, _int, _vp, _int, _int, _int, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp],

@@ -10,9 +10,10 @@ Layout: ``(time, z_l, yh, xh)`` C-contiguous, x fastest.  A
 time (the held field of the thermosteric / halosteric variants).
 """
 
+import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, hostio
 from ._lib import (
     DTYPE_F32,
     DTYPE_F32_UPCAST,
@@ -27,6 +28,9 @@ from ._lib import (
 )
 
 F32_MODES = {"faithful": DTYPE_F32, "upcast": DTYPE_F32_UPCAST}
+# K1's default time steps per block (csrc/momlevel_hip.hip kTChunk / kTChunkHeld; reported by
+# bench.py, kept in step by tests/test_host_logic.py)
+K1_TCHUNK = {"steric": 32, "held": 64}
 ARITH_FLAGS = {"exact": 0, "fused": _lib.FLAG_FMA}
 
 
@@ -97,9 +101,11 @@ def _ptr(t):
 
 def _f64(x, device):
     """Small time-invariant operand -> contiguous float64 device tensor."""
-    if isinstance(x, torch.Tensor):
+    if isinstance(x, torch.Tensor) and x.is_cuda:
         return x.to(device=device, dtype=torch.float64).contiguous()
-    return torch.as_tensor(x, dtype=torch.float64).to(device).contiguous()
+    if not isinstance(x, torch.Tensor):
+        x = np.asarray(x, dtype=np.float64)
+    return hostio.to_device(x, device, torch.float64).contiguous()  # host data: owned staging
 
 
 def _dtype_code(t, f32_mode):

@@ -1208,28 +1208,6 @@ int mlx_last_error(char* buf, size_t n) {
 
 int mlx_build_kind(void) { return MLX_BUILD_HIP; }
 
-// ---------------------------------------------------------------------------- host pinning
-// A failed hipHostRegister / hipHostUnregister leaves a sticky error that the NEXT unrelated
-// hipGetLastError() (e.g. torch's kernel-launch check) would report: fetch it here.
-static int host_pin_status(hipError_t e, const char* what) {
-  if (e == hipSuccess) return 0;
-  (void)hipGetLastError();
-  return hip_status(e, what);
-}
-
-int mlx_host_pin(void* ptr, size_t nbytes) {
-  if (!ptr) return fail(MLX_E_NULL, "ptr must not be NULL");
-  if (nbytes == 0) return fail(MLX_E_SHAPE, "nbytes must be > 0");
-  if (!aligned(ptr, MLX_HOST_PAGE) || nbytes % MLX_HOST_PAGE)
-    return fail(MLX_E_ALIGN, "mlx_host_pin: ptr and nbytes must be multiples of the 4 KiB page");
-  return host_pin_status(hipHostRegister(ptr, nbytes, hipHostRegisterDefault), "hipHostRegister");
-}
-
-int mlx_host_unpin(void* ptr) {
-  if (!ptr) return fail(MLX_E_NULL, "ptr must not be NULL");
-  return host_pin_status(hipHostUnregister(ptr), "hipHostUnregister");
-}
-
 // ---------------------------------------------------------------------------- K0
 static int eos_map_impl(const void* T, const void* S, int dtype, const double* p, int p_mode,
                         int eos, int func, double aux, int64_t nt, int64_t nz, int64_t plane,

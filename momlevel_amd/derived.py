@@ -11,7 +11,7 @@ HIP kernel.
 import numpy as np
 import torch
 
-from . import core, engine, util
+from . import core, engine, hostio, util
 from .adapters import accepts_xarray
 from .labeled import DataArray
 
@@ -143,7 +143,7 @@ def calc_masso(rho, volcello, tcoord="time"):
     out = core.masso(r, v)
     data = out if has_t else out[0]
     if not (rho.is_device or volcello.is_device):
-        data = data.cpu().numpy()
+        data = hostio.to_host(data)
     masso = DataArray(data, (tcoord,) if has_t else (),
                       {tcoord: rho.coords[tcoord]} if has_t and tcoord in rho.coords else None)
     masso.attrs = {
@@ -160,7 +160,7 @@ def calc_volo(volcello):
     assert len(volcello.dims) == 3, "Expecting only 3 dimensions for volcello"
     dev = engine.device_of(volcello.data)
     total = core.nansum(engine.to_device(volcello.data, dev, torch.float64))
-    volo = DataArray(total if volcello.is_device else total.cpu().numpy(), ())
+    volo = DataArray(total if volcello.is_device else hostio.to_host(total), ())
     volo.attrs = {
         "standard_name": "sea_water_volume",
         "long_name": "Sea Water Volume",
@@ -202,4 +202,4 @@ def calc_dz(levels, interfaces, depth, top=0.0, bottom=None, fraction=False):
     zdim = levels.dims[0]
     coords = dict(depth.coords)
     coords[zdim] = levels.coords.get(zdim, levels)
-    return DataArray(out if depth.is_device else out.cpu().numpy(), (zdim,) + depth.dims, coords)
+    return DataArray(out if depth.is_device else hostio.to_host(out), (zdim,) + depth.dims, coords)

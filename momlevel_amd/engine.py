@@ -6,7 +6,8 @@ It owns the time-chunk streaming of host-resident inputs: the reference hands
 ``steric()`` numpy-backed xarray objects of any size, so (time, z, y, x) fields
 are moved to HBM a few time steps at a time (sized from free HBM), the kernels of
 chunk k overlapping the upload of chunk k+1, while the time-invariant reference
-state stays resident on the device.
+state stays resident on the device.  Every byte moves through hostio.py: staging and
+result buffers of our own, never a GPU mapping of the caller's memory.
 """
 
 import os
@@ -15,7 +16,7 @@ import warnings
 import numpy as np
 import torch
 
-from . import _lib, core
+from . import core, hostio
 
 _GIB = 1 << 30
 
@@ -34,13 +35,7 @@ def device_of(*arrays):
 
 def to_device(x, device, dtype=None):
     """Small or already-resident operand -> device tensor (no copy if resident)."""
-    if isinstance(x, torch.Tensor):
-        t = x.to(device)
-    else:
-        t = _host_tensor(x).to(device)
-    if dtype is not None and t.dtype != dtype:
-        t = t.to(dtype)
-    return t
+    return hostio.to_device(x, device, dtype)
 
 
 def _stream_dtype(x):
@@ -57,54 +52,6 @@ def chunk_steps(nt, bytes_per_step, device, budget_bytes=None):
         free, _total = torch.cuda.mem_get_info(device)
         budget_bytes = min(free // 3, 4 * _GIB)  # small chunks: deeper H2D|compute|D2H overlap
     return int(max(1, min(nt, budget_bytes // max(1, 2 * bytes_per_step))))
-
-
-# ---------------------------------------------------------------------------------------
-# in-place page-locking of the caller's arrays (C ABI: mlx_host_pin / mlx_host_unpin)
-# ---------------------------------------------------------------------------------------
-_PAGE = _lib.HOST_PAGE
-_LIVE_PINS = {}  # page-aligned start -> end of every range this process currently has pinned
-
-
-def page_interior(ptr, nbytes, page=_PAGE):
-    """The largest page-aligned range inside [ptr, ptr+nbytes): -> (lo, hi), hi <= lo when the
-    buffer holds no whole page.  Only this interior is ever page-locked: a page that the buffer
-    merely touches may hold other heap objects (numpy arrays below glibc's mmap threshold live in
-    the brk heap) or the neighbouring time chunk's first bytes, and must not be registered."""
-    lo = -(-ptr // page) * page
-    hi = ((ptr + nbytes) // page) * page
-    return lo, hi
-
-
-def _overlaps_live_pin(lo, hi):
-    return any(lo < e and s < hi for s, e in _LIVE_PINS.items())
-
-
-def pin_interior(lo, hi):
-    """Page-lock [lo, hi) unless some page of it is pinned already -> True when pinned.  A refusal
-    by the runtime (locked-memory limit, foreign registration, ...) is not an error: nothing was
-    registered, and the caller copies synchronously instead."""
-    if hi <= lo or _overlaps_live_pin(lo, hi):
-        return False
-    rc = _lib.load().mlx_host_pin(lo, hi - lo)
-    if rc != 0:
-        warnings.warn(f"asynchronous upload disabled for this chunk: {_lib.last_error()} "
-                      f"(status {rc}); copying synchronously", RuntimeWarning, stacklevel=3)
-        return False
-    _LIVE_PINS[lo] = hi
-    return True
-
-
-def unpin_interior(lo):
-    """Release a range pinned by pin_interior.  A failure here is NOT survivable: the range would
-    stay registered while its memory goes back to the allocator, and the next pageable copy from
-    recycled memory would be treated as pinned -- raise."""
-    rc = _lib.load().mlx_host_unpin(lo)
-    _LIVE_PINS.pop(lo, None)
-    if rc != 0:
-        raise core.MomlevelHipError(
-            f"hipHostUnregister failed for the upload buffer at {lo:#x} (status {rc}): "
-            f"{_lib.last_error()}")
 
 
 def _host_tensor(a, dtype=None):
@@ -126,13 +73,13 @@ class TimeChunks:
 
     Device-resident fields are sliced (no copy).  Lazy fields (dask / netCDF4 / h5py / zarr
     arrays, anything sliceable that is not numpy) are READ chunk by chunk -- ``np.asarray(f[t0:t1])``
-    -- so the host never holds more than the chunks in flight.  Host (numpy) fields are copied chunk by chunk
-    straight from the caller's memory into a fresh device tensor -- no staging copy (a pageable
-    hipMemcpy already runs at the PCIe Gen5 rate on the MI355X hosts, 56 GB/s measured; staging
-    through a pinned buffer halved it).  The chunk's pages are page-locked in place
-    (hipHostRegister) for the duration of the copy so that it can run asynchronously on a copy
-    stream: chunk k+1 uploads while chunk k's kernels run and its results download on a third
-    stream.  A (nz,ny,nx) operand (a held field) is uploaded once and yielded with every chunk.
+    -- so the host never holds more than the chunks in flight.  Host (numpy) fields are copied
+    chunk by chunk into a fresh device tensor through hostio's page-locked staging ring, on a
+    copy stream: the host fills one staging buffer while the DMA engine drains another, chunk
+    k+1 uploads while chunk k's kernels run and its results download on a third stream.  The
+    caller's memory is only ever READ BY THE HOST -- rounds 1-2 page-locked it in place
+    (hipHostRegister) and died twice of GPU page faults on heap addresses, DESIGN.md section 7.
+    A (nz,ny,nx) operand (a held field) is uploaded once and yielded with every chunk.
     """
 
     def __init__(self, T, S, device, steps=None, extra_bytes_per_step=0):
@@ -153,23 +100,9 @@ class TimeChunks:
         self._held = [
             to_device(f, device, _stream_dtype(f)) if f.ndim == 3 else None for f in self.fields
         ]
-        # asynchronous uploads: the page-aligned interior of the caller's chunk is page-locked in
-        # place for the duration of the copy (page_interior / pin_interior), so the H2D of a chunk
-        # runs on its own stream and overlaps the previous chunk's kernels and result download
+        # uploads run on their own stream and overlap the previous chunk's kernels and result
+        # download
         self._copy_stream = None if all(self.resident) else torch.cuda.Stream(device=device)
-        self._registered = []  # (pinned range start or None, completion event, keep-alive objects)
-
-    def _release(self, wait=False):
-        keep = []
-        for lo, ev, alive in self._registered:
-            if wait:
-                ev.synchronize()
-            if ev.query():
-                if lo is not None:
-                    unpin_interior(lo)  # raises if the runtime refuses: never leave a stale pin
-            else:
-                keep.append((lo, ev, alive))
-        self._registered = keep
 
     def _upload(self, f, t0, t1):
         dt = _stream_dtype(f)
@@ -178,43 +111,13 @@ class TimeChunks:
             return src.to(device=self.device, dtype=dt)
         host = _host_tensor(src, np.float32 if dt == torch.float32 else np.float64)
         dev = torch.empty(host.shape, dtype=dt, device=self.device)
-        ptr, nbytes = host.data_ptr(), host.numel() * host.element_size()
-        # In-place page-locking pays only for real chunks: a copy of less than a MiB is
-        # latency-bound either way.
-        min_bytes = int(os.environ.get("MOMLEVEL_AMD_ASYNC_H2D_MIN_BYTES", str(1 << 20)))
-        lo, hi = page_interior(ptr, nbytes)
-        if (self._copy_stream is None or hi - lo < max(min_bytes, _PAGE)
-                or os.environ.get("MOMLEVEL_AMD_ASYNC_H2D", "1") == "0"):
-            dev.copy_(host)
-            return dev
-        already = host.is_pinned()  # e.g. the caller's array lives in a torch pinned tensor
-        pinned = (not already) and pin_interior(lo, hi)
-        if not (already or pinned):
-            dev.copy_(host)
-            return dev
-        hb, db = host.view(torch.uint8).reshape(-1), dev.view(torch.uint8).reshape(-1)
-        head, tail = (0, 0) if already else (lo - ptr, ptr + nbytes - hi)
-        # the ragged head and tail (< one page each) travel through a small page-locked staging
-        # buffer of our own, so that the whole upload is asynchronous and no page of the caller's
-        # that we did not register is ever handed to the DMA engine
-        frag = None
-        if head or tail:
-            frag = torch.empty(head + tail, dtype=torch.uint8, pin_memory=True)
-            frag[:head] = hb[:head]
-            frag[head:] = hb[nbytes - tail:]
         main = torch.cuda.current_stream(self.device)
         self._copy_stream.wait_stream(main)  # `dev` may reuse memory main is done with
-        with torch.cuda.stream(self._copy_stream):
-            db[head:nbytes - tail].copy_(hb[head:nbytes - tail], non_blocking=True)
-            if head:
-                db[:head].copy_(frag[:head], non_blocking=True)
-            if tail:
-                db[nbytes - tail:].copy_(frag[head:], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self._copy_stream)
+        hostio.upload(host, dev, stream=self._copy_stream)  # host bytes are staged on return
+        ev = torch.cuda.Event()
+        ev.record(self._copy_stream)
         dev.record_stream(self._copy_stream)
         main.wait_event(ev)
-        self._registered.append((lo if pinned else None, ev, (host, frag)))
         return dev
 
     def _stage(self, t0, t1):
@@ -230,17 +133,13 @@ class TimeChunks:
 
     def __iter__(self):
         bounds = [(t0, min(t0 + self.steps, self.nt)) for t0 in range(0, self.nt, self.steps)]
-        try:
-            nxt = self._stage(*bounds[0]) if bounds else None
-            for i, (t0, t1) in enumerate(bounds):
-                cur = nxt
-                # chunk i+1 starts uploading before the caller enqueues chunk i's kernels
-                nxt = self._stage(*bounds[i + 1]) if i + 1 < len(bounds) else None
-                yield t0, t1, cur[0], cur[1]
-                self._release()
-        finally:
-            self._release(wait=True)
-            assert self._registered == [], "an upload buffer is still page-locked"
+        nxt = self._stage(*bounds[0]) if bounds else None
+        for i, (t0, t1) in enumerate(bounds):
+            cur = nxt
+            # chunk i+1 is staged and enqueued for upload before the caller enqueues chunk i's
+            # kernels: the DMA of i+1 overlaps the kernels of i
+            nxt = self._stage(*bounds[i + 1]) if i + 1 < len(bounds) else None
+            yield t0, t1, cur[0], cur[1]
 
 
 def time_dependent(pres):
@@ -349,21 +248,12 @@ def global_finalize(masso, volo, rhoga, area_sum):
 # ---------------------------------------------------------------------------------------
 # local variant (src/momlevel/steric.py:150-166)
 # ---------------------------------------------------------------------------------------
-_PINNED_OUTPUT_LIMIT = 32 * _GIB
-
-
 def _host_output(shape):
-    """float64 host array for results copied back from the device.  Page-locked when it is not
-    huge: the D2H copy then runs at the link rate and the pages are already resident (a fresh
-    np.empty pays a page fault per 4 KiB on first touch).  The numpy view keeps the pinned
-    tensor alive."""
-    nbytes = int(np.prod(shape)) * 8
-    if 0 < nbytes <= _PINNED_OUTPUT_LIMIT:
-        try:
-            return torch.empty(shape, dtype=torch.float64, pin_memory=True).numpy()
-        except RuntimeError:
-            pass
-    return np.empty(shape, dtype=np.float64)
+    """float64 host array for results copied back from the device: page-locked memory of our own
+    when it is not huge (the D2H copy is then one asynchronous DMA and the pages are already
+    resident); see hostio.pinned_array."""
+    return hostio.pinned_array(shape, np.float64)
+
 
 def local_steric(T, S, rho0, vol0, pres, rhozero, z_i=None, deptho=None, dz=None,
                  eos="wright", f32_mode="faithful", want_delta_rho=True, out_host=None,
@@ -413,13 +303,10 @@ def local_steric(T, S, rho0, vol0, pres, rhozero, z_i=None, deptho=None, dz=None
                                      deptho=deptho, eos=eos, f32_mode=f32_mode,
                                      want_delta_rho=want_delta_rho)
             d2h.wait_stream(main)
-            with torch.cuda.stream(d2h):
-                # straight into the caller-visible arrays (one D2H pass, no intermediate copy)
-                torch.from_numpy(eta[t0:t1]).copy_(e, non_blocking=True)
-                e.record_stream(d2h)
-                if want_delta_rho:
-                    torch.from_numpy(drho[t0:t1]).copy_(d, non_blocking=True)
-                    d.record_stream(d2h)
+            # straight into the caller-visible arrays (one D2H pass, no intermediate copy)
+            hostio.download_into(eta[t0:t1], e, d2h)
+            if want_delta_rho:
+                hostio.download_into(drho[t0:t1], d, d2h)
         else:
             core.steric_local(Tc, Sc, rho0m, surface, pc, neg_inv, dz=dz, z_i=z_i,
                               deptho=deptho, eos=eos, f32_mode=f32_mode,
@@ -585,12 +472,9 @@ def local_steric_variants(T, S, T0, S0, rho0, vol0, pres, rhozero, variants, z_i
                     d, e = (chunk_fields[v] if one_pass else
                             core.steric_local(Tv, Sv, rho0m, surface, pc, neg_inv, **kw))
                 d2h.wait_stream(main)
-                with torch.cuda.stream(d2h):
-                    torch.from_numpy(eta[v][o0:o1]).copy_(e, non_blocking=True)
-                    e.record_stream(d2h)
-                    if want_delta_rho:
-                        torch.from_numpy(drho[v][o0:o1]).copy_(d, non_blocking=True)
-                        d.record_stream(d2h)
+                hostio.download_into(eta[v][o0:o1], e, d2h)
+                if want_delta_rho:
+                    hostio.download_into(drho[v][o0:o1], d, d2h)
             else:
                 core.steric_local(Tv, Sv, rho0m, surface, pc, neg_inv,
                                   delta_rho_out=drho[v][t0:t1] if want_delta_rho else None,

@@ -9,7 +9,7 @@ device tensors stay on the device.  There is no host arithmetic fallback.
 import numpy as np
 import torch
 
-from .. import core
+from .. import core, hostio
 
 
 def _as_tensor(x, device):
@@ -18,7 +18,7 @@ def _as_tensor(x, device):
     a = np.asarray(x)
     if a.dtype not in (np.float32, np.float64):
         a = a.astype(np.float64)
-    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return hostio.to_device(a, device)  # through our own page-locked staging
 
 
 _HOST_CHUNK_ELEMS = 1 << 28  # 2 GiB of float64 per operand and chunk
@@ -96,7 +96,7 @@ def evaluate(eos, func, T, S, p, gravity=None):
 
     if on_device:
         return out
-    res = out.cpu().numpy()
+    res = hostio.to_host(out)
     if scalar_in:
         return np.float64(res.reshape(()))
     return res

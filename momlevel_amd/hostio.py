@@ -1,0 +1,204 @@
+"""Host <-> HBM transfers of the steric path: everything the DMA engines touch is memory WE own.
+
+momlevel hands ``steric()`` numpy-backed arrays: caller-owned, pageable heap or mmap memory.
+Rounds 1-2 page-locked those arrays in place (hipHostRegister) and let the runtime pin pageable
+sources and destinations on the fly for everything else.  Both put GPU mappings on memory whose
+lifetime belongs to somebody else -- glibc trims and regrows the brk heap, numpy frees and reuses
+blocks, mappings come and go -- and both of this project's unexplained aborts were GPU page faults
+on exactly such addresses ("Memory access fault by GPU node-N on address <a heap page>", DESIGN.md
+section 7).  So this module never shows the GPU a byte of foreign memory:
+
+* uploads go through a small ring of page-locked staging buffers (torch's pinned allocator:
+  hipHostMalloc'ed once, reused for the life of the process): the host copies piece k+1 into one
+  buffer with all its cores while the DMA engine drains piece k from another;
+* downloads land in page-locked arrays of our own, handed to the caller as numpy arrays (or, for
+  results too large to keep pinned, come back through the same ring).
+
+Nothing here computes: allocation, copies, stream ordering (torch as the device-array container).
+"""
+
+import os
+
+import numpy as np
+import torch
+
+_MIB = 1 << 20
+PIECE_BYTES = int(os.environ.get("MOMLEVEL_AMD_STAGING_PIECE_MIB", "64")) * _MIB
+RING_DEPTH = 3
+# below this size a transfer is latency-bound and travels through the runtime's own small staging
+# buffers (it never pins caller memory for less than a MiB)
+SMALL_BYTES = 256 << 10
+# the last page of a staging buffer is never handed to the DMA engine: a copy engine that reads a
+# little past the end of its source must find mapped memory there
+_SLACK = 64 << 10
+
+_rings = {}
+
+
+class _Ring:
+    """RING_DEPTH page-locked buffers of PIECE_BYTES (+ slack) and the event that marks each
+    buffer's last transfer as finished."""
+
+    def __init__(self):
+        self.bufs = [None] * RING_DEPTH
+        self.events = [None] * RING_DEPTH
+        self.next = 0
+
+    def acquire(self):
+        i = self.next
+        self.next = (i + 1) % RING_DEPTH
+        if self.events[i] is not None:
+            self.events[i].synchronize()  # the DMA that last used this buffer is done
+            self.events[i] = None
+        if self.bufs[i] is None:
+            self.bufs[i] = torch.empty(PIECE_BYTES + _SLACK, dtype=torch.uint8, pin_memory=True)
+        return i, self.bufs[i]
+
+
+def _ring(device):
+    key = torch.device(device).index if torch.device(device).index is not None else -1
+    if key not in _rings:
+        _rings[key] = _Ring()
+    return _rings[key]
+
+
+def _bytes_view(t):
+    return t.view(torch.uint8).reshape(-1)
+
+
+def _wide(piece, itemsize):
+    """A byte slice viewed in the field's own element type: torch copies float32/float64 tensors
+    with all cores (34 GB/s on 8 cores measured), uint8 tensors element by element (4 GB/s)."""
+    return piece.view({4: torch.float32, 8: torch.float64}[itemsize])
+
+
+def upload(host, dev, stream=None):
+    """Copy the contiguous CPU tensor ``host`` into the device tensor ``dev`` (same dtype and
+    number of elements) through the staging ring, asynchronously on ``stream`` (default: the
+    device's current stream).  Returns when the last piece has been ENQUEUED; ``host`` may be
+    modified or freed from then on (its bytes are in the staging buffers), ``dev`` is complete
+    once ``stream`` has passed the copies."""
+    assert host.dtype == dev.dtype and host.numel() == dev.numel() and host.is_contiguous()
+    device = dev.device
+    stream = stream if stream is not None else torch.cuda.current_stream(device)
+    nbytes = host.numel() * host.element_size()
+    if nbytes == 0:
+        return
+    if nbytes < SMALL_BYTES:
+        with torch.cuda.stream(stream):
+            dev.copy_(host.reshape(dev.shape))  # staged by the runtime itself
+        return
+    es = host.element_size()
+    hb, db = _bytes_view(host), _bytes_view(dev)
+    ring = _ring(device)
+    step = PIECE_BYTES // 8 * 8
+    for off in range(0, nbytes, step):
+        n = min(step, nbytes - off)
+        i, buf = ring.acquire()
+        _wide(buf[:n], es).copy_(_wide(hb[off:off + n], es))  # host copy, all cores
+        with torch.cuda.stream(stream):
+            db[off:off + n].copy_(buf[:n], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        ring.events[i] = ev
+
+
+def to_device(x, device, dtype=None):
+    """numpy array / CPU tensor -> new device tensor (through the staging ring when large)."""
+    if isinstance(x, torch.Tensor):
+        if x.is_cuda:
+            t = x.to(device)
+            return t if dtype is None or t.dtype == dtype else t.to(dtype)
+        host = x.contiguous()
+    else:
+        a = np.asarray(x)
+        if a.dtype.byteorder not in ("=", "|"):
+            a = a.astype(a.dtype.newbyteorder("="))
+        if not a.flags["C_CONTIGUOUS"]:
+            a = np.ascontiguousarray(a)
+        import warnings
+
+        with warnings.catch_warnings():  # read-only views (broadcasts, memmaps) are only read
+            warnings.simplefilter("ignore", UserWarning)
+            host = torch.from_numpy(a)
+    if host.dtype not in (torch.float32, torch.float64):
+        host = host.to(torch.float64)
+    dev = torch.empty(host.shape, dtype=host.dtype, device=device)
+    upload(host, dev)
+    return dev if dtype is None or dev.dtype == dtype else dev.to(dtype)
+
+
+PINNED_RESULT_LIMIT = 32 << 30
+
+
+def pinned_array(shape, dtype=np.float64):
+    """A page-locked numpy array of our own (the DMA target of result downloads); the array keeps
+    its pinned tensor alive.  Falls back to pageable memory (filled through the ring) when the
+    result is too large to keep page-locked or the pinned allocation fails."""
+    tdt = {np.dtype(np.float64): torch.float64, np.dtype(np.float32): torch.float32}[np.dtype(dtype)]
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    if 0 < nbytes <= PINNED_RESULT_LIMIT:
+        try:
+            return torch.empty(tuple(shape), dtype=tdt, pin_memory=True).numpy()
+        except RuntimeError:
+            pass
+    return np.empty(shape, dtype=dtype)
+
+
+def download_into(out, dev, stream=None):
+    """Copy the device tensor ``dev`` into the numpy array ``out`` (same shape / dtype, contiguous).
+    Page-locked ``out`` (pinned_array): one asynchronous DMA on ``stream`` -- the caller
+    synchronises the stream before reading.  Pageable ``out``: piecewise through the ring,
+    complete on return."""
+    device = dev.device
+    stream = stream if stream is not None else torch.cuda.current_stream(device)
+    host = torch.from_numpy(out)
+    if host.numel() == 0:
+        return
+    nbytes = host.numel() * host.element_size()
+    if host.is_pinned() or nbytes < SMALL_BYTES:
+        with torch.cuda.stream(stream):
+            host.copy_(dev.reshape(host.shape), non_blocking=host.is_pinned())
+            dev.record_stream(stream)
+        return
+    es = host.element_size()
+    src = dev.contiguous()
+    hb, db = _bytes_view(host), _bytes_view(src)
+    ring = _ring(device)
+    step = PIECE_BYTES // 8 * 8
+    pending = []  # (offset, n, buffer index): DMA enqueued, host copy-out still to do
+
+    def drain(k):
+        off, n, i = pending.pop(k)
+        ring.events[i].synchronize()
+        ring.events[i] = None
+        _wide(hb[off:off + n], es).copy_(_wide(ring.bufs[i][:n], es))
+
+    for off in range(0, nbytes, step):
+        n = min(step, nbytes - off)
+        if len(pending) == RING_DEPTH - 1:
+            drain(0)
+        i, buf = ring.acquire()
+        with torch.cuda.stream(stream):
+            buf[:n].copy_(db[off:off + n], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        ring.events[i] = ev
+        pending.append((off, n, i))
+    while pending:
+        drain(0)
+    src.record_stream(stream)
+
+
+def to_host(t):
+    """Device tensor -> numpy array (a page-locked array of ours when not small; synchronises)."""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        return t.detach().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+    t = t.detach()
+    if t.dtype not in (torch.float32, torch.float64) or t.numel() * t.element_size() < SMALL_BYTES:
+        return t.cpu().numpy()
+    out = pinned_array(tuple(t.shape), np.float32 if t.dtype == torch.float32 else np.float64)
+    stream = torch.cuda.current_stream(t.device)
+    download_into(out, t, stream)
+    stream.synchronize()
+    return out

@@ -38,7 +38,9 @@ def is_lazy(x):
 
 def _to_numpy(x):
     if _is_tensor(x):
-        return x.detach().cpu().numpy()
+        from . import hostio
+
+        return hostio.to_host(x)
     if is_lazy(x):
         return np.asarray(x[...])  # reads all of it
     return np.asarray(x)

@@ -117,12 +117,15 @@ class ChunkedExchange:
     from K1 in the product; the gloo tests feed it host tensors).
     """
 
-    def __init__(self, nrows, group=None):
+    def __init__(self, nrows, group=None, force=False):
+        """``force``: run the collective even in a world of ONE rank (a sum over one rank is the
+        identity) -- how the RCCL leg (communicator, asynchronous all-reduce on its own stream,
+        ``work.wait()`` ordering) is exercised on a single-GPU box (tests/test_gpu_config4.py)."""
         self.nrows = nrows
         self.group = group
         self._pending = []  # (vector, work handle or None, nt_chunk, has_tail)
         self.active = (dist.is_available() and dist.is_initialized()
-                       and dist.get_world_size(group) > 1)
+                       and (dist.get_world_size(group) > 1 or force))
 
     def add(self, rows, tail=None):
         """rows: (nrows, nt_chunk) partial sums of this rank; tail: (volo, masso0, area_sum)
@@ -185,7 +188,7 @@ def _chunk_source(source, device, steps):
 
 def steric_global_tile_streamed(source, vol0, areacello, pres, variants=("steric",), steps=None,
                                 eos="wright", f32_mode="faithful", group=None, validate_area=True,
-                                heat=False, skip_dry=None, events=None):
+                                heat=False, skip_dry=None, events=None, force_collective=False):
     """Global steric of a horizontally tiled grid over a record of ANY length; call on every rank
     with its tile.  The record is walked in time chunks (``steps`` per chunk): K1 -- the
     all-variants kernel when more than one row is wanted -- runs on the chunk and its partial sums
@@ -197,6 +200,7 @@ def steric_global_tile_streamed(source, vol0, areacello, pres, variants=("steric
     vol0 (nz,ny_t,nx_t): reference volcello; areacello (ny_t,nx_t).  ``heat``: also the
     ocean-heat-content integrand sum(theta*vol0) (extension).  ``events``: list that receives a
     (start, end) torch.cuda.Event pair per chunk around its K1 launch (bench.py).
+    ``force_collective``: all-reduce even with one rank (ChunkedExchange ``force``).
     Returns {variant: finalize() dict} (+ "heat": (nt,) numpy, summed over the whole grid).
     """
     from . import core
@@ -214,7 +218,7 @@ def steric_global_tile_streamed(source, vol0, areacello, pres, variants=("steric
     one_pass = len(variants) > 1 or heat
     names = list(variants) + (["heat"] if heat else [])
     walker, nt = _chunk_source(source, dev, steps)
-    exchange = ChunkedExchange(len(names), group=group)
+    exchange = ChunkedExchange(len(names), group=group, force=force_collective)
     T0 = S0 = None
     for t0, t1, Tc, Sc in walker:
         first = T0 is None
@@ -321,11 +325,20 @@ def steric(dset, reference=None, coord_names=None, varname_map=None, rhozero=103
     rank's own ``(yh, xh)`` tile of thetao / so / volcello / areacello (/ deptho).  Arguments and
     the ``(result, reference)`` return value are those of ``steric`` (src/momlevel/steric.py:17-31).
 
-    ``domain="local"`` needs no communication: the result is the tile's part of the field.
-    ``domain="global"``: the tile sums [masso(t)..., volo] are all-reduced ONCE per call (RCCL over
-    xGMI; nt+1 doubles), every rank returns the same global ``reference_height`` and height time
-    series, and the scalars volo / masso / rhoga of the returned reference state are the GLOBAL
-    ones.  The areacello range check applies to the sum over all tiles.
+    Collectives per call (all latency-bound all-reduces of a few doubles, RCCL over xGMI):
+      * every domain: an error flag, then sum(areacello) over the tiles (the range check of
+        util.validate_areacello is about the whole ocean), then two more error flags around the
+        reference state -- a rank that finds its tile unusable makes EVERY rank raise instead of
+        leaving the others blocked in the next all-reduce (steric.all_ranks_ok);
+      * ``domain="local"``: nothing else -- the DATA path has no collective, the result is the
+        tile's part of the field;
+      * ``domain="global"``: one more flag and the path's one data exchange, the tile sums
+        [masso(t) of every requested variant..., volo] (nt+1 doubles per variant); with a
+        time-dependent ``patm`` also [volo, masso] of the reference state.  Every rank returns the
+        same global ``reference_height`` and height time series, and volo / masso / rhoga of the
+        returned reference state are the GLOBAL ones.
+    The bandwidth path for long records is ``steric_global_tile_streamed`` (one asynchronous
+    all-reduce per time chunk, nothing else).
     """
     from .steric import _steric_many  # (momlevel_amd.steric the attribute is the function)
 

@@ -8,7 +8,7 @@ time loop) are computed there.
 
 import numpy as np
 
-from . import engine
+from . import engine, hostio
 from .adapters import accepts_xarray
 from .labeled import DataArray, Dataset
 from .util import default_coords, eos_func_from_str
@@ -84,7 +84,7 @@ def _setup(dset, patm, eos, coord_names, time_index, defer_masso):
         rho0, volo, masso_t = engine.reference_state_time_dependent(
             T0.data, S0.data, V0.data, p, eos=eos.lower(), f32_mode=_f32_mode())
         tdim = (tcoord,)
-        rho = DataArray(rho0 if on_device else rho0.cpu().numpy(), tdim + cdims,
+        rho = DataArray(rho0 if on_device else hostio.to_host(rho0), tdim + cdims,
                         dict(T0.coords, **({tcoord: dset[tcoord]} if tcoord in dset.variables
                                            else {})), rho_attrs)
         reference["rho"] = rho
@@ -97,7 +97,7 @@ def _setup(dset, patm, eos, coord_names, time_index, defer_masso):
             T0.data, S0.data, V0.data, p, eos=eos.lower(), f32_mode=_f32_mode(),
             with_masso=not defer_masso,
         )
-        rho = DataArray(rho0 if on_device else rho0.cpu().numpy(), cdims, T0.coords, rho_attrs)
+        rho = DataArray(rho0 if on_device else hostio.to_host(rho0), cdims, T0.coords, rho_attrs)
         reference["rho"] = rho.transpose(*reference["thetao"].dims)
         volo_h = float(volo.item())
         masso_h = float("nan") if masso0 is None else float(masso0.item())

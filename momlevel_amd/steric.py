@@ -74,9 +74,14 @@ def _global_results(ops, reference, variants, dtype, tcoord, coords_for, deferre
     ``exchange`` (tiled multi-GPU runs, momlevel_amd.parallel): sums a float64 vector over the
     ranks -- the path's ONE collective: [masso rows of this tile..., volo of this tile]."""
     T, S, T0, S0, vol0, p, eos = ops
-    masso = engine.global_masso_variants(T, S, T0, S0, vol0, p, variants, eos=eos,
-                                         f32_mode=_f32_mode(), with_heat=heat is not None)
-    masso = {v: m.cpu().numpy() for v, m in masso.items()}
+
+    def local_sums():
+        rows = engine.global_masso_variants(T, S, T0, S0, vol0, p, variants, eos=eos,
+                                            f32_mode=_f32_mode(), with_heat=heat is not None)
+        return {v: m.cpu().numpy() for v, m in rows.items()}  # (synchronises: errors surface here)
+
+    masso, err = _attempt(local_sums)
+    all_ranks_ok(exchange, err)  # a rank whose kernels failed must not leave the others waiting
     if exchange is not None:
         names = list(masso)
         nt = masso[names[0]].shape[0]
@@ -158,6 +163,34 @@ def _local_results(ops, dset, reference, variants, dtype, rhozero, names, cdims3
     return out
 
 
+def all_ranks_ok(exchange, error=None):
+    """Make a rank-local failure COLLECTIVE (tiled multi-GPU runs): one tiny all-reduce of an error
+    flag, after which either every rank goes on or every rank raises -- the failing rank its own
+    exception, the others a RuntimeError naming the situation.  Without it a rank that raised
+    between two collectives would leave its peers blocked in the next all-reduce: a hang instead
+    of an error.  No-op for single-domain calls (``exchange`` None)."""
+    if exchange is None:
+        if error is not None:
+            raise error
+        return
+    failed = exchange(np.array([0.0 if error is None else 1.0]))[0]
+    if failed > 0:
+        if error is not None:
+            raise error
+        raise RuntimeError(
+            f"steric(): {int(failed)} other rank(s) of the tiled run failed before the exchange "
+            "(their exception is in their own log); no result on this rank")
+
+
+def _attempt(fn, *args, **kwargs):
+    """-> (result, None) or (None, exception): rank-local work whose failure must first be agreed
+    upon by all ranks (all_ranks_ok) before anybody raises"""
+    try:
+        return fn(*args, **kwargs), None
+    except Exception as exc:  # noqa: BLE001 -- re-raised by all_ranks_ok on this very rank
+        return None, exc
+
+
 def globalise_reference(reference, exchange):
     """Replace the tile sums volo / masso of a reference state made from ONE RANK'S tile by the
     sums over all ranks (rhoga follows); scalar reference states only."""
@@ -182,14 +215,24 @@ def _steric_many(dset, variants, reference, coord_names, varname_map, rhozero, p
     tcoord, zcoord, zbounds = names
 
     area_total = None
-    if exchange is not None and "areacello" in dset.variables:
-        from .util import _area_sum
+    extra_vars = None if domain == "global" else [zbounds, "deptho"]
+    if exchange is not None:
+        # Tiled run: everything a rank can find wrong with ITS tile is established before the
+        # first collective and agreed upon by all ranks; only then are the tile sums exchanged.
+        from .util import _area_sum, local_findings
 
-        area_total = float(exchange(np.array([_area_sum(dset["areacello"])]))[0])
-    validate_dataset(
-        dset, strict=strict, additional_vars=None if domain == "global" else [zbounds, "deptho"],
-        area_total=area_total,
-    )
+        def precheck():
+            fatal = local_findings(dset, additional_vars=extra_vars)
+            if fatal:
+                print("\n".join(fatal))
+                raise ValueError("Errors found in dataset.")
+            return _area_sum(dset["areacello"])
+
+        tile_area, err = _attempt(precheck)
+        all_ranks_ok(exchange, err)
+        area_total = float(exchange(np.array([tile_area]))[0])
+    # (with the global area every rank reaches the same verdict on the range check)
+    validate_dataset(dset, strict=strict, additional_vars=extra_vars, area_total=area_total)
     pres = pressure_field(dset, zcoord, patm)  # 1 m of depth ~ 1 dbar = 1e4 Pa, plus patm
 
     # (not with a time-dependent patm: that reference state is time dependent itself and is
@@ -197,7 +240,9 @@ def _steric_many(dset, variants, reference, coord_names, varname_map, rhozero, p
     deferred = reference is None and domain == "global" and tcoord not in pres.dims
     if reference is None:
         # domain="global": masso0 is masso(t=0) of the K1 launch below (same kernel, same bits)
-        reference = _setup(dset, patm, equation_of_state, coord_names, 0, defer_masso=deferred)
+        reference, err = _attempt(_setup, dset, patm, equation_of_state, coord_names, 0,
+                                  defer_masso=deferred)
+        all_ranks_ok(exchange, err)
         if exchange is not None and not deferred:
             globalise_reference(reference, exchange)
         if verbose:
@@ -206,7 +251,9 @@ def _steric_many(dset, variants, reference, coord_names, varname_map, rhozero, p
         assert isinstance(reference, Dataset), "`reference` must be an xarray Dataset"
         if verbose:
             print("Using supplied reference state")
-    validate_dataset(reference, reference=True, strict=strict, area_total=area_total)
+    _, err = _attempt(validate_dataset, reference, reference=True, strict=strict,
+                      area_total=area_total)
+    all_ranks_ok(exchange, err)
 
     _check_variants(variants)
     eos_func_from_str(equation_of_state)  # unknown EOS -> ValueError (util.py:247)

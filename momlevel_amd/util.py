@@ -119,6 +119,15 @@ def _dataset_findings(dset, reference, additional_vars, area_total=None):
                 yield "error", f"Variable {name} must be a scalar"
 
 
+def local_findings(dset, reference=False, additional_vars=None):
+    """The fatal findings that do not depend on the areacello range check -- what ONE RANK of a
+    tiled run can establish about its own tile before the first collective (steric.all_ranks_ok)."""
+    # area_total=reference value: the range finding cannot fire here; it is judged on the global sum
+    return [msg for severity, msg in _dataset_findings(dset, reference, additional_vars,
+                                                       area_total=3.6111092e14)
+            if severity != "area"]
+
+
 def validate_dataset(dset, reference=False, strict=True, additional_vars=None, area_total=None):
     """Is ``dset`` a usable input (or, ``reference=True``, reference-state) dataset?
 

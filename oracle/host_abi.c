@@ -189,20 +189,6 @@ int mlx_version(void) { return MLX_ABI_VERSION; }
 
 int mlx_build_kind(void) { return MLX_BUILD_HOST; } /* the product refuses to bind this build */
 
-/* nothing to page-lock on the host: argument checks only (the same as the device library's) */
-int mlx_host_pin(void *ptr, size_t nbytes) {
-  if (!ptr) return fail(MLX_E_NULL, "ptr must not be NULL");
-  if (nbytes == 0) return fail(MLX_E_SHAPE, "nbytes must be > 0");
-  if ((uintptr_t)ptr % MLX_HOST_PAGE || nbytes % MLX_HOST_PAGE)
-    return fail(MLX_E_ALIGN, "mlx_host_pin: ptr and nbytes must be multiples of the 4 KiB page");
-  return 0;
-}
-
-int mlx_host_unpin(void *ptr) {
-  if (!ptr) return fail(MLX_E_NULL, "ptr must not be NULL");
-  return 0;
-}
-
 int mlx_last_error(char *buf, size_t n) {
   if (buf && n) {
     strncpy(buf, g_err, n - 1);

@@ -35,6 +35,42 @@ def pytest_collection_modifyitems(config, items):
 
 
 @pytest.fixture(scope="session", autouse=True)
+def _bulk_transfers_through_pinned_memory():
+    """On the GPU box the tests' OWN bulk transfers (``tensor.cpu()``, ``tensor.cuda()`` of a MiB or
+    more) go through page-locked memory too.  A pageable copy of that size makes the HIP runtime
+    pin the malloc'ed source / destination on the fly and cache the pin by address; both aborts
+    this project has seen were GPU page faults on such heap addresses, one of
+    them inside a test's ``.cpu()``.  The product moves its data through momlevel_amd.hostio; this
+    keeps the checker's side of the suite off the same path."""
+    if not _have_gpu():
+        yield
+        return
+    import torch
+
+    limit = 256 << 10
+    orig_cpu, orig_cuda = torch.Tensor.cpu, torch.Tensor.cuda
+
+    def cpu(self, *args, **kwargs):
+        if self.is_cuda and not args and not kwargs and self.numel() * self.element_size() >= limit:
+            out = torch.empty(self.shape, dtype=self.dtype, pin_memory=True)
+            out.copy_(self)
+            return out
+        return orig_cpu(self, *args, **kwargs)
+
+    def cuda(self, *args, **kwargs):
+        if (not self.is_cuda and not args and not kwargs and not self.is_pinned()
+                and self.numel() * self.element_size() >= limit):
+            staged = torch.empty(self.shape, dtype=self.dtype, pin_memory=True)
+            staged.copy_(self)
+            return orig_cuda(staged)
+        return orig_cuda(self, *args, **kwargs)
+
+    torch.Tensor.cpu, torch.Tensor.cuda = cpu, cuda
+    yield
+    torch.Tensor.cpu, torch.Tensor.cuda = orig_cpu, orig_cuda
+
+
+@pytest.fixture(scope="session", autouse=True)
 def _built_library():
     """Make sure libmomlevel_hip.so exists (hipcc cross-compiles without a GPU)."""
     from momlevel_amd.csrc import build

@@ -106,6 +106,23 @@ int main(int argc, char** argv) {
   }
   const long iters = argc > 1 ? atol(argv[1]) : 20000;
   if (mlx_version() != MLX_ABI_VERSION) return 2;
+  {  // a NULL pressure (linear EOS) is a placeholder that only MLX_P_SCALAR never dereferences:
+     // every array mode must be refused before anything is launched
+    void* fake = (void*)(uintptr_t)(1 << 20);
+    for (int pm = MLX_P_ZPROF; pm <= MLX_P_FULL4D; ++pm) {
+      const int rc1 = mlx_steric_global(fake, fake, MLX_DTYPE_F64, (const double*)fake, nullptr, pm,
+                                        MLX_EOS_LINEAR, 2, 3, 32, 96, 96, 0, (double*)fake, fake,
+                                        1 << 20, nullptr);
+      const int rc2 = mlx_steric_local(fake, fake, MLX_DTYPE_F64, (const double*)fake,
+                                       (const double*)fake, (const double*)fake, nullptr, nullptr,
+                                       nullptr, pm, MLX_EOS_LINEAR, -1.0 / 1035.0, 2, 3, 32, 96, 96,
+                                       0, nullptr, (double*)fake, nullptr);
+      if (rc1 != MLX_E_NULL || rc2 != MLX_E_NULL) {
+        fprintf(stderr, "FAIL: NULL p with p_mode %d -> %d / %d, expected MLX_E_NULL\n", pm, rc1, rc2);
+        return 1;
+      }
+    }
+  }
   char tiny[4];
   mlx_last_error(tiny, sizeof tiny);  // truncation path
   mlx_last_error(nullptr, 0);

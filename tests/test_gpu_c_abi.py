@@ -49,7 +49,7 @@ def test_c_abi_demo_matches_python_path():
     dvol = torch.from_numpy(vol).cuda()
     T = core.synth_field((nt, nz, ny, nx), seed=20251114, field_id=1, lo=-2.0, scale=34.0, mask3d=dvol)
     S = core.synth_field((nt, nz, ny, nx), seed=20251114, field_id=2, lo=30.0, scale=10.0, mask3d=dvol)
-    masso = core.steric_global_masso(T, S, dvol, pz).cpu().numpy()
+    masso = core.steric_global_masso(T, S, dvol, pz, arith="exact").cpu().numpy()  # the demo passes flags 0
     volo = core.nansum(dvol).item()
     assert np.array_equal(masso_c, masso)  # %.17g round-trips doubles exactly
     assert volo_c == volo

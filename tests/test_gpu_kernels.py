@@ -441,17 +441,63 @@ def test_fused_arithmetic_meets_the_parity_gate(shape, dtype):
         assert np.nanmax(np.abs(eta - eref)) <= 1e-10 * np.nanmax(np.abs(eref))
 
 
-def test_fused_mode_is_opt_in(monkeypatch):
+def test_default_arithmetic_policy(monkeypatch):
+    """Round 3: the global sums (K1) on float64 theta/S default to fused arithmetic -- within the
+    north-star gate (<= 1e-10 relative) of the oracle, masso(t=0) == masso0 still exact -- while
+    float32 inputs, K0 and K2 keep numpy's exact arithmetic.  MOMLEVEL_AMD_ARITH overrides."""
+    monkeypatch.delenv("MOMLEVEL_AMD_ARITH", raising=False)
     g, vol0, T, S, pres = make_case(4, 3, 8, 16)
     exact = core.steric_global_masso(T, S, vol0, pres, arith="exact").cpu().numpy()
+    fused = core.steric_global_masso(T, S, vol0, pres, arith="fused").cpu().numpy()
+    default = core.steric_global_masso(T, S, vol0, pres).cpu().numpy()
+    assert np.array_equal(default, fused)
+    assert_rel(fused, exact, 1e-12)
+    ref = o.calc_masso(o.calc_rho(T.cpu().numpy(), S.cpu().numpy(), pres), g["volcello"])
+    assert_rel(default, ref, 1e-10, "default (fused) masso vs the oracle")
+    rows = core.steric_global_decomp(T, S, T[0], S[0], vol0, pres).cpu().numpy()
+    assert np.array_equal(rows, core.steric_global_decomp(T, S, T[0], S[0], vol0, pres,
+                                                          arith="fused").cpu().numpy())
+    assert rows[0, 0] == rows[1, 0] == rows[2, 0] == default[0]
+    # pointwise outputs stay bit-identical to numpy by default
+    rho = core.eos_map(T, S, pres).cpu().numpy()
+    assert_bit_equal(rho, o.calc_rho(T.cpu().numpy(), S.cpu().numpy(), pres), "default K0")
+    # float32 inputs: exact (numpy's own float32 polynomial) in every kernel
+    T32, S32 = T.float(), S.float()
+    m32 = core.steric_global_masso(T32, S32, vol0, pres).cpu().numpy()
+    assert np.array_equal(m32, core.steric_global_masso(T32, S32, vol0, pres, arith="exact").cpu().numpy())
+    assert core.arith_default("k1", torch.float64) == "fused"
+    assert core.arith_default("k1", torch.float32) == "exact"
+    assert core.arith_default("k0", torch.float64) == core.arith_default("k2", torch.float64) == "exact"
+    # the environment overrides the policy for every kernel
+    monkeypatch.setenv("MOMLEVEL_AMD_ARITH", "exact")
     assert np.array_equal(core.steric_global_masso(T, S, vol0, pres).cpu().numpy(), exact)
     monkeypatch.setenv("MOMLEVEL_AMD_ARITH", "fused")
-    fused = core.steric_global_masso(T, S, vol0, pres).cpu().numpy()
-    assert np.array_equal(fused, core.steric_global_masso(T, S, vol0, pres, arith="fused").cpu().numpy())
-    assert_rel(fused, exact, 1e-12)
+    assert np.array_equal(core.steric_global_masso(T, S, vol0, pres).cpu().numpy(), fused)
+    assert not np.array_equal(core.eos_map(T, S, pres).cpu().numpy()[~np.isnan(rho)], rho[~np.isnan(rho)])
     monkeypatch.setenv("MOMLEVEL_AMD_ARITH", "sloppy")
     with pytest.raises(ValueError):
         core.steric_global_masso(T, S, vol0, pres)
+
+
+def test_fused_float32_against_the_reference_vectors(wright_vectors):
+    """MLX_FLAG_FMA computes in float64 on the float32 VALUES (upcast), so on float32
+    input it is NOT a few ulp from momlevel: numpy evaluates the polynomial in float32.  Pinned
+    here against the reference module's own float32 outputs (tests/golden/wright_vectors.npz):
+    density within 2e-7 relative -- the float32 rounding of al0, p0, lam -- and nowhere near
+    1e-10; the faithful mode reproduces the same vectors bit for bit (test_gpu_wright.py)."""
+    v = wright_vectors
+    T = torch.from_numpy(v["f32_T"]).cuda()
+    S = torch.from_numpy(v["f32_S"]).cuda()
+    assert T.dtype == torch.float32
+    ref = v["f32_density"]
+    m = np.isfinite(ref)
+    fused = core.eos_map(T, S, v["blk_p"].reshape(-1), arith="fused").cpu().numpy()
+    assert np.array_equal(np.isnan(fused), np.isnan(ref))
+    err = np.max(np.abs(fused[m] - ref[m]) / np.abs(ref[m]))
+    assert 1e-10 < err < 2e-7, err
+    # ... and a few ulp from float64 arithmetic on the same float32 values, which is what it computes
+    up = o.wright_density(v["f32_T"].astype(np.float64), v["f32_S"].astype(np.float64), v["blk_p"])
+    assert_rel(fused, up, 1e-14, "fused vs float64 arithmetic on the float32 values")
 
 
 @pytest.mark.parametrize("t_chunk", [8, 16, 64, 2040])

@@ -415,38 +415,88 @@ def test_memory_mapped_inputs_stream_from_disk(tmp_path, monkeypatch):
     assert_bit_equal(gres["steric"].values, gbase["steric"].values)
 
 
-def test_async_uploads_of_page_locked_chunks(monkeypatch):
-    """chunks of >= 1 MiB are page-locked in place and uploaded on the copy stream while the
-    previous chunk's kernels run (engine.TimeChunks); smaller ones go through a plain copy.  Same
-    bits either way."""
-    from momlevel_amd import engine
+def test_uploads_and_downloads_go_through_owned_staging(monkeypatch):
+    """Round 3: no GPU mapping of caller memory, ever (hostio.py) -- host chunks are copied into a
+    ring of page-locked staging buffers of our own and DMA'd from there, results land in
+    page-locked arrays of our own (or come back through the ring when too large to keep pinned).
+    Forced here through many small pieces (ring wrap-around, ragged last piece) and through the
+    pageable-result path; same bits as the plain path every time."""
+    from momlevel_amd import engine, hostio
 
     d = _masked_dataset(nt=6, nz=12, ny=64, nx=96)  # 590 KB per step and field
-    registered = []
-    real_upload = engine.TimeChunks._upload
+    monkeypatch.setattr(engine, "chunk_steps", lambda nt, b, dev, budget_bytes=None: 2)
+    base, _ = steric(d)
+    gbase, _ = steric(d, domain="global")
+    assert hostio._rings, "the staging ring was never used"
 
-    def spy(self, f, t0, t1):
-        before = len(self._registered)
-        out = real_upload(self, f, t0, t1)
-        registered.append(len(self._registered) > before)
+    acquired = []
+    real_acquire = hostio._Ring.acquire
+
+    def spy(self):
+        out = real_acquire(self)
+        acquired.append(out[0])
         return out
 
-    monkeypatch.setattr(engine.TimeChunks, "_upload", spy)
-    monkeypatch.setattr(engine, "chunk_steps", lambda nt, b, dev, budget_bytes=None: 2)
+    monkeypatch.setattr(hostio._Ring, "acquire", spy)
+    monkeypatch.setattr(hostio, "PIECE_BYTES", 200_000)  # 1.18 MB chunks -> 6 pieces, last ragged
     res, _ = steric(d)
-    assert registered and all(registered)  # 1.18 MB chunks: the asynchronous path
-    registered.clear()
-    monkeypatch.setenv("MOMLEVEL_AMD_ASYNC_H2D", "0")
-    plain, _ = steric(d)
-    assert registered and not any(registered)
-    assert_bit_equal(res["steric"].values, plain["steric"].values)
-    assert_bit_equal(res["delta_rho"].values, plain["delta_rho"].values)
-    registered.clear()
-    monkeypatch.delenv("MOMLEVEL_AMD_ASYNC_H2D")
-    monkeypatch.setattr(engine, "chunk_steps", lambda nt, b, dev, budget_bytes=None: 1)
-    small, _ = steric(d)  # 590 KB chunks stay below the 1 MiB threshold
-    assert registered and not any(registered)
-    assert_bit_equal(small["steric"].values, plain["steric"].values)
+    assert len(acquired) >= 2 * 3 * 6 and set(acquired) == {0, 1, 2}
+    assert_bit_equal(res["steric"].values, base["steric"].values)
+    assert_bit_equal(res["delta_rho"].values, base["delta_rho"].values)
+    gres, _ = steric(d, domain="global")
+    assert_bit_equal(gres["steric"].values, gbase["steric"].values)
+    # results too large to keep page-locked: pageable arrays filled through the same ring
+    monkeypatch.setattr(hostio, "PINNED_RESULT_LIMIT", 0)
+    acquired.clear()
+    big, _ = steric(d)
+    assert acquired
+    assert_bit_equal(big["steric"].values, base["steric"].values)
+    assert_bit_equal(big["delta_rho"].values, base["delta_rho"].values)
+    # the staging buffers are page-locked memory of torch's allocator, never the caller's array
+    ring = next(iter(hostio._rings.values()))
+    assert all(b is None or b.is_pinned() for b in ring.bufs)
+    assert not torch.from_numpy(d["thetao"].values).is_pinned()
+
+
+def test_leading_one_pressure_with_several_time_chunks():
+    """a (1,nz,1,1) pressure (calc_rho's 4-D broadcast of a z profile) must give the same
+    result whatever the number of time chunks -- it used to be sliced like a time-dependent field
+    and came out empty from the second chunk on"""
+    from momlevel_amd import engine
+
+    d = _masked_dataset(nt=5)
+    T = np.ascontiguousarray(d["thetao"].values)
+    S = np.ascontiguousarray(d["so"].values)
+    vol0 = np.ascontiguousarray(d["volcello"].values[0])
+    nz = T.shape[1]
+    pres = o.pressure_from_depth(np.asarray(d["z_l"].values)).reshape(1, nz, 1, 1)
+    one = engine.global_masso(T, S, vol0, pres).cpu().numpy()
+    many = engine.global_masso(T, S, vol0, pres, steps=2).cpu().numpy()
+    assert np.array_equal(one, many)
+    ref = engine.global_masso(T, S, vol0, pres.reshape(nz), steps=2).cpu().numpy()
+    assert np.array_equal(ref, many)
+
+
+def test_hostio_round_trip_ragged_sizes(monkeypatch):
+    """upload / download_into on sizes around the piece and small-transfer boundaries, float32
+    and float64, pinned and pageable destinations"""
+    from momlevel_amd import hostio
+
+    monkeypatch.setattr(hostio, "PIECE_BYTES", 1 << 20)
+    r = np.random.default_rng(5)
+    for dtype in (np.float64, np.float32):
+        for n in (1, 1000, (256 << 10) // 8, (1 << 20) // 8 + 3, 3 * (1 << 20) // 8 + 17, 1234567):
+            a = r.standard_normal(n).astype(dtype)
+            t = hostio.to_device(a, "cuda")
+            assert t.dtype == (torch.float64 if dtype == np.float64 else torch.float32)
+            assert np.array_equal(t.cpu().numpy(), a)
+            for out in (hostio.pinned_array((n,), dtype), np.empty(n, dtype)):
+                hostio.download_into(out, t)
+                torch.cuda.synchronize()
+                assert np.array_equal(out, a)
+            assert np.array_equal(hostio.to_host(t), a)
+    b = r.standard_normal((7, 300, 301))
+    assert np.array_equal(hostio.to_host(hostio.to_device(b[:, ::2], "cuda")), b[:, ::2])
 
 
 @pytest.mark.parametrize("domain", ["local", "global"])

@@ -175,8 +175,10 @@ def test_held_field_kernels_match_reference_vectors(wright_vectors, held, prec, 
         hot = np.full((nz, ny * nx), np.nan)
         hot[z, j] = 1.0
         for skip in (False, True):
+            # (arith="exact": K1's default on float64 input is the fused policy since round 3)
             one = core.steric_global_masso(Tv, Sv, torch.from_numpy(hot.reshape(nz, ny, nx)).cuda(),
-                                           pz, f32_mode=f32_mode, skip_dry=skip).cpu().numpy()
+                                           pz, f32_mode=f32_mode, skip_dry=skip,
+                                           arith="exact").cpu().numpy()
             assert_bit_equal(one, ref.reshape(nt, nz, -1)[:, z, j], f"K1 one-hot held {held}")
 
 

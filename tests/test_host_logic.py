@@ -308,3 +308,29 @@ def test_lazy_arrays_stay_lazy_in_the_labelled_layer():
     assert not slab.is_lazy and np.array_equal(slab.values, a[0])
     assert lazy.largest_read == 2 * 3 * 4 * 5 * 4  # still: nothing larger than the 2-step chunk
     assert np.array_equal(da.values, a)  # an explicit .values reads everything -- by request
+
+
+def test_reported_time_chunks_match_the_kernel_constants():
+    """bench.py reports K1's time steps per block from core.K1_TCHUNK: keep it equal to the
+    constants the library is compiled with"""
+    import os
+    import re
+
+    from momlevel_amd import core
+
+    root = os.path.dirname(os.path.abspath(m.__file__))
+    text = open(os.path.join(root, "csrc", "momlevel_hip.hip")).read()
+    assert int(re.search(r"constexpr int kTChunk = (\d+);", text).group(1)) == core.K1_TCHUNK["steric"]
+    assert int(re.search(r"constexpr int kTChunkHeld = (\d+);", text).group(1)) == core.K1_TCHUNK["held"]
+
+
+def test_leading_one_pressure_is_not_time_dependent():
+    """a (1,nz,1,1) pressure is a z profile (core._pressure squeezes it); slicing it per
+    time chunk would hand chunk 2 an empty operand"""
+    from momlevel_amd import engine
+
+    assert not engine.time_dependent(np.zeros((1, 5, 1, 1)))
+    assert engine.time_dependent(np.zeros((3, 5, 1, 1)))
+    assert not engine.time_dependent(np.zeros((5, 4, 3)))
+    p = np.arange(5.0).reshape(1, 5, 1, 1)
+    assert engine.pressure_chunk(p, 2, 4, None) is p

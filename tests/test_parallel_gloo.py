@@ -163,3 +163,64 @@ def test_chunked_exchange_without_a_process_group():
     assert (volo.item(), masso0.item(), area.item()) == (5.0, 1.0, 7.0)
     with pytest.raises(RuntimeError):
         parallel.ChunkedExchange(1).finish()
+
+
+def _failing_worker(rank, world, port, q, scenario):
+    """the labelled tiled front end when something goes wrong on ONE rank (no GPU needed: the
+    failures under test happen before, or instead of, the first kernel)"""
+    import warnings
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel.init_from_env(backend="gloo")
+    import momlevel_amd as m
+
+    d = m.test_data.generate_test_data()
+    if scenario == "broken_tile" and rank == 1:
+        d = d.drop_vars(["so"]) if hasattr(d, "drop_vars") else _without(d, "so")
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            parallel.steric(d, domain="global", strict=False)
+        q.put((rank, "ok", ""))
+    except Exception as exc:  # noqa: BLE001
+        q.put((rank, type(exc).__name__, str(exc)))
+    dist.barrier()  # every rank got here: nobody is stuck in a collective
+    dist.destroy_process_group()
+
+
+def _without(d, name):
+    from momlevel_amd.labeled import Dataset
+
+    out = Dataset()
+    for k in d.variables:
+        if k != name:
+            out[k] = d[k]
+    return out
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("scenario", ["broken_tile", "no_device"])
+def test_a_failing_rank_makes_every_rank_raise_instead_of_hanging(scenario):
+    """a rank that raised between two collectives used to leave its peers blocked in the
+    next all-reduce.  Now the failure is agreed upon first (steric.all_ranks_ok): the failing rank
+    raises its own exception, the others a RuntimeError -- and all of them reach the barrier."""
+    if scenario == "no_device" and torch.cuda.is_available():
+        pytest.skip("needs a GPU-less host: the rank-local failure is the missing device")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, q, scenario))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict((r[0], r[1:]) for r in (q.get(timeout=240) for _ in range(world)))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    if scenario == "broken_tile":
+        assert results[1][0] == "ValueError" and "Errors found in dataset" in results[1][1]
+        assert results[0][0] == "RuntimeError" and "other rank" in results[0][1]
+    else:  # every rank fails the same way (no HIP device) and says so itself
+        assert results[0][0] == results[1][0] == "MomlevelHipError"
