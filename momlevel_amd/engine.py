@@ -100,46 +100,67 @@ class TimeChunks:
         self._held = [
             to_device(f, device, _stream_dtype(f)) if f.ndim == 3 else None for f in self.fields
         ]
-        # uploads run on their own stream and overlap the previous chunk's kernels and result
-        # download
+        # Uploads run on their own stream AND are staged by a worker thread: while the main thread
+        # enqueues chunk k's kernels and result downloads, the worker copies chunk k+1 into the
+        # staging ring piece by piece and enqueues its DMAs -- H2D(k+1), kernels(k) and D2H(k) all
+        # overlap, and the main thread never blocks in a memcpy.
         self._copy_stream = None if all(self.resident) else torch.cuda.Stream(device=device)
+        self._ring = None if all(self.resident) else hostio.new_ring()
+        self._main = None  # the consumer's stream, captured when the iteration starts
 
     def _upload(self, f, t0, t1):
+        """(worker thread) -> (device tensor, event that completes its upload)"""
         dt = _stream_dtype(f)
         src = f[t0:t1]
         if isinstance(src, torch.Tensor):
-            return src.to(device=self.device, dtype=dt)
+            return src.to(device=self.device, dtype=dt), None
         host = _host_tensor(src, np.float32 if dt == torch.float32 else np.float64)
-        dev = torch.empty(host.shape, dtype=dt, device=self.device)
-        main = torch.cuda.current_stream(self.device)
-        self._copy_stream.wait_stream(main)  # `dev` may reuse memory main is done with
-        hostio.upload(host, dev, stream=self._copy_stream)  # host bytes are staged on return
-        ev = torch.cuda.Event()
-        ev.record(self._copy_stream)
-        dev.record_stream(self._copy_stream)
-        main.wait_event(ev)
-        return dev
+        with torch.cuda.device(self.device):
+            dev = torch.empty(host.shape, dtype=dt, device=self.device)
+            # `dev` may reuse memory the consumer's stream is done with (the allocator is
+            # stream-ordered): everything enqueued there so far goes first
+            self._copy_stream.wait_stream(self._main)
+            hostio.upload(host, dev, stream=self._copy_stream, ring=self._ring)
+            ev = torch.cuda.Event()
+            ev.record(self._copy_stream)
+            dev.record_stream(self._copy_stream)
+        return dev, ev
 
     def _stage(self, t0, t1):
-        cur = []
+        cur, events = [], []
         for f, res, held in zip(self.fields, self.resident, self._held):
             if f.ndim == 3:
                 cur.append(held)
             elif res:
                 cur.append(f[t0:t1])
             else:
-                cur.append(self._upload(f, t0, t1))
-        return cur
+                dev, ev = self._upload(f, t0, t1)
+                cur.append(dev)
+                if ev is not None:
+                    events.append(ev)
+        return cur, events
 
     def __iter__(self):
         bounds = [(t0, min(t0 + self.steps, self.nt)) for t0 in range(0, self.nt, self.steps)]
-        nxt = self._stage(*bounds[0]) if bounds else None
-        for i, (t0, t1) in enumerate(bounds):
-            cur = nxt
-            # chunk i+1 is staged and enqueued for upload before the caller enqueues chunk i's
-            # kernels: the DMA of i+1 overlaps the kernels of i
-            nxt = self._stage(*bounds[i + 1]) if i + 1 < len(bounds) else None
-            yield t0, t1, cur[0], cur[1]
+        if not bounds:
+            return
+        self._main = torch.cuda.current_stream(self.device)
+        if all(self.resident):  # nothing to move: plain slicing
+            for t0, t1 in bounds:
+                cur, _ = self._stage(t0, t1)
+                yield t0, t1, cur[0], cur[1]
+            return
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(1, thread_name_prefix="mlx-upload") as worker:
+            nxt = worker.submit(self._stage, *bounds[0])
+            for i, (t0, t1) in enumerate(bounds):
+                cur, events = nxt.result()  # (re-raises what the worker raised)
+                # chunk i+1 is staged while the caller enqueues chunk i's kernels and downloads
+                nxt = worker.submit(self._stage, *bounds[i + 1]) if i + 1 < len(bounds) else None
+                for ev in events:
+                    self._main.wait_event(ev)  # the consumer's stream waits for this chunk's DMAs
+                yield t0, t1, cur[0], cur[1]
 
 
 def time_dependent(pres):
