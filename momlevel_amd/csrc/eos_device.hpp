@@ -189,44 +189,24 @@ struct ExactFastF32Ops : ExactOps {  // float32-valued al0, p0, lam: the class o
 
 struct FusedOps {
   static constexpr bool fused = true;
-  static constexpr bool guarded = true;
+  static constexpr bool guarded = false;
   template <typename R>
   static __device__ __forceinline__ R mad(R a, R b, R c) {
     return __builtin_fma(a, b, c);
   }
-  // Nothing here has to match numpy's bits, so the guard only has to keep the quotient SANE: the
-  // class of the seed sends 0, inf and huge denominators (seed inf / 0 / denormal) to the IEEE
-  // division of FusedSlowOps, which then yields numpy's inf / 0 instead of a NaN.
-  static __device__ __forceinline__ double quotient(double num, double den, lanemask_t& unsafe) {
+  // Unguarded: nothing here has to match numpy's bits, and the Wright denominator of any ocean
+  // state lives near 2^19.  A denominator of exactly 0, inf or a denormal (temperatures and
+  // salinities hundreds of units outside the fit's range) yields NaN -- skipped by the sums -- where
+  // numpy yields inf / 0.  (Round 3 measured the class guard of ExactFastF32Ops on this policy too:
+  // +2 instructions per cell and -4.5 % on the thermosteric sums, profiles/r03_variants_summary.json
+  // -- not worth it for inputs that are not sea water.)
+  static __device__ __forceinline__ double quotient(double num, double den, lanemask_t&) {
     double r = __builtin_amdgcn_rcp(den);           // ~2^-23 relative
-    unsafe |= lanes_not_nan_nor_normal(r);
     r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);  // ~2^-45
     const double q = num * r;
     return __builtin_fma(__builtin_fma(-den, q, num), r, q);  // exact residual: <= 1 ulp
   }
   static __device__ __forceinline__ lanemask_t p_unsafe(double) { return 0; }
-};
-
-// FusedOps' arithmetic with the IEEE division: what a wave falls back to when FusedOps' guard
-// objects, so that 0 / inf / denormal denominators behave as in numpy (inf, 0, ...) in fused mode
-struct FusedSlowOps : FusedOps {
-  static constexpr bool guarded = false;
-  static __device__ __forceinline__ double quotient(double num, double den, lanemask_t&) {
-    return num / den;
-  }
-};
-
-// FusedOps without the guard, for the one kernel that has no register to spare for it (K1's
-// all-variants pass): identical bits wherever FusedOps' guard stays quiet, i.e. on any ocean data;
-// a 0 / inf / denormal denominator yields NaN (skipped by the sums) instead of numpy's inf / 0.
-struct FusedUnguardedOps : FusedOps {
-  static constexpr bool guarded = false;
-  static __device__ __forceinline__ double quotient(double num, double den, lanemask_t&) {
-    double r = __builtin_amdgcn_rcp(den);
-    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
-    const double q = num * r;
-    return __builtin_fma(__builtin_fma(-den, q, num), r, q);
-  }
 };
 
 // the unguarded twin of a policy: what the kernels rerun a wave's work with after an objection
@@ -241,10 +221,6 @@ struct SlowOf<ExactFastOps> {
 template <>
 struct SlowOf<ExactFastF32Ops> {
   typedef ExactOps type;
-};
-template <>
-struct SlowOf<FusedOps> {
-  typedef FusedSlowOps type;
 };
 
 // ---- the Wright polynomial, split into the part that depends on T only, the part that depends
@@ -535,6 +511,33 @@ __device__ __forceinline__ double eos_eval(int eos, int func, TIn T, TIn S, doub
 }
 
 __device__ __forceinline__ bool is_nan(double x) { return x != x; }
+
+// c += term unless term is NaN (xarray's skipna sums: derived.py:435-438, steric.py:163).  The
+// compiler's form of `c += isnan(term) ? 0.0 : term` is v_cmp + 2 x v_cndmask_b32 + v_add_f64 --
+// four VALU instructions per cell and sum.  PREDICATED does the same operation in two: the
+// compare's lane mask goes into EXEC for the one add (lanes with a NaN term keep their sum
+// untouched) and EXEC is put back; the two scalar instructions issue beside other waves' vector
+// work.  Identical results bit for bit: the select form adds +0.0 in the skipped lanes, and
+// c + 0.0 == c.  Measured in one process per library on one box (profiles/r03_tune_skipna_*.log):
+// +2-5 % on the VALU-bound kernels (every float32 kernel, the float64 held-field sums, the one-pass
+// kernels), -2 % on the HBM-bound float64 steric sum -- so the kernels pick per instantiation.
+// (Not volatile: a pure function of c and term; the compiler stays free to move loads and stores
+// across it, which K2's interleaving of delta_rho stores with arithmetic depends on.)
+template <bool PREDICATED>
+__device__ __forceinline__ void add_skipna(double& c, double term) {
+  if constexpr (PREDICATED) {
+    lanemask_t saved;
+    asm("v_cmp_o_f64 vcc, %2, %2\n\t"
+        "s_and_saveexec_b64 %1, vcc\n\t"
+        "v_add_f64 %0, %0, %2\n\t"
+        "s_mov_b64 exec, %1"
+        : "+v"(c), "=&s"(saved)
+        : "v"(term)
+        : "vcc");
+  } else {
+    c += is_nan(term) ? 0.0 : term;
+  }
+}
 
 __device__ __forceinline__ double canonical_nan() {
   return __longlong_as_double(0x7FF8000000000000LL);

@@ -162,11 +162,12 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
   // the IEEE division (eos_device.hpp, quotients<>); same bits as ExactOps in exact mode.  The
   // all-variants kernel sits at the 256-VGPR / 2-waves-per-SIMD edge and every form of the guard
   // measured (per batch, per step with reloaded operands) pushed it over: it keeps the IEEE
-  // division (exact) and the unguarded Newton quotient (fused) -- the same bits as the guarded
-  // single-variant launches wherever their guard stays quiet.
+  // division in exact mode -- the same bits as the guarded single-variant launches.
   constexpr bool GUARD = !GENERIC && VAR != kVarAll;
+  // the predicated skipna accumulate where the kernel is VALU-bound (eos_device.hpp add_skipna)
+  constexpr bool PRED = !(VAR == kVarSteric && sizeof(TIn) == 8);
   typedef typename std::conditional<
-      FMA, typename std::conditional<GUARD || GENERIC, FusedOps, FusedUnguardedOps>::type,
+      FMA, FusedOps,
       typename std::conditional<GUARD, typename ExactFastFor<MODE>::type, ExactOps>::type>::type Ops;
   static_assert(!FMA || MODE != kF32Faithful, "fused arithmetic is float64");
   __shared__ double red[NOUT][NTC][kBlock];
@@ -333,10 +334,10 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
 #pragma unroll
             for (int o = 0; o < 3; ++o) {
               const double term = r3[o][w] * vol[u][k];
-              c[o] += is_nan(term) ? 0.0 : term;
+              add_skipna<PRED>(c[o], term);
             }
             const double term = (double)curT[u].v[k] * vol[u][k];  // extension: heat content
-            c[3] += is_nan(term) ? 0.0 : term;
+            add_skipna<PRED>(c[3], term);
           }
         }
         continue;
@@ -363,11 +364,11 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
 #pragma unroll
         for (int o = 0; o < NR; ++o) {
           const double term = rho[o][k] * vol[u][k];  // derived.py:435
-          c[o] += is_nan(term) ? 0.0 : term;          // skipna
+          add_skipna<PRED>(c[o], term);                     // skipna
         }
         if constexpr (VAR == kVarAll) {  // extension: heat-content integrand theta*vol0
           const double term = (double)curT[u].v[k] * vol[u][k];
-          c[3] += is_nan(term) ? 0.0 : term;
+          add_skipna<PRED>(c[3], term);
         }
       }
     }
@@ -607,6 +608,7 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
       FMA, FusedOps,
       typename std::conditional<GENERIC, ExactOps, typename ExactFastFor<MODE>::type>::type>::type Ops;
   static_assert(!FMA || MODE != kF32Faithful, "fused arithmetic is float64");
+  constexpr bool PRED = sizeof(TIn) == 4;  // add_skipna form: neutral at float64, +2-3 % at float32
   const int64_t col = (xcd_remap(blockIdx.x, gridDim.x) * kBlock + threadIdx.x) * VEC;
   if (col + VEC > plane) return;  // whole packs only; no barrier below
   const int t0 = blockIdx.y * NTI;
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
             const double dr = rho[o][k] - r0.v[k];  // steric.py:152 (NaN where vol0 is NaN)
             d[o].v[k] = dr;
             const double term = dzv.v[k] * dr;          // steric.py:163
-            acc[o][j][k] += is_nan(term) ? 0.0 : term;  // skipna, z ascending like numpy
+            add_skipna<PRED>(acc[o][j][k], term);             // skipna, z ascending like numpy
           }
         }
         if (drho_out != nullptr) {  // wave-uniform: the eta-only mode skips payload fix and store

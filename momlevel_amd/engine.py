@@ -120,7 +120,8 @@ class TimeChunks:
             # `dev` may reuse memory the consumer's stream is done with (the allocator is
             # stream-ordered): everything enqueued there so far goes first
             self._copy_stream.wait_stream(self._main)
-            hostio.upload(host, dev, stream=self._copy_stream, ring=self._ring)
+            with hostio.roctx_range(f"stage+H2D steps {t0}:{t1} ({host.numel() * host.element_size() >> 20} MiB)"):
+                hostio.upload(host, dev, stream=self._copy_stream, ring=self._ring)
             ev = torch.cuda.Event()
             ev.record(self._copy_stream)
             dev.record_stream(self._copy_stream)

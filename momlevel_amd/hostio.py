@@ -134,6 +134,23 @@ def _host_copy(dst, src):
         f.result()
 
 
+class roctx_range:
+    """``with roctx_range("H2D chunk 3"):`` -- a roctx range (torch's nvtx binding) when
+    MOMLEVEL_AMD_ROCTX=1, nothing otherwise; read by scripts/ingest_profile.py's rocprofv3 run."""
+
+    def __init__(self, name):
+        self.name = name if os.environ.get("MOMLEVEL_AMD_ROCTX") == "1" else None
+
+    def __enter__(self):
+        if self.name is not None:
+            torch.cuda.nvtx.range_push(self.name)
+
+    def __exit__(self, *exc):
+        if self.name is not None:
+            torch.cuda.nvtx.range_pop()
+        return False
+
+
 def new_ring():
     """A private staging ring (engine.TimeChunks stages its uploads from a worker thread and must
     not share buffers with transfers issued by the main thread)."""
