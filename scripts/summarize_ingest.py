@@ -52,7 +52,11 @@ def main(src, out_path):
     ts = lambda r: (int(r["Start_Timestamp"]), int(r["End_Timestamp"]))  # noqa: E731
     h2d = [ts(r) for r in copies if "HOST_TO_DEVICE" in r.get("Direction", "").upper()]
     d2h = [ts(r) for r in copies if "DEVICE_TO_HOST" in r.get("Direction", "").upper()]
-    ker = [ts(r) for r in kernels]
+    # the runtime moves device -> page-locked host with a blit KERNEL (__amd_rocclr_copyBuffer), not
+    # with the DMA engines: those dispatches are downloads, not compute
+    blit = [ts(r) for r in kernels if "rocclr_copy" in r["Kernel_Name"]]
+    ker = [ts(r) for r in kernels if "rocclr_copy" not in r["Kernel_Name"]]
+    d2h = d2h + blit
     out = {"source": src, "ranges": []}
     for r in markers:
         name = r.get("Function", "") or r.get("Name", "")
@@ -70,7 +74,9 @@ def main(src, out_path):
             "range": name, "wall_ms": wall / 1e6,
             "h2d_busy_ms": th / 1e6, "h2d_busy_frac": th / wall, "h2d_copies": len(clip(h2d, lo, hi)),
             "d2h_busy_ms": td / 1e6, "d2h_busy_frac": td / wall,
+            "d2h_note": "SDMA copies + __amd_rocclr_copyBuffer blit kernels (device -> page-locked host)",
             "kernel_busy_ms": tk / 1e6, "kernel_busy_frac": tk / wall,
+            "h2d_or_d2h_busy_frac": union([tuple(x) for x in uh] + [tuple(x) for x in ud])[1] / wall,
             "kernel_hidden_behind_h2d_frac": (overlap(uk, uh) / tk) if tk else None,
             "d2h_hidden_behind_h2d_frac": (overlap(ud, uh) / td) if td else None,
             "host_staging_ranges": len(stage),
