@@ -50,7 +50,7 @@ class _Ring:
         if self.events[i] is not None:
             self.events[i].synchronize()  # the DMA that last used this buffer is done
             self.events[i] = None
-        if self.bufs[i] is None:
+        if self.bufs[i] is None or self.bufs[i].numel() < PIECE_BYTES + _SLACK:
             self.bufs[i] = torch.empty(PIECE_BYTES + _SLACK, dtype=torch.uint8, pin_memory=True)
         return i, self.bufs[i]
 
@@ -66,10 +66,21 @@ def _bytes_view(t):
     return t.view(torch.uint8).reshape(-1)
 
 
+_threads = None
+
+
 def host_threads():
     """Threads for the host side of a staged copy: the CPUs this process may actually use -- its
     affinity mask AND its cgroup CPU quota (a container that sees 128 cores but is allowed 16 must
-    not start 128 copy threads) -- capped at 8; MOMLEVEL_AMD_COPY_THREADS overrides."""
+    not start 128 copy threads) -- capped at 8; MOMLEVEL_AMD_COPY_THREADS overrides.  Evaluated
+    once per process."""
+    global _threads
+    if _threads is None:
+        _threads = _count_host_threads()
+    return _threads
+
+
+def _count_host_threads():
     env = os.environ.get("MOMLEVEL_AMD_COPY_THREADS")
     if env:
         return max(1, int(env))
