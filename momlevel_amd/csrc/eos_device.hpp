@@ -84,7 +84,8 @@ struct Lanes<f2> {
 // ---- arithmetic policies -----------------------------------------------------------------------
 // ExactOps: numpy's evaluation -- every + - * / is ONE correctly rounded IEEE operation, in the
 //   reference's operator order; results are bit-identical to eos/wright.py on the host.
-// FusedOps (opt-in, MLX_FLAG_FMA): the same expression tree with each "c + a*b" node contracted
+// FusedOps (MLX_FLAG_FMA; momlevel_amd's default for the global sums on float64 input, opt-in
+//   elsewhere): the same expression tree with each "c + a*b" node contracted
 //   into one fma and the quotient taken by a Newton reciprocal (v_rcp_f64 + 1 refinement + exact
 //   residual correction; the Wright denominator lives near 2^19, far from over/underflow).  Not
 //   bit-identical to numpy: |rho_fused - rho_numpy| <= a few ulp (parity gate 1e-10 relative).

@@ -1166,6 +1166,11 @@ int steric_local_impl(const void* T, const void* S, const void* T0, const void* 
     if (eta_vstride % vec || drho_vstride % vec) fast = false;
   }
   if (var != kVarAll) var = (sT == 0) ? kVarHalo : ((sS == 0) ? kVarThermo : kVarSteric);
+  // (float32 theta/S evaluated in float64 -- MLX_DTYPE_F32_UPCAST, or MLX_FLAG_FMA on float32 input
+  //  -- were tried in the float64 kernel's shape, 2 columns x 16 steps with float2 loads, because
+  //  four columns of float64 polynomial need 254 VGPRs: 64.6 ms instead of 43 for the upcast pass
+  //  at the roofline grid, no change for the fused one -- 8-byte loads stream worse than they save.
+  //  Neither is a default path.)
   const int v = !fast ? 1 : ((var == kVarAll && !f64) ? kVec32All : vec_of(dtype));
   const int nti = (var == kVarAll) ? (fast ? (f64 ? kNTI64All : kNTI32All) : kNTIGenAll)
                                    : (fast ? (f64 ? kNTI64 : kNTI32) : kNTIGen);

@@ -613,6 +613,59 @@ def test_lazy_inputs_are_read_one_time_chunk_at_a_time(domain, order, monkeypatc
     assert_bit_equal(ref["rho"].transpose(*bref["rho"].dims).values, bref["rho"].values)
 
 
+@pytest.mark.parametrize("domain", ["local", "global"])
+def test_a_failing_source_raises_from_steric_and_leaves_no_thread_behind(domain, monkeypatch):
+    """Uploads are staged by a worker thread (engine.TimeChunks): a source that fails in the middle
+    of the record -- an I/O error of a lazily read file -- must surface as THAT exception from
+    steric(), promptly, and the worker must be gone afterwards; a following call works."""
+    import threading
+
+    from lazy_array import CountingLazy
+    from momlevel_amd import engine
+
+    class Flaky(CountingLazy):
+        def __getitem__(self, key):
+            if isinstance(key, slice) and (key.start or 0) >= 4:
+                raise OSError("simulated read error in the third time chunk")
+            return super().__getitem__(key)
+
+    d = _masked_dataset(nt=7, dtype=np.float32)
+    dl = d.copy()
+    dl["thetao"] = DataArray(Flaky(np.ascontiguousarray(d["thetao"].values)), d["thetao"].dims)
+    monkeypatch.setattr(engine, "chunk_steps", lambda nt, b, dev, budget_bytes=None: 2)
+    with pytest.raises(OSError, match="simulated read error"):
+        steric(dl, domain=domain)
+    assert not [t for t in threading.enumerate() if t.name.startswith("mlx-upload")]
+    good, _ = steric(d, domain=domain)  # the streams and the staging ring are still usable
+    base, _ = steric(d, domain=domain)
+    assert_bit_equal(good["steric"].values, base["steric"].values)
+
+
+def test_time_chunks_stop_early_without_hanging(monkeypatch):
+    """a consumer that leaves the chunk loop early (an exception of its own, a `return`) shuts the
+    upload worker down with the generator"""
+    import threading
+
+    from momlevel_amd import engine
+
+    r = np.random.default_rng(3)
+    T = r.uniform(0, 30, (9, 4, 64, 96))
+    S = r.uniform(30, 40, (9, 4, 64, 96))
+    chunks = engine.TimeChunks(T, S, torch.device("cuda", 0), steps=2)
+    seen = []
+    for t0, t1, Tc, Sc in chunks:
+        seen.append((t0, t1))
+        assert np.array_equal(Tc.cpu().numpy(), T[t0:t1])
+        if len(seen) == 2:
+            break
+    del chunks
+    import gc
+
+    gc.collect()
+    assert seen == [(0, 2), (2, 4)]
+    assert not [t for t in threading.enumerate() if t.name.startswith("mlx-upload")]
+
+
 @pytest.mark.parametrize("resident", [False, True])
 def test_local_variants_come_from_one_pass(resident, monkeypatch):
     """steric_variants(domain="local") with all three variants: one launch of the all-variants K2
