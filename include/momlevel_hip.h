@@ -82,20 +82,22 @@ extern "C" {
                                never leave HBM.  0 = load every cell, wet or dry.               */
 #define MLX_FLAG_FMA 2      /* fused arithmetic for the Wright DENSITY: the reference's expression
                                tree with every "c + a*b" contracted into one fma and the quotient
-                               taken by a Newton reciprocal, all in float64.  NOT bit-identical to
-                               numpy: on float64 theta/S rho differs by a few ulp (parity gate: 1e-10
-                               relative on rho and masso, 1e-10*max|ref| on delta_rho and eta).  On
-                               float32 theta/S the values are UPCAST first, so the result is a few ulp
-                               from float64 arithmetic on those values and ~1e-7 relative from what
-                               numpy computes on float32 input (its float32 polynomial, MLX_DTYPE_F32)
-                               -- further from the reference, not closer; pinned at < 2e-7 against
-                               the reference module's float32 outputs.  All kernels share one tree,
-                               so in this mode too masso(t=0) == masso0 and delta_rho(t=0) == 0 hold
-                               exactly.  About two thirds of the VALU work per cell: lifts the 8 B/cell
-                               thermosteric / halosteric sums off the fp64-VALU bound.  momlevel_amd
-                               passes it by default for the global sums (mlx_steric_global*) on
-                               float64 input only.  Denominators of exactly 0 / inf / denormal size
-                               (never sea water) give NaN here, inf / 0 in numpy.                   */
+                               taken by a Newton reciprocal.  NOT bit-identical to numpy:
+                               - MLX_DTYPE_F64: rho differs by a few ulp (parity gate: 1e-10 relative
+                                 on rho and masso, 1e-10*max|ref| on delta_rho and eta);
+                               - MLX_DTYPE_F32 (numpy's mixed precision): the float32 polynomial is
+                                 evaluated exactly as numpy rounds it, only the float64 tail
+                                 (lam + al0*(p+p0), the quotient) is fused: a few float64 ulp from what
+                                 numpy computes on float32 input;
+                               - MLX_DTYPE_F32_UPCAST: the float64 form on the upcast values (a few
+                                 ulp from float64 arithmetic on them, ~1e-7 from numpy's float32
+                                 polynomial).
+                               All kernels share one tree, so in this mode too masso(t=0) == masso0
+                               and delta_rho(t=0) == 0 hold exactly.  About two thirds of the VALU work
+                               per cell: lifts the thermosteric / halosteric sums and every float32
+                               sum off the fp64-VALU bound.  momlevel_amd passes it by default for the
+                               global sums (mlx_steric_global*) only.  Denominators of exactly 0 / inf
+                               / denormal size (never sea water) give NaN here, inf / 0 in numpy.  */
 #define MLX_FLAG_TCHUNK_MASK 0xFF00 /* K1 tuning hint, never changes a result: time steps per
                                block = 8 * ((flags >> 8) & 0xFF); 0 = the default (32)            */
 #define MLX_FLAG_TCHUNK(steps) ((((steps) / 8) & 0xFF) << 8)

@@ -38,28 +38,29 @@ def arith_default(kernel="k0", dtype=None):
     """Arithmetic of the Wright density when the caller does not choose (``arith=None``).
 
     "exact": numpy's operator-for-operator evaluation, bit-identical to the reference.
-    "fused": MLX_FLAG_FMA -- contracted multiply-adds and a Newton reciprocal in float64, <= 2 ulp
-    from numpy on rho (parity gate 1e-10 relative), about two thirds of the VALU work per cell.
+    "fused": MLX_FLAG_FMA -- contracted multiply-adds and a Newton reciprocal: on float64 theta/S the
+    whole expression (<= 2 ulp from numpy on rho, two thirds of the VALU work per cell); on float32
+    theta/S in numpy's mixed precision (``f32_mode="faithful"``) the float32 polynomial is kept
+    exactly as numpy rounds it and only the float64 tail is fused (a few float64 ulp from numpy's
+    own value on float32 input); with ``f32_mode="upcast"`` it is float64 arithmetic on the
+    float32 values.  Parity gate either way: 1e-10 relative.
 
     Default policy (MOMLEVEL_AMD_ARITH unset):
-      * K1, the global sums (``domain="global"``: masso(t), src/momlevel/steric.py:134-147), on
-        float64 theta/S -> "fused".  No global result was ever bit-identical to numpy -- the order
-        of summation over (z,y,x) already differs at the 1e-15 level -- so exact arithmetic bought
-        nothing there and kept the held-field variants and the one-pass decomposition on the fp64
-        VALU bound (0.48-0.68 of the HBM roofline instead of 0.6-0.8).  masso(t=0) == masso0 and
-        steric[t=0] == 0.0 hold exactly in this mode too (one expression tree in every kernel).
+      * K1, the global sums (``domain="global"``: masso(t), src/momlevel/steric.py:134-147) ->
+        "fused".  No global result was ever bit-identical to numpy -- the order of summation over
+        (z,y,x) already differs at the 1e-15 level -- so exact arithmetic bought nothing there and
+        kept the held-field variants, the one-pass decomposition and every float32 sum on the fp64
+        VALU bound.  masso(t=0) == masso0 and steric[t=0] == 0.0 hold exactly in this mode too (one
+        expression tree in every kernel).
       * K0 / K2, the pointwise outputs (rho, delta_rho, local eta) -> "exact": those ARE
         bit-identical to numpy and stay so.
-      * float32 theta/S -> "exact" in every kernel: the fused policy computes in float64 (float32
-        inputs are upcast), which is ~1e-7 relative away from numpy's own float32 polynomial --
-        further from the reference, not closer.  Ask for it explicitly (arith="fused") if wanted.
     MOMLEVEL_AMD_ARITH=exact|fused overrides the policy for every kernel and dtype.
     """
     import os
 
     mode = os.environ.get("MOMLEVEL_AMD_ARITH")
     if mode is None:
-        return "fused" if (kernel == "k1" and dtype == torch.float64) else "exact"
+        return "fused" if kernel == "k1" else "exact"
     if mode not in ARITH_FLAGS:
         raise ValueError(f"MOMLEVEL_AMD_ARITH must be 'exact' or 'fused', got '{mode}'")
     return mode
@@ -238,8 +239,7 @@ def steric_global_masso(T, S, vol0, p, eos="wright", f32_mode="faithful", events
     ``events=(start, end)``: two ``torch.cuda.Event(enable_timing=True)`` recorded on the
     launch stream immediately around the kernel launches (bench.py's per-launch timing).
     ``skip_dry``: MLX_FLAG_SKIP_DRY (None = the default policy, on); results are bit-identical
-    either way.  ``arith``: "exact" | "fused" (None = arith_default("k1", dtype): fused for
-    float64 theta/S, exact for float32).  ``t_chunk``: tuning
+    either way.  ``arith``: "exact" | "fused" (None = arith_default("k1"): fused).  ``t_chunk``: tuning
     hint, time steps per block (multiple of 8; 0 = library default); never changes a result.
     ``p`` may be time dependent, (nt,nz,ny,nx)-broadcastable (a DataArray ``patm``).
     """

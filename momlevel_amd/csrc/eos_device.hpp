@@ -84,12 +84,13 @@ struct Lanes<f2> {
 // ---- arithmetic policies -----------------------------------------------------------------------
 // ExactOps: numpy's evaluation -- every + - * / is ONE correctly rounded IEEE operation, in the
 //   reference's operator order; results are bit-identical to eos/wright.py on the host.
-// FusedOps (MLX_FLAG_FMA; momlevel_amd's default for the global sums on float64 input, opt-in
-//   elsewhere): the same expression tree with each "c + a*b" node contracted
+// FusedOps (MLX_FLAG_FMA; momlevel_amd's default for the global sums, opt-in elsewhere): the same
+//   expression tree with each "c + a*b" node contracted
 //   into one fma and the quotient taken by a Newton reciprocal (v_rcp_f64 + 1 refinement + exact
 //   residual correction; the Wright denominator lives near 2^19, far from over/underflow).  Not
 //   bit-identical to numpy: |rho_fused - rho_numpy| <= a few ulp (parity gate 1e-10 relative).
-//   Always float64, also for float32 theta/S (upcast first).
+//   float64 arithmetic; float32 theta/S in numpy's mixed precision keep their float32 polynomial
+//   and fuse the float64 tail only (FusedTailOps below).
 // ---- the reciprocal ------------------------------------------------------------------------------
 // hipcc expands the IEEE f64 division 1.0/den into
 //     d' = v_div_scale(den)   y = v_rcp_f64(d')   2 x { e = fma(-d',y,1); y = fma(y,e,y) }
@@ -208,6 +209,38 @@ struct FusedOps {
     return __builtin_fma(__builtin_fma(-den, q, num), r, q);  // exact residual: <= 1 ulp
   }
   static __device__ __forceinline__ lanemask_t p_unsafe(double) { return 0; }
+};
+
+// MLX_FLAG_FMA on float32 theta/S in numpy's mixed precision (MLX_DTYPE_F32): the POLYNOMIAL stays
+// what numpy computes on float32 arrays -- float32, every + and * rounded separately, because that
+// rounding (1e-7 relative) is what makes a float32 result a float32 result -- and only the float64
+// TAIL is fused: den = fma(al0, p + p0, lam) and FusedOps' Newton quotient.  rho is then within a
+// few float64 ulp of numpy's own value on float32 input (FusedOps on upcast values is 1e-7 away),
+// for four instructions per cell less than the exact tail.
+struct FusedTailOps {
+  static constexpr bool fused = false;  // no pressure folding: p enters in float64, as in numpy
+  static constexpr bool guarded = false;
+  template <typename A, typename B, typename C>
+  static __device__ __forceinline__ auto mad(A a, B b, C c) -> decltype(a * b + c) {
+    return a * b + c;  // the float32 polynomial: two roundings (contraction is off)
+  }
+  static __device__ __forceinline__ double mad(double a, double b, double c) {
+    return __builtin_fma(a, b, c);  // the float64 tail (an exact match beats the template)
+  }
+  static __device__ __forceinline__ double quotient(double num, double den, lanemask_t& m) {
+    return FusedOps::quotient(num, den, m);
+  }
+  static __device__ __forceinline__ lanemask_t p_unsafe(double) { return 0; }
+};
+
+// the policy of MLX_FLAG_FMA for a dtype mode
+template <int MODE>
+struct FusedFor {
+  typedef FusedOps type;
+};
+template <>
+struct FusedFor<kF32Faithful> {
+  typedef FusedTailOps type;
 };
 
 // the unguarded twin of a policy: what the kernels rerun a wave's work with after an objection
@@ -375,7 +408,7 @@ struct PolyVec<kF32Faithful, 4> {
 template <int MODE, typename TIn, typename Ops = ExactOps>
 __device__ __forceinline__ double wright_density(TIn Tin, TIn Sin, double p) {
   typedef typename PolyType<MODE>::type R;
-  static_assert(!(Ops::fused && MODE == kF32Faithful), "FusedOps computes in float64");
+  static_assert(!(Ops::fused && MODE == kF32Faithful), "FusedOps computes in float64: FusedTailOps");
   const TPart<R> a = t_part<Ops, R>((R)Tin);
   const SPart<R> b = s_part<Ops, R>((R)Sin, Ops::fused ? (R)p : R(0));
   return wright_combine<Ops, R>(a, b, p);

@@ -138,7 +138,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 // SKIP (MLX_FLAG_SKIP_DRY): a pack whose vol0 is NaN in every cell contributes exactly 0
 // whatever theta/S hold (rho*NaN is skipped), so its lanes neither load nor compute; whole
 // 64/128-byte lines of land or sub-bottom cells then never leave HBM.  Same bits out.
-// FMA (MLX_FLAG_FMA): FusedOps arithmetic (eos_device.hpp), float64, not bit-identical to numpy.
+// FMA (MLX_FLAG_FMA): FusedOps arithmetic (eos_device.hpp; FusedTailOps on float32 input in
+// numpy's mixed precision), not bit-identical to numpy.
 // ------------------------------------------------------------------------------------
 constexpr int kVarSteric = 0, kVarHalo = 1, kVarThermo = 2, kVarAll = 3;
 
@@ -167,9 +168,8 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
   // the predicated skipna accumulate where the kernel is VALU-bound (eos_device.hpp add_skipna)
   constexpr bool PRED = !(VAR == kVarSteric && sizeof(TIn) == 8);
   typedef typename std::conditional<
-      FMA, FusedOps,
+      FMA, typename FusedFor<MODE>::type,
       typename std::conditional<GUARD, typename ExactFastFor<MODE>::type, ExactOps>::type>::type Ops;
-  static_assert(!FMA || MODE != kF32Faithful, "fused arithmetic is float64");
   __shared__ double red[NOUT][NTC][kBlock];
 
   const int tid = threadIdx.x;
@@ -212,8 +212,8 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
   double pz = 0.0;
   if (!GENERIC || p_mode == MLX_P_ZPROF) pz = p[z];
   if (GENERIC && p_mode == MLX_P_SCALAR) pz = p[0];
-  RV pfold = RV{};  // FusedOps (float64 only) folds the level's pressure into B0
-  if constexpr (FMA) pfold = (R)pz;
+  RV pfold = RV{};  // FusedOps (float64 polynomial) folds the level's pressure into B0
+  if constexpr (Ops::fused) pfold = (R)pz;
   const lanemask_t pbad = Ops::p_unsafe(pz);  // the level's pressure vetoes the fast quotient?
 
   // held fields: read once; fast path keeps their PART of the polynomial, generic the values
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(kBlock) void k_eos_map(const TIn* __restrict__ T,
                                                     double* __restrict__ out) {
   // the fast density kernels use the guarded policies (scale-free reciprocal, eos_device.hpp)
   typedef typename std::conditional<
-      FMA, FusedOps,
+      FMA, typename FusedFor<MODE>::type,
       typename std::conditional<!GENERIC && FUNC == kDensity, typename ExactFastFor<MODE>::type,
                                 ExactOps>::type>::type Ops;
   const int z = blockIdx.y;
@@ -605,9 +605,8 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
   typedef typename PolyVec<MODE, GENERIC ? 1 : VEC>::type RV;  // float2 pairs: see K1
   constexpr int W = Lanes<RV>::n, G = VEC / W;
   typedef typename std::conditional<
-      FMA, FusedOps,
+      FMA, typename FusedFor<MODE>::type,
       typename std::conditional<GENERIC, ExactOps, typename ExactFastFor<MODE>::type>::type>::type Ops;
-  static_assert(!FMA || MODE != kF32Faithful, "fused arithmetic is float64");
   constexpr bool PRED = sizeof(TIn) == 4;  // add_skipna form: neutral at float64, +2-3 % at float32
   const int64_t col = (xcd_remap(blockIdx.x, gridDim.x) * kBlock + threadIdx.x) * VEC;
   if (col + VEC > plane) return;  // whole packs only; no barrier below
@@ -663,7 +662,7 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
       if (HELD_S) hS = load_pack<TIn, VEC>((VAR == kVarAll ? S0 : S) + off);
     }
     RV pfold = RV{};
-    if constexpr (FMA) pfold = (R)pz;
+    if constexpr (Ops::fused) pfold = (R)pz;
     TPart<RV> hTp[G];
     SPart<RV> hSp[G];
     if constexpr (!GENERIC && HELD_T) {
@@ -976,7 +975,7 @@ void k1_go(const K1Args& a) {
 
 template <typename TIn, int VEC, int U, int VAR, int MODE, bool GEN>
 void k1_flags(const K1Args& a, bool skip, bool fma) {
-  constexpr int FM = (MODE == kF32Faithful) ? kF32Upcast : MODE;  // fused arithmetic is float64
+  constexpr int FM = MODE;   // (faithful float32 keeps its float32 polynomial under MLX_FLAG_FMA)
   constexpr bool S1 = !GEN;  // the generic twin has no skipping instantiation
   if (fma) {
     if (skip && S1) k1_go<TIn, VEC, U, VAR, FM, GEN, S1, true>(a);
@@ -1097,7 +1096,7 @@ void k2_go(const K2Args& a) {
 
 template <typename TIn, int VEC, int NTI, int VAR, int MODE, bool GEN>
 void k2_flags(const K2Args& a, bool skip, bool fma) {
-  constexpr int FM = (MODE == kF32Faithful) ? kF32Upcast : MODE;
+  constexpr int FM = MODE;
   constexpr bool S1 = !GEN;
   if (fma) {
     if (skip && S1) k2_go<TIn, VEC, NTI, VAR, FM, GEN, S1, true>(a);
@@ -1255,7 +1254,8 @@ static int eos_map_impl(const void* T, const void* S, int dtype, const double* p
           default: MLX_LAUNCH_K0(double, 2, kF64, kBeta, false); break;
         }
       } else if (fma) {
-        MLX_LAUNCH_K0(float, 4, kF32Upcast, kDensity, true);
+        if (dtype == MLX_DTYPE_F32) MLX_LAUNCH_K0(float, 4, kF32Faithful, kDensity, true);
+        else MLX_LAUNCH_K0(float, 4, kF32Upcast, kDensity, true);
       } else if (dtype == MLX_DTYPE_F32) {
         MLX_LAUNCH_K0(float, 4, kF32Faithful, kDensity, false);
       } else {
@@ -1271,6 +1271,7 @@ static int eos_map_impl(const void* T, const void* S, int dtype, const double* p
                      aux, out)
       if (fma) {
         if (f64) MLX_LAUNCH_K0G(double, kF64, true);
+        else if (dtype == MLX_DTYPE_F32) MLX_LAUNCH_K0G(float, kF32Faithful, true);
         else MLX_LAUNCH_K0G(float, kF32Upcast, true);
       } else if (f64) MLX_LAUNCH_K0G(double, kF64, false);
       else if (dtype == MLX_DTYPE_F32) MLX_LAUNCH_K0G(float, kF32Faithful, false);

@@ -398,7 +398,9 @@ def test_fused_arithmetic_meets_the_parity_gate(shape, dtype):
     OTHER bit for bit: masso(t=0) identical across variants and equal to the reference state's,
     delta_rho(t=0) exactly 0, K0 == K2 + rho0."""
     g, T, S = _case_fields(shape, dtype)
-    Tn, Sn = T.astype(np.float64), S.astype(np.float64)  # fused arithmetic is float64 on the values
+    # float32 input (numpy's mixed precision, the default f32_mode): the fused policy keeps numpy's
+    # float32 polynomial and fuses the float64 tail only -- the oracle is numpy ON THE float32 ARRAYS
+    Tn, Sn = T, S
     dT, dS = torch.from_numpy(T).cuda(), torch.from_numpy(S).cuda()
     vol0 = torch.from_numpy(g["volcello"]).cuda()
     pres = o.pressure_from_depth(g["z_l"])
@@ -442,9 +444,9 @@ def test_fused_arithmetic_meets_the_parity_gate(shape, dtype):
 
 
 def test_default_arithmetic_policy(monkeypatch):
-    """Round 3: the global sums (K1) on float64 theta/S default to fused arithmetic -- within the
-    north-star gate (<= 1e-10 relative) of the oracle, masso(t=0) == masso0 still exact -- while
-    float32 inputs, K0 and K2 keep numpy's exact arithmetic.  MOMLEVEL_AMD_ARITH overrides."""
+    """Round 3: the global sums (K1) default to fused arithmetic -- within the
+    north-star gate (<= 1e-10 relative) of the oracle, masso(t=0) == masso0 still exact -- while K0
+    and K2 (pointwise outputs) keep numpy's exact arithmetic.  MOMLEVEL_AMD_ARITH overrides."""
     monkeypatch.delenv("MOMLEVEL_AMD_ARITH", raising=False)
     g, vol0, T, S, pres = make_case(4, 3, 8, 16)
     exact = core.steric_global_masso(T, S, vol0, pres, arith="exact").cpu().numpy()
@@ -461,12 +463,17 @@ def test_default_arithmetic_policy(monkeypatch):
     # pointwise outputs stay bit-identical to numpy by default
     rho = core.eos_map(T, S, pres).cpu().numpy()
     assert_bit_equal(rho, o.calc_rho(T.cpu().numpy(), S.cpu().numpy(), pres), "default K0")
-    # float32 inputs: exact (numpy's own float32 polynomial) in every kernel
+    # float32 inputs: the same policy -- K1 fused (float32 polynomial as numpy rounds it, fused
+    # float64 tail: a few ulp from the exact kernel), K0 / K2 exact
     T32, S32 = T.float(), S.float()
     m32 = core.steric_global_masso(T32, S32, vol0, pres).cpu().numpy()
-    assert np.array_equal(m32, core.steric_global_masso(T32, S32, vol0, pres, arith="exact").cpu().numpy())
-    assert core.arith_default("k1", torch.float64) == "fused"
-    assert core.arith_default("k1", torch.float32) == "exact"
+    assert np.array_equal(m32, core.steric_global_masso(T32, S32, vol0, pres, arith="fused").cpu().numpy())
+    assert_rel(m32, core.steric_global_masso(T32, S32, vol0, pres, arith="exact").cpu().numpy(), 1e-13)
+    ref32 = o.calc_masso(o.calc_rho(T32.cpu().numpy(), S32.cpu().numpy(), pres), g["volcello"])
+    assert_rel(m32, ref32, 1e-12, "default float32 masso vs numpy on the float32 arrays")
+    assert_bit_equal(core.eos_map(T32, S32, pres).cpu().numpy(),
+                     o.calc_rho(T32.cpu().numpy(), S32.cpu().numpy(), pres), "default K0, float32")
+    assert core.arith_default("k1", torch.float64) == core.arith_default("k1", torch.float32) == "fused"
     assert core.arith_default("k0", torch.float64) == core.arith_default("k2", torch.float64) == "exact"
     # the environment overrides the policy for every kernel
     monkeypatch.setenv("MOMLEVEL_AMD_ARITH", "exact")
@@ -480,24 +487,39 @@ def test_default_arithmetic_policy(monkeypatch):
 
 
 def test_fused_float32_against_the_reference_vectors(wright_vectors):
-    """MLX_FLAG_FMA computes in float64 on the float32 VALUES (upcast), so on float32
-    input it is NOT a few ulp from momlevel: numpy evaluates the polynomial in float32.  Pinned
-    here against the reference module's own float32 outputs (tests/golden/wright_vectors.npz):
-    density within 2e-7 relative -- the float32 rounding of al0, p0, lam -- and nowhere near
-    1e-10; the faithful mode reproduces the same vectors bit for bit (test_gpu_wright.py)."""
+    """MLX_FLAG_FMA on float32 theta/S.  With numpy's mixed precision (MLX_DTYPE_F32, the
+    default) the float32 polynomial is evaluated exactly as numpy rounds it and only the float64
+    tail is fused, so the density is a few float64 ulp from what the reference module computed on
+    the same float32 arrays (tests/golden/wright_vectors.npz).  With f32_mode="upcast" it is float64
+    arithmetic on the float32 VALUES: a few ulp from that, and the float32 rounding of al0, p0, lam
+    (~1e-7) away from the reference -- pinned at 1e-10 < err < 2e-7."""
     v = wright_vectors
     T = torch.from_numpy(v["f32_T"]).cuda()
     S = torch.from_numpy(v["f32_S"]).cuda()
     assert T.dtype == torch.float32
     ref = v["f32_density"]
     m = np.isfinite(ref)
-    fused = core.eos_map(T, S, v["blk_p"].reshape(-1), arith="fused").cpu().numpy()
+    p = v["blk_p"].reshape(-1)
+    fused = core.eos_map(T, S, p, arith="fused").cpu().numpy()
     assert np.array_equal(np.isnan(fused), np.isnan(ref))
-    err = np.max(np.abs(fused[m] - ref[m]) / np.abs(ref[m]))
+    assert np.max(np.abs(fused[m] - ref[m]) / np.abs(ref[m])) < 1e-15
+    assert not np.array_equal(fused[m], ref[m])  # (it IS the fused kernel)
+    upf = core.eos_map(T, S, p, arith="fused", f32_mode="upcast").cpu().numpy()
+    err = np.max(np.abs(upf[m] - ref[m]) / np.abs(ref[m]))
     assert 1e-10 < err < 2e-7, err
-    # ... and a few ulp from float64 arithmetic on the same float32 values, which is what it computes
     up = o.wright_density(v["f32_T"].astype(np.float64), v["f32_S"].astype(np.float64), v["blk_p"])
-    assert_rel(fused, up, 1e-14, "fused vs float64 arithmetic on the float32 values")
+    assert_rel(upf, up, 1e-14, "upcast + fused vs float64 arithmetic on the float32 values")
+    # held-field operands (thermosteric / halosteric) through K2, fused: delta_rho + rho0 within
+    # a few ulp of the reference module's broadcast float32 outputs
+    nt, nz, ny, nx = v["f32_T"].shape
+    vol = torch.ones((nz, ny, nx), dtype=torch.float64, device="cuda")
+    rho0 = core.eos_map(T[0], S[0], p, arith="fused")
+    z_i = np.concatenate([[0.0], np.cumsum(np.full(nz, 10.0))])
+    for a_, b_, key in ((T, S[0], "f32_density_heldS"), (T[0], S, "f32_density_heldT")):
+        drho, _ = core.steric_local(a_, b_, core.fold_mask(rho0, vol), vol[0], p, -1.0 / 1035.0,
+                                    z_i=z_i, deptho=np.full((ny, nx), 1e4), arith="fused")
+        got = drho.cpu().numpy() + rho0.cpu().numpy()
+        assert np.max(np.abs(got - v[key]) / v[key]) < 1e-15, key
 
 
 @pytest.mark.parametrize("t_chunk", [8, 16, 64, 2040])
@@ -613,10 +635,16 @@ def test_config5_f32_properties():
     heat = np.nansum(Tn.astype(np.float64) * g["volcello"])
     assert abs(rows[3][t] - heat) <= 1e-12 * abs(heat)
     # the tolerance study in one line each: upcast and fused arithmetic vs the faithful result
-    up = core.steric_global_decomp(T, S, T[0], S[0], vol0, pres, f32_mode="upcast").cpu().numpy()
+    up = core.steric_global_decomp(T, S, T[0], S[0], vol0, pres, f32_mode="upcast",
+                                   arith="exact").cpu().numpy()
     fu = core.steric_global_decomp(T, S, T[0], S[0], vol0, pres, arith="fused").cpu().numpy()
-    assert np.max(np.abs(up[:3] - rows[:3]) / rows[:3]) < 2e-7   # float32 polynomial rounding
-    assert np.max(np.abs(fu[:3] - up[:3]) / up[:3]) < 1e-12      # fused == upcast to ~1e-15
+    ex = core.steric_global_decomp(T, S, T[0], S[0], vol0, pres, arith="exact").cpu().numpy()
+    upf = core.steric_global_decomp(T, S, T[0], S[0], vol0, pres, f32_mode="upcast",
+                                    arith="fused").cpu().numpy()
+    assert np.array_equal(fu, rows)                                # the default IS the fused policy
+    assert np.max(np.abs(fu[:3] - ex[:3]) / ex[:3]) < 1e-12      # float32 polynomial kept: ~1e-15
+    assert np.max(np.abs(up[:3] - ex[:3]) / ex[:3]) < 2e-7       # upcast: float32 polynomial rounding
+    assert np.max(np.abs(upf[:3] - up[:3]) / up[:3]) < 1e-12     # upcast fused == upcast to ~1e-15
     assert np.array_equal(fu[3], rows[3]) and np.array_equal(up[3], rows[3])
     # local variant on a 135-row band of one step, float32, vs the oracle (bit-exact)
     y0, y1 = 400, 535
