@@ -10,7 +10,6 @@ state stays resident on the device.  Every byte moves through hostio.py: staging
 result buffers of our own, never a GPU mapping of the caller's memory.
 """
 
-import os
 import warnings
 
 import numpy as np
@@ -116,7 +115,11 @@ class TimeChunks:
             return src.to(device=self.device, dtype=dt), None
         host = _host_tensor(src, np.float32 if dt == torch.float32 else np.float64)
         with torch.cuda.device(self.device):
-            dev = torch.empty(host.shape, dtype=dt, device=self.device)
+            # the chunk belongs to the CONSUMER's stream (the caching allocator ties a block to the
+            # stream that was current when it was allocated -- in this worker thread that would be
+            # the default stream, whatever stream the consumer runs on)
+            with torch.cuda.stream(self._main):
+                dev = torch.empty(host.shape, dtype=dt, device=self.device)
             # `dev` may reuse memory the consumer's stream is done with (the allocator is
             # stream-ordered): everything enqueued there so far goes first
             self._copy_stream.wait_stream(self._main)

@@ -641,6 +641,24 @@ def test_a_failing_source_raises_from_steric_and_leaves_no_thread_behind(domain,
     assert_bit_equal(good["steric"].values, base["steric"].values)
 
 
+@pytest.mark.parametrize("domain", ["local", "global"])
+def test_host_inputs_under_a_callers_stream(domain, monkeypatch):
+    """the caller may run steric() with a stream of its own current: uploads (worker thread, copy
+    stream), kernels (the caller's stream) and downloads order themselves against THAT stream"""
+    from momlevel_amd import engine
+
+    d = _masked_dataset(nt=7)
+    base, _ = steric(d, domain=domain)
+    monkeypatch.setattr(engine, "chunk_steps", lambda nt, b, dev, budget_bytes=None: 2)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        res, _ = steric(d, domain=domain)
+    side.synchronize()
+    assert_bit_equal(res["steric"].values, base["steric"].values)
+    if domain == "local":
+        assert_bit_equal(res["delta_rho"].values, base["delta_rho"].values)
+
+
 def test_time_chunks_stop_early_without_hanging(monkeypatch):
     """a consumer that leaves the chunk loop early (an exception of its own, a `return`) shuts the
     upload worker down with the generator"""
