@@ -901,8 +901,12 @@ constexpr int kTChunkHeld = 64;      // held-field variants and the all-variants
                                      // held field are re-read once per chunk -- at 8 B/cell that is
                                      // 10 % extra traffic with 32-step chunks; 64..120 steps measured
                                      // 1-3.5 % faster (profiles/r02_tune_tchunk.log), steric is flat
-constexpr int kNTI64 = 16;           // time steps per K2 thread, f64 (2 columns/thread)
-constexpr int kNTI32 = 8;            // f32 (4 columns/thread)
+constexpr int kNTI64 = 16;           // time steps per K2 thread, f64 (2 columns/thread); 8, 10
+                                     // (3 waves/SIMD) and 12 re-measured in round 3: within noise
+                                     // (profiles/r03_tune_k2_nti64_*.log)
+constexpr int kNTI32 = 6;            // f32 (4 columns/thread): 154 VGPRs = 3 waves/SIMD; 8 steps
+                                     // (186 VGPRs, 2 waves) measured 6 % slower on the eta-only pass,
+                                     // 4 steps slower with delta_rho (profiles/r03_tune_k2_nti32_*.log)
 constexpr int kNTIGen = 8;           // generic scalar path
 
 constexpr int kKnownFlags = MLX_FLAG_SKIP_DRY | MLX_FLAG_FMA | MLX_FLAG_TCHUNK_MASK;
