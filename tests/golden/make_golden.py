@@ -118,6 +118,28 @@ def main():
     out["lin_scalar_out"] = np.array([lin.density(18.0, 35.0), lin.drho_dtemp(), lin.drho_dsal(),
                                       lin.alpha(18.0, 35.0, None), lin.beta(18.0, 35.0, None)])
 
+    # (7) round 3: operands no ocean produces -- huge, tiny, infinite, cancelling -- next to ordinary
+    # ones, float64 and float32, with a pressure profile of 2e5 / 1e300 / 1e-300 Pa: what the
+    # REFERENCE returns there (inf, 0, NaN included) pins the fallback of the kernels' guarded
+    # reciprocal (eos_device.hpp) to momlevel itself, not only to the oracle
+    r = np.random.default_rng(23)
+    nt, nz, ny, nx = 2, 3, 8, 64
+    for tag, dtype, big, tiny in (("f64", np.float64, 1e150, 1e-300), ("f32", np.float32, 3e38, 1e-44)):
+        T = r.uniform(-2, 32, (nt, nz, ny, nx))
+        S = r.uniform(30, 40, (nt, nz, ny, nx))
+        weird = [big, -big, big * 1e-3, tiny, 0.0, np.inf, -974.2, 740.54, 1e30, -1e30]
+        for i, w in enumerate(weird):
+            T[i % nt, i % nz, i % ny, 3 + 5 * i] = w
+            S[(i + 1) % nt, i % nz, (i + 3) % ny, 7 + 5 * i] = w
+            T[0, (i + 1) % nz, (i + 5) % ny, 11 + 5 * i] = w
+            S[0, (i + 1) % nz, (i + 5) % ny, 11 + 5 * i] = -w
+        T, S = T.astype(dtype), S.astype(dtype)
+        out[f"patho_{tag}_T"], out[f"patho_{tag}_S"] = T, S
+        with np.errstate(all="ignore"):
+            out[f"patho_{tag}_density"] = ref.density(T, S, np.array([2.0e5, 1.0e300, 1.0e-300])[:, None, None])
+        assert out[f"patho_{tag}_density"].dtype == np.float64
+    out["patho_p"] = np.array([2.0e5, 1.0e300, 1.0e-300])
+
     # scalars of tests/test_wright.py:11-12,30-31,50-51,70-71,120-121
     out["scalar_args"] = np.array([18.0, 35.0, 200000.0])
     out["scalar_out"] = np.array(

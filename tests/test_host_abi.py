@@ -59,6 +59,15 @@ def test_float32_mixed_precision_and_held_fields(wright_vectors, func):
                                               v["blk_p"]))
 
 
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_pathological_operands_through_the_host_build(wright_vectors, prec):
+    """huge / tiny / infinite operands and pressures of 1e300 / 1e-300: the reference module's own
+    outputs (inf, 0, NaN included), bit for bit"""
+    v = wright_vectors
+    got = h.eos_map(v[f"patho_{prec}_T"], v[f"patho_{prec}_S"], v["patho_p"])
+    assert_bit_equal(got, v[f"patho_{prec}_density"], f"host, pathological operands, {prec}")
+
+
 @pytest.mark.parametrize("func", ["density", "alpha", "beta", "drho_dtemp", "drho_dsal"])
 def test_linear_eos_bit_identical_to_reference_vectors(wright_vectors, func):
     v = wright_vectors
