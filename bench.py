@@ -44,7 +44,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-from momlevel_amd import core, engine, parallel, synthetic  # noqa: E402
+from momlevel_amd import core, engine, hostio, parallel, synthetic  # noqa: E402
 
 # BASELINE.json's metric string, verbatim
 METRIC = "Mcells/s for fused Wright-EOS+steric at 1440\u00d71080\u00d775; % HBM roofline"
@@ -147,8 +147,8 @@ def cpu_baseline(T, S, g, pres, target_s, gpu_masso):
     vol = g["volcello"]
     spent, slabs, err, done = 0.0, 0, 0.0, []
     for t in parity_slabs(T.shape[0])[:8]:
-        Tn = T[t].cpu().numpy()
-        Sn = S[t].cpu().numpy()
+        Tn = hostio.to_host(T[t])  # (page-locked download: no GPU mapping of malloc'ed memory)
+        Sn = hostio.to_host(S[t])
         t0 = time.perf_counter()
         rho = o.calc_rho(Tn, Sn, pres)
         m = o.calc_masso(rho, vol)
@@ -246,10 +246,10 @@ def cpu_baseline_fused(T, S, g, pres, gpu_masso, slabs=2):
         return None
     wright_c.set_threads(min(16, os.cpu_count() or 1))  # the 1-GPU box's CPU share is 16 cores
     vol = g["volcello"]
-    wright_c.masso_slab(T[0].cpu().numpy(), S[0].cpu().numpy(), vol, pres)  # warm the thread pool
+    wright_c.masso_slab(hostio.to_host(T[0]), hostio.to_host(S[0]), vol, pres)  # warm the thread pool
     spent, err = 0.0, 0.0
     for t in range(min(slabs, T.shape[0])):
-        Tn, Sn = T[t].cpu().numpy(), S[t].cpu().numpy()
+        Tn, Sn = hostio.to_host(T[t]), hostio.to_host(S[t])
         t0 = time.perf_counter()
         m = wright_c.masso_slab(Tn, Sn, vol, pres)
         spent += time.perf_counter() - t0
@@ -296,8 +296,8 @@ def main():
         nt = int(allreduce_scalar(nt, dist.ReduceOp.MIN, torch.int64))
     shrunk = nt < nt_req  # free HBM did not hold the requested record: said so in the JSON line
 
-    vol0 = torch.from_numpy(g["volcello"]).to(dev)
-    area = torch.from_numpy(g["areacello"]).to(dev)
+    vol0 = hostio.to_device(g["volcello"], dev)  # (through page-locked staging, like the product)
+    area = hostio.to_device(g["areacello"], dev)
     pres = torch.from_numpy(np.asarray(g["z_l"]) * 1.0e4 + 101325.0).to(dev)
     shape = (nt, nz, th, tw)
     kw = dict(seed=synthetic.SEED, mask3d=vol0, global_hw=(ny, nx), origin=g["origin"], device=dev)
@@ -532,8 +532,8 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
         "note": "same outputs bit for bit; not the headline: the metric counts dry cells as loaded",
     }
     rho0m = core.fold_mask(core.eos_map(T[0], S[0], pres), vol0)
-    zi = torch.from_numpy(g["z_i"]).to(dev)
-    dep = torch.from_numpy(g["deptho"]).to(dev)
+    zi = hostio.to_device(g["z_i"], dev)
+    dep = hostio.to_device(g["deptho"], dev)
     eta = torch.empty((nt, ny, nx), dtype=torch.float64, device=dev)
     ms = _time(lambda: core.steric_local(T, S, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=zi,
                                          deptho=dep, want_delta_rho=False, eta_out=eta,
@@ -698,8 +698,8 @@ def f32_timings(vol0, pres, g, dev, nt, synth_kw):
             r["steric"]["ms"] + r["thermosteric"]["ms"] + r["halosteric"]["ms"], 3)
         out[mode] = r
     rho0m = core.fold_mask(core.eos_map(T[0], S[0], pres), vol0)
-    zi = torch.from_numpy(g["z_i"]).to(dev)
-    dep = torch.from_numpy(g["deptho"]).to(dev)
+    zi = hostio.to_device(g["z_i"], dev)
+    dep = hostio.to_device(g["deptho"], dev)
     eta = torch.empty((nt, ny, nx), dtype=torch.float64, device=dev)
     for mode, kw in modes.items():
         out[mode]["local_eta_only"] = rate(_time(lambda: core.steric_local(
@@ -718,7 +718,7 @@ def f32_timings(vol0, pres, g, dev, nt, synth_kw):
                                            **modes["faithful_fused"])
     exact = core.steric_global_decomp(T, S, T[0], S[0], vol0, pres, skip_dry=False,
                                       **modes["faithful"])
-    Tn, Sn, T0n, S0n = (x.cpu().numpy() for x in (T[t], S[t], T[0], S[0]))
+    Tn, Sn, T0n, S0n = (hostio.to_host(x) for x in (T[t], S[t], T[0], S[0]))
     pn = pres.cpu().numpy()
     errs = {}
     for name, row, (a_, b_) in zip(("steric", "thermosteric", "halosteric"), rows.cpu().numpy(),

@@ -15,7 +15,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from momlevel_amd import core, synthetic  # noqa: E402
+from momlevel_amd import core, hostio, synthetic  # noqa: E402
 
 
 def main():
@@ -29,7 +29,7 @@ def main():
     nz, ny, nx = 75, 1080, 1440
     nt = a.nt
     g = synthetic.make_grid(ny, nx, nz)
-    vol0 = torch.from_numpy(g["volcello"]).cuda()
+    vol0 = hostio.to_device(g["volcello"], "cuda")
     pres = torch.from_numpy(np.asarray(g["z_l"]) * 1.0e4 + 101325.0).cuda()
     shape = (nt, nz, ny, nx)
     kw = dict(seed=synthetic.SEED, mask3d=vol0)
@@ -38,8 +38,8 @@ def main():
     S = core.synth_field(shape, td, field_id=2, lo=30.0, scale=10.0, **kw)
     rho0 = core.eos_map(T[0], S[0], pres)
     rho0m = core.fold_mask(rho0, vol0)
-    zi = torch.from_numpy(g["z_i"]).cuda()
-    dep = torch.from_numpy(g["deptho"]).cuda()
+    zi = hostio.to_device(g["z_i"], "cuda")
+    dep = hostio.to_device(g["deptho"], "cuda")
     drho = torch.empty(shape, dtype=torch.float64, device="cuda")
     eta = torch.empty((nt, ny, nx), dtype=torch.float64, device="cuda")
     d3 = torch.empty((3,) + shape, dtype=torch.float64, device="cuda")
