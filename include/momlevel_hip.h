@@ -38,10 +38,11 @@
 extern "C" {
 #endif
 
-#define MLX_ABI_VERSION 3 /* 2: mlx_eos_map takes flags; mlx_steric_global_decomp, mlx_steric_local_decomp,
+#define MLX_ABI_VERSION 4 /* 2: mlx_eos_map takes flags; mlx_steric_global_decomp, mlx_steric_local_decomp,
                              mlx_stream_probe;
                              MLX_FLAG_FMA, MLX_FLAG_TCHUNK; MLX_P_FULL4D in K1/K2
-                             3: mlx_build_kind; a NULL p (linear EOS) requires p_mode MLX_P_SCALAR */
+                             3: mlx_build_kind; a NULL p (linear EOS) requires p_mode MLX_P_SCALAR
+                             4: mlx_eos_map_promote (MLX_KIND_*) */
 
 /* argument-error codes (negative) */
 #define MLX_E_NULL     (-1) /* a required pointer is NULL                      */
@@ -127,6 +128,36 @@ int mlx_eos_map(const void *T, const void *S, int dtype,
                 int64_t nt, int64_t nz, int64_t plane,
                 int64_t t_stride_T, int64_t t_stride_S, int flags, /* 0 or MLX_FLAG_FMA (density) */
                 double *out, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * K0 for EVERY dtype combination numpy accepts.  The reference's EOS functions are bare numpy
+ * expressions (src/momlevel/eos/wright.py:44-48, 74-83, 108-117, 142, 165; eos/linear.py:44-46,
+ * 104, 124), so their sub-expressions take the dtypes numpy's promotion gives them (numpy >= 2,
+ * NEP 50): array (op) array -> the wider dtype; a python float takes the dtype of the array it
+ * meets.  mlx_eos_map covers float64 fields and float32 theta/S with a float64 pressure; this
+ * entry point covers the rest bit for bit -- a python-float or float32 pressure on float32 fields
+ * (the whole expression stays float32: derived.calc_pdens, src/momlevel/derived.py:477, on MOM6's
+ * float32 output), theta and salinity of different dtypes, python floats for theta or salinity.
+ *
+ * Each operand is n cells (stride 1) or one value used for every cell (stride 0) of kind
+ *   MLX_KIND_F64 / MLX_KIND_F32: a DEVICE pointer to float64 / float32 (numpy scalars count as
+ *                                arrays of their dtype);
+ *   MLX_KIND_WEAK:               a python float or int -- a HOST pointer to ONE double, read
+ *                                during the call; stride ignored.
+ * func: any MLX_FUNC_* (MLX_FUNC_IBH: out = p * (-1.0 / (rho * gravity)), dynamic.py:34-36, gravity a
+ * python float; ignored otherwise).  The linear EOS never reads p: it may be NULL there and takes no
+ * part in the promotion.  out is float64 storage of n cells holding numpy's values exactly;
+ * *out_kind (host, may be NULL) receives MLX_KIND_F32 when numpy's result dtype is float32 (every
+ * value is then a float32 value) and MLX_KIND_F64 otherwise.
+ * ------------------------------------------------------------------------------- */
+#define MLX_KIND_F64  0
+#define MLX_KIND_F32  1
+#define MLX_KIND_WEAK 2
+int mlx_eos_map_promote(const void *T, int kind_T, int64_t stride_T,
+                        const void *S, int kind_S, int64_t stride_S,
+                        const void *p, int kind_p, int64_t stride_p,
+                        int eos, int func, double gravity, int64_t n,
+                        double *out, int *out_kind, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * dynamic.inverse_barometer (src/momlevel/dynamic.py:34-36): out = p * (-1.0 / (rho(T,S,p) * gravity))

@@ -18,14 +18,15 @@ LIB_PATH = os.environ.get("MOMLEVEL_AMD_LIB") or os.path.join(HERE, "libmomlevel
 _ORACLE_DIR = os.path.join(os.path.dirname(HERE), "oracle")
 
 # ---- constants mirrored from include/momlevel_hip.h --------------------------------
-ABI_VERSION = 3
+ABI_VERSION = 4
 EOS_WRIGHT, EOS_LINEAR = 0, 1
-FUNC_DENSITY, FUNC_DRHO_DTEMP, FUNC_DRHO_DSAL, FUNC_ALPHA, FUNC_BETA = 0, 1, 2, 3, 4
+FUNC_DENSITY, FUNC_DRHO_DTEMP, FUNC_DRHO_DSAL, FUNC_ALPHA, FUNC_BETA, FUNC_IBH = 0, 1, 2, 3, 4, 5
 P_SCALAR, P_ZPROF, P_FULL3D, P_FULL4D = 0, 1, 2, 3
 DTYPE_F64, DTYPE_F32, DTYPE_F32_UPCAST = 0, 1, 2
 FLAG_SKIP_DRY = 1
 FLAG_FMA = 2
 BUILD_HIP, BUILD_HOST = 1, 2
+KIND_F64, KIND_F32, KIND_WEAK = 0, 1, 2  # operand kinds of mlx_eos_map_promote
 
 
 def flag_tchunk(steps):
@@ -57,6 +58,11 @@ SIGNATURES = {
     "mlx_eos_map": (
         _int,
         [_vp, _vp, _int, _vp, _int, _int, _int, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp],
+    ),
+    "mlx_eos_map_promote": (
+        _int,
+        [_vp, _int, _i64, _vp, _int, _i64, _vp, _int, _i64, _int, _int, _dbl, _i64, _vp,
+         ctypes.POINTER(ctypes.c_int), _vp],
     ),
     "mlx_inverse_barometer": (
         _int,

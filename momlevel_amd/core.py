@@ -216,6 +216,55 @@ def inverse_barometer(T, S, p, gravity=9.8, eos="wright", f32_mode="faithful"):
     return out[0] if squeeze else out
 
 
+def eos_map_promote(T, S, p, eos="wright", func="density", gravity=9.8):
+    """K0 under numpy's type promotion (mlx_eos_map_promote; csrc/eos_promote.hpp) for the dtype
+    combinations mlx_eos_map does not cover.  Each operand is a python float / int (a WEAK scalar:
+    it takes the dtype of the arrays it meets) or a float32 / float64 device tensor of n elements or
+    of ONE element (used for every cell); ``p`` may be None for the linear EOS.  ``func`` may also
+    be "inverse_barometer" (``gravity`` a python float).  Returns ``(out, is_f32)``: a float64
+    device tensor of n elements holding numpy's values exactly, and whether numpy's result dtype is
+    float32."""
+    import ctypes
+
+    require_device()
+    if p is None and (eos.lower() != "linear" or func == "inverse_barometer"):
+        raise TypeError("p must not be None (only the linear EOS ignores the pressure)")
+    tensors = [x for x in (T, S, p) if isinstance(x, torch.Tensor)]
+    if not tensors:
+        raise TypeError("at least one operand must be a device tensor")
+    device = tensors[0].device
+    n = max(int(x.numel()) for x in tensors)
+    keep, args = [], []
+    for name, x in (("T", T), ("S", S), ("p", p)):
+        if x is None:
+            if name != "p":
+                raise TypeError(f"{name} must not be None")
+            args += [None, _lib.KIND_WEAK, 0]
+        elif isinstance(x, torch.Tensor):
+            if not x.is_cuda or x.device != device:
+                raise ValueError("operands of one call must live on one GPU")
+            if x.dtype not in (torch.float32, torch.float64):
+                raise TypeError(f"{name} must be float32 or float64, not {x.dtype}")
+            if x.numel() not in (1, n):
+                raise ValueError(f"{name} has {x.numel()} elements, expected 1 or {n}")
+            x = x.contiguous()
+            keep.append(x)
+            args += [x.data_ptr(), _lib.KIND_F32 if x.dtype == torch.float32 else _lib.KIND_F64,
+                     1 if x.numel() == n and n > 1 else 0]
+        else:
+            w = ctypes.c_double(float(x))
+            keep.append(w)
+            args += [ctypes.addressof(w), _lib.KIND_WEAK, 0]
+    fid = _lib.FUNC_IBH if func == "inverse_barometer" else FUNC_IDS[func]
+    out = torch.empty(n, dtype=torch.float64, device=device)
+    kind = ctypes.c_int(-1)
+    with _on(device):
+        rc = _lib.load().mlx_eos_map_promote(*args, EOS_IDS[eos.lower()], fid, float(gravity), n,
+                                             _ptr(out), ctypes.byref(kind), _stream(device))
+    _lib.check(rc, "mlx_eos_map_promote")
+    return out, kind.value == _lib.KIND_F32
+
+
 def skip_dry_default():
     """Land / sub-bottom skipping is exact, so it is on unless MOMLEVEL_AMD_SKIP_DRY=0."""
     import os

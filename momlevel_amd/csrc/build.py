@@ -16,9 +16,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
-SOURCES = [os.path.join(HERE, "momlevel_hip.hip")]
+SOURCES = [os.path.join(HERE, "momlevel_hip.hip"), os.path.join(HERE, "momlevel_promote.hip")]
 DEPENDS = SOURCES + [
     os.path.join(HERE, "eos_device.hpp"),
+    os.path.join(HERE, "eos_promote.hpp"),
+    os.path.join(HERE, "mlx_internal.hpp"),
     os.path.join(ROOT, "include", "momlevel_hip.h"),
     os.path.abspath(__file__),
 ]

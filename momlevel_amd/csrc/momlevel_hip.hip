@@ -32,6 +32,7 @@
 
 #include "../../include/momlevel_hip.h"
 #include "eos_device.hpp"
+#include "mlx_internal.hpp"
 
 #pragma clang fp contract(off)
 
@@ -873,6 +874,15 @@ int hip_status(hipError_t e, const char* what) {
   snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
   return (int)e;
 }
+
+}  // namespace
+
+// the other translation units of the library (momlevel_promote.hip) report errors through the same
+// per-thread buffer
+int mlx::detail::fail(int code, const char* msg) { return ::fail(code, msg); }
+int mlx::detail::hip_status(hipError_t e, const char* what) { return ::hip_status(e, what); }
+
+namespace {
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 

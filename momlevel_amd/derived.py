@@ -52,16 +52,23 @@ def _apply_eos(func_name, thetao, so, pres, eos, eos_func=None):
     """xr.apply_ufunc(eos_func, thetao, so, pres) restated: broadcast by dim name."""
     if eos_func is None:
         eos_func = util.eos_func_from_str(eos, func_name=func_name)
-    args = [a if isinstance(a, DataArray) else DataArray(np.asarray(a, dtype=np.float64), ())
+    # python floats / ints stay python scalars (xr.apply_ufunc hands them through): numpy lets them
+    # take the dtype of the arrays they meet -- calc_pdens' pressure on float32 fields
+    weak = [isinstance(a, (bool, int, float)) and not isinstance(a, np.generic)
             for a in (thetao, so, pres)]
-    dims = _broadcast_dims(*args)
+    args = [a if (isinstance(a, DataArray) or w) else DataArray(np.asarray(a), ())
+            for a, w in zip((thetao, so, pres), weak)]
+    arrays = [a for a, w in zip(args, weak) if not w]
+    dims = _broadcast_dims(*arrays)
     sizes = {}
-    for a in args:
+    for a in arrays:
         sizes.update(a.sizes)
-    raw = [_expand_to(a, dims, sizes) for a in args]
+    raw = [a if w else _expand_to(a, dims, sizes) for a, w in zip(args, weak)]
     out = eos_func(*raw)
+    if not arrays:  # python scalars only: a 0-d result
+        return DataArray(np.asarray(out), ())
     coords = {}
-    for a in args:
+    for a in arrays:
         coords.update(a.coords)
     return DataArray(out, dims, {k: v for k, v in coords.items() if set(v.dims) <= set(dims)})
 

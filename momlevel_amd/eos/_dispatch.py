@@ -4,6 +4,13 @@ The reference's EOS functions are numpy ufunc expressions with numpy broadcastin
 (src/momlevel/eos/wright.py:23-165).  Here the same call signature routes to the
 HIP kernel: host arrays are uploaded, evaluated on the MI355X and copied back;
 device tensors stay on the device.  There is no host arithmetic fallback.
+
+Being numpy expressions, the reference's functions compute in whatever dtypes numpy's promotion
+gives their sub-expressions.  float64 fields, and float32 theta/S with a float64 pressure (the
+steric path), run on the tuned kernel (mlx_eos_map).  Every other combination -- a python-float or
+float32 pressure on float32 fields (calc_pdens on MOM6 output: the WHOLE expression is float32 and
+so is the result), theta and salinity of different dtypes, python floats for theta or salinity --
+runs on mlx_eos_map_promote, which restates the promotion rules exactly (csrc/eos_promote.hpp).
 """
 
 import numpy as np
@@ -21,27 +28,90 @@ def _as_tensor(x, device):
     return hostio.to_device(a, device)  # through our own page-locked staging
 
 
+def _is_weak(x):
+    """A python float / int: numpy (>= 2, NEP 50) lets it take the dtype of the arrays it meets.
+    numpy scalars (np.float32(1.0), np.float64(1.0)) are NOT weak: they count as arrays."""
+    return isinstance(x, (bool, int, float)) and not isinstance(x, np.generic)
+
+
+def _kind(x):
+    """"weak" | "f32" | "f64": how the operand enters numpy's promotion (None for a missing p).
+    Anything that is not float32 computes as float64 (integer arrays, float16)."""
+    if x is None:
+        return None
+    if _is_weak(x):
+        return "weak"
+    dt = x.dtype if isinstance(x, torch.Tensor) else np.asarray(x).dtype
+    return "f32" if str(dt) in ("torch.float32", "float32") else "f64"
+
+
+def _tuned_kernel_covers(kT, kS, kp, eos):
+    """mlx_eos_map computes float64 fields (any pressure: it widens exactly) and, for the Wright EOS,
+    float32 fields with a float64 pressure -- float64 out in both cases, as numpy.  Python floats
+    for BOTH fields are float64 arithmetic too.  (The linear EOS on float32 fields is float32
+    throughout in numpy, result included: the promote kernel.)"""
+    if kT == "weak" and kS == "weak":
+        return kp != "f32"
+    if kT == "f64" and kS == "f64":
+        return True
+    return eos != "linear" and kT == "f32" and kS == "f32" and kp == "f64"
+
+
 _HOST_CHUNK_ELEMS = 1 << 28  # 2 GiB of float64 per operand and chunk
 
 
 def _evaluate_host_chunked(eos, func, T, S, p, gravity):
     """Large host arrays: walk the leading axis of the broadcast shape in chunks so that the
     device never holds more than a few GiB (the result is a host array anyway)."""
-    arrs = [np.asarray(x) for x in (T, S, p if p is not None else 0.0)]
-    shape = np.broadcast_shapes(*(a.shape for a in arrs))
+    arrs = [x if _is_weak(x) else np.asarray(x) for x in (T, S, p if p is not None else 0.0)]
+    shape = np.broadcast_shapes(*(np.shape(a) for a in arrs))
     rows = max(1, _HOST_CHUNK_ELEMS // max(1, int(np.prod(shape[1:]))))
-    out = np.empty(shape, dtype=np.float64)
+    out = None
 
     def part(a, i0, i1):  # slice the leading axis unless the operand broadcasts along it
-        if a.ndim == len(shape) and a.shape[0] == shape[0] and shape[0] > 1:
+        if np.ndim(a) == len(shape) and a.shape[0] == shape[0] and shape[0] > 1:
             return a[i0:i1]
         return a
 
     for i0 in range(0, shape[0], rows):
         i1 = min(i0 + rows, shape[0])
-        out[i0:i1] = evaluate(eos, func, part(arrs[0], i0, i1), part(arrs[1], i0, i1),
-                              None if p is None else part(arrs[2], i0, i1), gravity=gravity)
+        res = evaluate(eos, func, part(arrs[0], i0, i1), part(arrs[1], i0, i1),
+                       None if p is None else part(arrs[2], i0, i1), gravity=gravity)
+        if out is None:
+            out = np.empty(shape, dtype=res.dtype)
+        out[i0:i1] = res
     return out
+
+
+def _evaluate_promoted(eos, func, T, S, p, gravity, device, on_device, scalar_in):
+    """The dtype combinations of numpy's promotion that the tuned kernel does not cover."""
+    ops, shapes = [], []
+    for x in (T, S, p):
+        if x is None or _is_weak(x):
+            ops.append(x)
+            continue
+        t = _as_tensor(x, device)
+        if t.dtype not in (torch.float32, torch.float64):
+            t = t.double()
+        ops.append(t)
+        shapes.append(tuple(t.shape))
+    shape = torch.broadcast_shapes(*shapes)
+    flat = []
+    for t in ops:
+        if isinstance(t, torch.Tensor):
+            t = t.reshape(1) if t.numel() == 1 else t.expand(shape).contiguous().reshape(-1)
+        flat.append(t)
+    out, is_f32 = core.eos_map_promote(flat[0], flat[1], flat[2], eos=eos, func=func,
+                                       gravity=9.8 if gravity is None else gravity)
+    out = out.reshape(shape)
+    if is_f32:
+        out = out.float()  # exact: every value is a float32 value
+    if on_device:
+        return out
+    res = hostio.to_host(out)
+    if scalar_in:
+        return res.dtype.type(res.reshape(()))
+    return res
 
 
 def evaluate(eos, func, T, S, p, gravity=None):
@@ -57,9 +127,9 @@ def evaluate(eos, func, T, S, p, gravity=None):
         (x.device for x in (T, S, p) if isinstance(x, torch.Tensor) and x.is_cuda),
         torch.device("cuda", torch.cuda.current_device()),
     )
+    if not _tuned_kernel_covers(_kind(T), _kind(S), _kind(p), eos):
+        return _evaluate_promoted(eos, func, T, S, p, gravity, device, on_device, scalar_in)
     Tt, St = _as_tensor(T, device), _as_tensor(S, device)
-    if Tt.dtype != St.dtype:  # mixed precision inputs: evaluate in float64
-        Tt, St = Tt.double(), St.double()
     pt = None if p is None else _as_tensor(p, device).double()
 
     shape = torch.broadcast_shapes(Tt.shape, St.shape, pt.shape if pt is not None else ())

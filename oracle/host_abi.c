@@ -36,6 +36,9 @@ static int fail(int code, const char *msg) {
   return code;
 }
 
+/* host_promote.cpp (mlx_eos_map_promote) reports through the same buffer */
+int mlxh_fail(int code, const char *msg) { return fail(code, msg); }
+
 /* ---- eos/wright.py:6-20 ------------------------------------------------------------------- */
 #define A0 7.057924e-4
 #define A1 3.480336e-7

@@ -20,7 +20,9 @@ F32_MODES = {"faithful": abi.DTYPE_F32, "upcast": abi.DTYPE_F32_UPCAST}
 
 
 def build(force=False):
-    deps = [os.path.join(HERE, "host_abi.c"), os.path.join(HERE, "..", "include", "momlevel_hip.h")]
+    deps = [os.path.join(HERE, "host_abi.c"), os.path.join(HERE, "host_promote.cpp"),
+            os.path.join(HERE, "..", "include", "momlevel_hip.h"),
+            os.path.join(HERE, "..", "momlevel_amd", "csrc", "eos_promote.hpp")]
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(map(os.path.getmtime, deps)):
         subprocess.run(["make", "-C", HERE, "-B", "libmomlevel_host.so"], check=True,
                        capture_output=True)
@@ -93,6 +95,33 @@ def eos_map(T, S, p, eos="wright", func="density", f32_mode="faithful"):
     _check(load().mlx_eos_map(_p(T), _p(S), dt, _p(pp), pm, abi.EOS_IDS[eos], abi.FUNC_IDS[func],
                               nt, nz, ny * nx, sT, sS, 0, _p(out), None), "mlx_eos_map")
     return out
+
+
+def eos_map_promote(T, S, p, eos="wright", func="density", gravity=9.8):
+    """mlx_eos_map_promote on host operands: python floats are weak scalars, float32 / float64
+    arrays of one common size (or one element) keep their dtype.  Returns numpy's values in
+    numpy's result dtype."""
+    keep, args, n = [], [], 1
+    for x in (T, S, p):
+        if x is None:
+            args += [None, abi.KIND_WEAK, 0]
+        elif isinstance(x, (bool, int, float)) and not isinstance(x, np.generic):
+            w = ctypes.c_double(float(x))
+            keep.append(w)
+            args += [ctypes.addressof(w), abi.KIND_WEAK, 0]
+        else:
+            a = np.ascontiguousarray(x)
+            assert a.dtype in _DT
+            keep.append(a)
+            n = max(n, a.size)
+            args += [a.ctypes.data, abi.KIND_F32 if a.dtype == np.float32 else abi.KIND_F64, a]
+    args = [(1 if (v.size == n and n > 1) else 0) if isinstance(v, np.ndarray) else v for v in args]
+    out = np.empty(n)
+    kind = ctypes.c_int(-1)
+    fid = abi.FUNC_IBH if func == "inverse_barometer" else abi.FUNC_IDS[func]
+    _check(load().mlx_eos_map_promote(*args, abi.EOS_IDS[eos], fid, float(gravity), n, _p(out),
+                                      ctypes.byref(kind), None), "mlx_eos_map_promote")
+    return out.astype(np.float32) if kind.value == abi.KIND_F32 else out
 
 
 def steric_global(T, S, vol0, p, eos="wright", f32_mode="faithful", flags=0):

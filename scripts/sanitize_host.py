@@ -3,7 +3,7 @@
 
     python scripts/sanitize_host.py [--iters N] [--keep]
 
-1. compiles momlevel_amd/csrc/momlevel_hip.hip with the HOST pass instrumented by
+1. compiles momlevel_amd/csrc/momlevel_hip.hip and momlevel_promote.hip with the HOST pass instrumented by
    AddressSanitizer + UndefinedBehaviorSanitizer (``-fsanitize=address,undefined
    -fno-gpu-sanitize``: the gfx950 device code is built as always and never instrumented -- GPU
    ASan is not available on this pool and is not used) into build/sanitize/libmomlevel_hip.so;
@@ -41,12 +41,14 @@ def main():
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     lib = os.path.join(OUT, "libmomlevel_hip.so")
-    src = os.path.join(ROOT, "momlevel_amd", "csrc", "momlevel_hip.hip")
-    deps = [src, os.path.join(ROOT, "momlevel_amd", "csrc", "eos_device.hpp"),
-            os.path.join(ROOT, "include", "momlevel_hip.h")]
+    csrc = os.path.join(ROOT, "momlevel_amd", "csrc")
+    srcs = [os.path.join(csrc, "momlevel_hip.hip"), os.path.join(csrc, "momlevel_promote.hip")]
+    deps = srcs + [os.path.join(csrc, "eos_device.hpp"), os.path.join(csrc, "eos_promote.hpp"),
+                   os.path.join(csrc, "mlx_internal.hpp"),
+                   os.path.join(ROOT, "include", "momlevel_hip.h"), os.path.abspath(__file__)]
     if not os.path.exists(lib) or os.path.getmtime(lib) < max(map(os.path.getmtime, deps)):
         run([hipcc(), "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
-             "-std=c++17"] + SAN + [src, "-o", lib], check=True)
+             "-std=c++17"] + SAN + srcs + ["-o", lib], check=True)
     exe = os.path.join(OUT, "abi_fuzz")
     run([hipcc(), "-std=c++17", "-x", "c++", "-D__HIP_PLATFORM_AMD__"] + SAN +
         [os.path.join(ROOT, "tests", "native", "abi_fuzz.cpp"), "-I/opt/rocm/include",

@@ -94,6 +94,21 @@ def steric_cases():
     return dict(np.load(os.path.join(GOLDEN, "steric_cases.npz")))
 
 
+MIX_KINDS = ["".join(k) for k in __import__("itertools").product("dfw", repeat=3) if k != ("w", "w", "w")]
+MIX_FUNCS = ["density", "drho_dtemp", "drho_dsal", "alpha", "beta", "lin_density", "lin_alpha", "lin_beta"]
+
+
+def mixed_operands(vectors, kinds):
+    """(T, S, p) of tests/golden/make_golden.py section (8) for a kinds string such as "ffw": d = the
+    float64 array, f = the same array as float32, w = a python float."""
+    ops = []
+    for i, (k, name) in enumerate(zip(kinds, "TSp")):
+        a = vectors[f"mix_{name}"]
+        ops.append(float(vectors["mix_weak"][i]) if k == "w"
+                   else a.astype(np.float32) if k == "f" else a)
+    return ops
+
+
 def assert_bit_equal(got, ref, what=""):
     """NaN placement identical; every finite value identical to the last bit."""
     got = np.asarray(got)

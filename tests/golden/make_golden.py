@@ -140,6 +140,34 @@ def main():
         assert out[f"patho_{tag}_density"].dtype == np.float64
     out["patho_p"] = np.array([2.0e5, 1.0e300, 1.0e-300])
 
+    # (8) round 3: every dtype combination numpy's promotion distinguishes.  Each of T, S, p is a
+    # float64 array (d), a float32 array (f) or a python float (w: a weak scalar that takes the
+    # dtype of the arrays it meets -- calc_pdens' pressure, derived.py:477); the REFERENCE's
+    # functions on all 26 combinations with at least one array.  Outputs keep the dtype numpy gave
+    # them (float32 where no float64 array takes part).  Pins csrc/eos_promote.hpp.
+    m = 512
+    out["mix_T"], out["mix_S"], out["mix_p"] = out["rnd_T"][:m], out["rnd_S"][:m], out["rnd_p"][:m]
+    out["mix_weak"] = np.array([11.25, 34.7, 2.0e7 + 101325.0])
+    import itertools
+
+    for kinds in itertools.product("dfw", repeat=3):
+        if kinds == ("w", "w", "w"):
+            continue
+        ops = []
+        for i, (k, name) in enumerate(zip(kinds, "TSp")):
+            a = out[f"mix_{name}"]
+            ops.append(float(out["mix_weak"][i]) if k == "w" else
+                       a.astype(np.float32) if k == "f" else a)
+        tag = "mix_" + "".join(kinds)
+        with np.errstate(all="ignore"):
+            for fn in ("density", "drho_dtemp", "drho_dsal", "alpha", "beta"):
+                out[f"{tag}_{fn}"] = np.asarray(getattr(ref, fn)(*ops))
+            out[f"{tag}_lin_density"] = np.asarray(lin.density(ops[0], ops[1]))
+            out[f"{tag}_lin_alpha"] = np.asarray(lin.alpha(ops[0], ops[1], None))
+            out[f"{tag}_lin_beta"] = np.asarray(lin.beta(ops[0], ops[1], None))
+    assert out["mix_ffw_density"].dtype == np.float32 and out["mix_fff_alpha"].dtype == np.float32
+    assert out["mix_fdd_density"].dtype == np.float64 and out["mix_wfd_density"].dtype == np.float64
+
     # scalars of tests/test_wright.py:11-12,30-31,50-51,70-71,120-121
     out["scalar_args"] = np.array([18.0, 35.0, 200000.0])
     out["scalar_out"] = np.array(

@@ -132,7 +132,7 @@ int main(int argc, char** argv) {
     // the products may overflow int64 for the extreme draws: computed unsigned, only as a hint
     const int64_t n3 = (int64_t)((uint64_t)nz * (uint64_t)plane);
     const int dtype = small_enum(), p_mode = small_enum(), eos = small_enum(), func = small_enum();
-    switch (rnd() % 12) {
+    switch (rnd() % 13) {
       case 0:
         check(mlx_eos_map(ptr(), ptr(), dtype, (const double*)ptr(), p_mode, eos, func, nt, nz,
                           plane, stride(n3), stride(n3), flagbits(), (double*)ptr(), nullptr),
@@ -185,6 +185,24 @@ int main(int argc, char** argv) {
                                       nullptr),
               "mlx_steric_local_decomp");
         break;
+      case 12: {
+        // a weak operand is a HOST pointer the call reads: a real double (or NULL), never a fake
+        static const double host_scalar = 101325.0;
+        int kinds[3];
+        const void* ops[3];
+        for (int k = 0; k < 3; ++k) {
+          kinds[k] = corrupt() ? (int)(rnd() % 9) - 3 : (int)(rnd() % 3);
+          ops[k] = (kinds[k] == MLX_KIND_WEAK) ? ((rnd() % 8) ? (const void*)&host_scalar : nullptr)
+                                               : (const void*)ptr();
+        }
+        int out_kind = -1;
+        check(mlx_eos_map_promote(ops[0], kinds[0], stride(1), ops[1], kinds[1], stride(1), ops[2],
+                                  kinds[2], stride(1), eos, corrupt() ? (int)(rnd() % 12) - 3 : (int)(rnd() % 6),
+                                  9.8, dim(), (double*)ptr(), (rnd() % 2) ? &out_kind : nullptr,
+                                  nullptr),
+              "mlx_eos_map_promote");
+        break;
+      }
       case 6: {
         const int64_t n = dim();
         check(mlx_nansum((const double*)ptr(), n, (double*)ptr(), ptr(),

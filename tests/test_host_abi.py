@@ -18,7 +18,7 @@ from momlevel_amd import _lib as abi
 from momlevel_amd import synthetic
 from oracle import host_abi as h
 from oracle import momlevel_numpy as o
-from conftest import assert_bit_equal, assert_rel
+from conftest import MIX_FUNCS, MIX_KINDS, mixed_operands, assert_bit_equal, assert_rel
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
