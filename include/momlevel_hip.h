@@ -42,7 +42,7 @@ extern "C" {
                              mlx_stream_probe;
                              MLX_FLAG_FMA, MLX_FLAG_TCHUNK; MLX_P_FULL4D in K1/K2
                              3: mlx_build_kind; a NULL p (linear EOS) requires p_mode MLX_P_SCALAR
-                             4: mlx_eos_map_promote (MLX_KIND_*) */
+                             4: mlx_eos_map_promote (MLX_KIND_*); MLX_DTYPE_T32_S64 / _T64_S32 in K1/K2 */
 
 /* argument-error codes (negative) */
 #define MLX_E_NULL     (-1) /* a required pointer is NULL                      */
@@ -74,6 +74,15 @@ extern "C" {
 #define MLX_DTYPE_F32 1 /* numpy mixed precision of the reference: al0,p0,lam rounded
                            in float32, the rest in float64        */
 #define MLX_DTYPE_F32_UPCAST 2 /* float32 storage, upcast to float64 before any math  */
+/* theta and salinity of DIFFERENT dtypes (a dataset whose variables were written with different
+ * precisions).  numpy then evaluates every sub-expression of eos/wright.py:44-46 that involves one
+ * field only in that field's precision and joins the two in float64; the steric entry points
+ * (mlx_steric_global*, mlx_steric_local*) reproduce that bit for bit, in exact arithmetic only
+ * (MLX_FLAG_FMA is refused).  T / T0 point at the first type, S / S0 at the second; strides are in
+ * elements of each field's own type.  The pointwise maps (mlx_eos_map, mlx_inverse_barometer) refuse
+ * these two: mlx_eos_map_promote covers every combination there. */
+#define MLX_DTYPE_T32_S64 3 /* theta float32, salinity float64 */
+#define MLX_DTYPE_T64_S32 4 /* theta float64, salinity float32 */
 
 /* flags of the fused steric entry points */
 #define MLX_FLAG_SKIP_DRY 1 /* do not load theta/S where the reference volcello (K1) / rho0m (K2)

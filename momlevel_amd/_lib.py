@@ -23,6 +23,7 @@ EOS_WRIGHT, EOS_LINEAR = 0, 1
 FUNC_DENSITY, FUNC_DRHO_DTEMP, FUNC_DRHO_DSAL, FUNC_ALPHA, FUNC_BETA, FUNC_IBH = 0, 1, 2, 3, 4, 5
 P_SCALAR, P_ZPROF, P_FULL3D, P_FULL4D = 0, 1, 2, 3
 DTYPE_F64, DTYPE_F32, DTYPE_F32_UPCAST = 0, 1, 2
+DTYPE_T32_S64, DTYPE_T64_S32 = 3, 4  # theta / salinity of different dtypes (K1 / K2 only)
 FLAG_SKIP_DRY = 1
 FLAG_FMA = 2
 BUILD_HIP, BUILD_HOST = 1, 2

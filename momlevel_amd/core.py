@@ -18,6 +18,8 @@ from ._lib import (
     DTYPE_F32,
     DTYPE_F32_UPCAST,
     DTYPE_F64,
+    DTYPE_T32_S64,
+    DTYPE_T64_S32,
     EOS_IDS,
     FUNC_IDS,
     P_FULL3D,
@@ -67,6 +69,13 @@ def arith_default(kernel="k0", dtype=None):
 
 
 def _arith_flag(arith, kernel="k0", dtype=None):
+    """``dtype``: the MLX_DTYPE_* code of the launch (or a torch dtype).  theta and salinity of
+    different dtypes have exact kernels only: the default policy and MOMLEVEL_AMD_ARITH fall back to
+    "exact" there, an explicit arith="fused" is an error."""
+    if dtype in (DTYPE_T32_S64, DTYPE_T64_S32):
+        if arith == "fused":
+            raise ValueError("arith='fused' is not available for thetao / so of different dtypes")
+        return 0
     if arith is None:
         arith = arith_default(kernel, dtype)
     try:
@@ -135,8 +144,12 @@ def _field(x, nz, ny, nx, name):
 
 def _pair(T, S, f32_mode):
     """Common shape logic of the (thetao, so) pair."""
-    if T.dtype != S.dtype:
-        raise TypeError("thetao and so must share a dtype")
+    for name, x in (("thetao", T), ("so", S)):
+        if x.dtype not in (torch.float32, torch.float64):
+            raise TypeError(f"{name} must be float64 or float32, got {x.dtype}")
+    mixed = T.dtype != S.dtype
+    if mixed and f32_mode != "faithful":  # "upcast": float64 arithmetic on the stored values
+        T, S, mixed = T.double(), S.double(), False
     if (isinstance(T, torch.Tensor) and isinstance(S, torch.Tensor) and T.is_cuda and S.is_cuda
             and T.device != S.device):
         raise ValueError(f"thetao is on {T.device} but so on {S.device}: operands of one call "
@@ -153,7 +166,13 @@ def _pair(T, S, f32_mode):
         nt = 1
     if nt == 0 or nz * ny * nx == 0:
         raise ValueError(f"empty field: shape {(nt, nz, ny, nx)} has no cells")
-    return T, S, nt, nz, ny, nx, sT, sS, _dtype_code(T, f32_mode), squeeze
+    if mixed:
+        # numpy evaluates each field's part of the polynomial in that field's precision and joins
+        # them in float64 (csrc/eos_device.hpp wright_density_mixed); exact kernels only
+        dt = DTYPE_T32_S64 if T.dtype == torch.float32 else DTYPE_T64_S32
+    else:
+        dt = _dtype_code(T, f32_mode)
+    return T, S, nt, nz, ny, nx, sT, sS, dt, squeeze
 
 
 def _pressure(p, nt, nz, ny, nx, device, allow4d):
@@ -188,9 +207,20 @@ def eos_map(T, S, p, eos="wright", func="density", f32_mode="faithful", arith=No
     density only."""
     require_device()
     T, S, nt, nz, ny, nx, sT, sS, dt, squeeze = _pair(T, S, f32_mode)
-    flags = (_arith_flag(arith, "k0", T.dtype)
-             if (func == "density" and eos.lower() == "wright") else 0)
     pt, p_mode = _pressure(p, nt, nz, ny, nx, T.device, allow4d=True)
+    if dt in (DTYPE_T32_S64, DTYPE_T64_S32):
+        # thetao and so of different dtypes: numpy's promotion per sub-expression is the promote
+        # kernel's job (one cell per thread over the broadcast operands)
+        full = (nt, nz, ny, nx)
+        ops = [(x if x.dim() == 4 else x.unsqueeze(0)).expand(full).reshape(-1) for x in (T, S)]
+        if pt is not None and pt.numel() > 1:
+            pt = {P_ZPROF: lambda q: q.reshape(1, nz, 1, 1), P_FULL3D: lambda q: q.reshape(1, nz, ny, nx),
+                  P_FULL4D: lambda q: q}[p_mode](pt).expand(full).reshape(-1)
+        out, _ = eos_map_promote(ops[0], ops[1], pt, eos=eos, func=func)
+        out = out.reshape(full)
+        return out[0] if squeeze else out
+    flags = (_arith_flag(arith, "k0", dt)
+             if (func == "density" and eos.lower() == "wright") else 0)
     out = torch.empty((nt, nz, ny, nx), dtype=torch.float64, device=T.device)
     with _on(T.device):
         rc = _lib.load().mlx_eos_map(
@@ -294,7 +324,7 @@ def steric_global_masso(T, S, vol0, p, eos="wright", f32_mode="faithful", events
     """
     require_device()
     T, S, nt, nz, ny, nx, sT, sS, dt, _ = _pair(T, S, f32_mode)
-    flags = _launch_flags(skip_dry, arith, t_chunk, "k1", T.dtype)
+    flags = _launch_flags(skip_dry, arith, t_chunk, "k1", dt)
     vol0 = _f64(vol0, T.device)
     if tuple(vol0.shape) != (nz, ny, nx):
         raise ValueError(f"vol0 has shape {tuple(vol0.shape)}, expected {(nz, ny, nx)}")
@@ -329,7 +359,7 @@ def steric_global_decomp(T, S, T0, S0, vol0, p, eos="wright", f32_mode="faithful
     bit-identical to three steric_global_masso calls."""
     require_device()
     T, S, nt, nz, ny, nx, sT, sS, dt, _ = _pair(T, S, f32_mode)
-    flags = _launch_flags(skip_dry, arith, t_chunk, "k1", T.dtype)
+    flags = _launch_flags(skip_dry, arith, t_chunk, "k1", dt)
     if T.dim() != 4 or S.dim() != 4:
         raise ValueError("steric_global_decomp streams both fields: thetao and so must be 4-D")
     dev = T.device
@@ -393,7 +423,7 @@ def steric_local(T, S, rho0m, vol0_surface, p, neg_inv_rhozero, dz=None, z_i=Non
     steric_global_masso.  ``p`` may be time dependent (4-D)."""
     require_device()
     T, S, nt, nz, ny, nx, sT, sS, dt, _ = _pair(T, S, f32_mode)
-    flags = _launch_flags(skip_dry, arith, 0, "k2", T.dtype)
+    flags = _launch_flags(skip_dry, arith, 0, "k2", dt)
     dev = T.device
     rho0m = _f64(rho0m, dev)
     vol0_surface = _f64(vol0_surface, dev)
@@ -440,7 +470,7 @@ def steric_local_decomp(T, S, T0, S0, rho0m, vol0_surface, p, neg_inv_rhozero, d
     tensors (or views whose variant axis has any stride, e.g. ``full[:, t0:t1]``)."""
     require_device()
     T, S, nt, nz, ny, nx, sT, sS, dt, _ = _pair(T, S, f32_mode)
-    flags = _launch_flags(skip_dry, arith, 0, "k2", T.dtype)
+    flags = _launch_flags(skip_dry, arith, 0, "k2", dt)
     if T.dim() != 4 or S.dim() != 4:
         raise ValueError("steric_local_decomp streams both fields: thetao and so must be 4-D")
     dev = T.device

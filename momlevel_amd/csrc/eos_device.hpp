@@ -14,6 +14,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #pragma clang fp contract(off)
 
 namespace mlx {
@@ -22,6 +24,15 @@ namespace mlx {
 constexpr int kF64 = 0;
 constexpr int kF32Faithful = 1;  // numpy's mixed precision for float32 theta/S
 constexpr int kF32Upcast = 2;    // upcast to float64 first
+// theta and salinity of DIFFERENT dtypes (generic kernels only).  numpy evaluates each part of the
+// polynomial in its own field's precision and promotes to float64 where the two meet: see
+// wright_density_mixed below
+constexpr int kMixT32 = 3;       // theta float32, salinity float64
+constexpr int kMixS32 = 4;       // theta float64, salinity float32
+template <int MODE>
+struct IsMixed {
+  static constexpr bool value = (MODE == kMixT32 || MODE == kMixS32);
+};
 
 constexpr int kWright = 0;
 constexpr int kLinear = 1;
@@ -505,12 +516,52 @@ __device__ __forceinline__ double linear_func(int func, TIn Tin, TIn Sin) {
   }
 }
 
+// ---- theta and salinity of different dtypes (MODE kMixT32 / kMixS32) ------------------------------
+// numpy's promotion on eos/wright.py:44-46 with one float32 and one float64 field: every
+// sub-expression that involves only ONE field and constants has that field's dtype -- these are
+// exactly the members of TPart / SPart -- and the sums and products that join the two are float64
+// (the float32 side widens exactly).  So: each part in its own precision, combine in float64.
+// The kernels hand both values over as doubles (the float32 field widened on load, exactly).
+template <typename R>
+__device__ __forceinline__ TPart<double> widen_part(const TPart<R>& a) {
+  return TPart<double>{(double)a.t, (double)a.a01, (double)a.tb, (double)a.tc};
+}
+template <typename R>
+__device__ __forceinline__ SPart<double> widen_part(const SPart<R>& b) {
+  return SPart<double>{(double)b.a2s, (double)b.b04, (double)b.b5s, (double)b.c04, (double)b.c5s};
+}
+template <int MODE>
+__device__ __forceinline__ double wright_density_mixed(double T, double S, double p) {
+  static_assert(IsMixed<MODE>::value, "mixed-dtype modes only");
+  typedef typename std::conditional<MODE == kMixT32, float, double>::type RT;
+  typedef typename std::conditional<MODE == kMixS32, float, double>::type RS;
+  const TPart<double> a = widen_part(t_part<ExactOps, RT>((RT)T));
+  const SPart<double> b = widen_part(s_part<ExactOps, RS>((RS)S, RS(0)));
+  return wright_combine<ExactOps, double>(a, b, p);
+}
+// eos/linear.py:55-56: 1000.0 + ((-0.2*T) + (0.8*S)); the products in their field's precision, the
+// sum of the two float64, and so is the rest
+template <int MODE>
+__device__ __forceinline__ double linear_density_mixed(double T, double S) {
+  static_assert(IsMixed<MODE>::value, "mixed-dtype modes only");
+  typedef typename std::conditional<MODE == kMixT32, float, double>::type RT;
+  typedef typename std::conditional<MODE == kMixS32, float, double>::type RS;
+  const double dt = (double)((RT)-0.2 * (RT)T), ds = (double)((RS)0.8 * (RS)S);
+  return 1000.0 + (dt + ds);
+}
+
 // runtime-dispatched EOS function (generic kernels; eos/func are wave-uniform)
 // Ops applies to the Wright DENSITY only (the one function on the steric path); the derivatives
 // and the linear EOS are always evaluated exactly.
 template <int MODE, typename TIn, typename Ops = ExactOps>
 __device__ __forceinline__ double eos_eval(int eos, int func, TIn T, TIn S, double p,
                                            double aux = 0.0) {
+  if constexpr (IsMixed<MODE>::value) {
+    // the steric kernels (K1 / K2) need the density only; the other functions of mixed-dtype
+    // operands are mlx_eos_map_promote's (eos_promote.hpp)
+    return (eos == kLinear) ? linear_density_mixed<MODE>((double)T, (double)S)
+                            : wright_density_mixed<MODE>((double)T, (double)S, p);
+  } else {
   if (func == kIbh) {  // pso * (-1.0 / (rho_conv * gravity))
     const double rho = (eos == kLinear) ? linear_density<MODE, TIn>(T, S)
                                         : wright_density<MODE, TIn>(T, S, p);
@@ -542,6 +593,7 @@ __device__ __forceinline__ double eos_eval(int eos, int func, TIn T, TIn S, doub
         return wright_drho_dsal((double)T, (double)S, p) /
                wright_density<kF64, double>((double)T, (double)S, p);
   }
+  }  // not mixed
 }
 
 __device__ __forceinline__ bool is_nan(double x) { return x != x; }

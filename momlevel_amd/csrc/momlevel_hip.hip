@@ -84,6 +84,24 @@ __device__ __forceinline__ Pack<TIn, VEC> load_pack(const TIn* __restrict__ p) {
   return r;
 }
 
+// theta / salinity loads at element offset `off`.  In the mixed-dtype modes (generic kernels only,
+// TIn = double) ONE of the two fields is float32 in memory: it is read as float and widened
+// (exact), so the kernel body sees doubles holding float32 values and eos_eval<kMix*> narrows them
+// back (exact) for that field's float32 part of the polynomial.
+template <int MODE, bool IS_T, typename TIn, int VEC, bool STREAM = false>
+__device__ __forceinline__ Pack<TIn, VEC> load_field(const TIn* __restrict__ base, int64_t off) {
+  constexpr bool F32_HERE = (MODE == kMixT32 && IS_T) || (MODE == kMixS32 && !IS_T);
+  if constexpr (F32_HERE) {
+    static_assert(VEC == 1 && sizeof(TIn) == 8, "mixed dtypes run on the generic kernels");
+    Pack<TIn, VEC> r;
+    if constexpr (STREAM) r.v[0] = __builtin_nontemporal_load(reinterpret_cast<const float*>(base) + off);
+    else r.v[0] = reinterpret_cast<const float*>(base)[off];
+    return r;
+  } else {
+    return load_pack<TIn, VEC, STREAM>(base + off);
+  }
+}
+
 // XCD-aware tile index: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share
 // one), so give the blocks that share an XCD one contiguous eighth of the row of tiles.
 // Bijective for any n (cdna_hip_programming.md T1); speed only, never correctness.
@@ -225,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       Pack<TIn, VEC> h = {};
-      if (alive[u]) h = load_pack<TIn, VEC, true>(T0 + off[u]);
+      if (alive[u]) h = load_field<MODE, true, TIn, VEC, true>(T0, off[u]);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         if constexpr (GENERIC) t0v[u][k] = h.v[k];
@@ -240,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       Pack<TIn, VEC> h = {};
-      if (alive[u]) h = load_pack<TIn, VEC, true>(S0 + off[u]);
+      if (alive[u]) h = load_field<MODE, false, TIn, VEC, true>(S0, off[u]);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         if constexpr (GENERIC) s0v[u][k] = h.v[k];
@@ -263,8 +281,8 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
     nxtT[u] = {};
     nxtS[u] = {};
     if (alive[u]) {
-      if (STREAM_T) nxtT[u] = load_pack<TIn, VEC, true>(T + (int64_t)tb * t_stride_T + off[u]);
-      if (STREAM_S) nxtS[u] = load_pack<TIn, VEC, true>(S + (int64_t)tb * t_stride_S + off[u]);
+      if (STREAM_T) nxtT[u] = load_field<MODE, true, TIn, VEC, true>(T, (int64_t)tb * t_stride_T + off[u]);
+      if (STREAM_S) nxtS[u] = load_field<MODE, false, TIn, VEC, true>(S, (int64_t)tb * t_stride_S + off[u]);
     }
   }
 
@@ -275,8 +293,8 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
         curT[u] = {};
         curS[u] = {};
         if (alive[u]) {
-          if (STREAM_T) curT[u] = load_pack<TIn, VEC, true>(T + (int64_t)t * t_stride_T + off[u]);
-          if (STREAM_S) curS[u] = load_pack<TIn, VEC, true>(S + (int64_t)t * t_stride_S + off[u]);
+          if (STREAM_T) curT[u] = load_field<MODE, true, TIn, VEC, true>(T, (int64_t)t * t_stride_T + off[u]);
+          if (STREAM_S) curS[u] = load_field<MODE, false, TIn, VEC, true>(S, (int64_t)t * t_stride_S + off[u]);
         }
       }
     }
@@ -290,9 +308,9 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
       for (int u = 0; u < U; ++u) {
         if (alive[u]) {
           if (STREAM_T)
-            nxtT[u] = load_pack<TIn, VEC, true>(T + (int64_t)(t + 1) * t_stride_T + off[u]);
+            nxtT[u] = load_field<MODE, true, TIn, VEC, true>(T, (int64_t)(t + 1) * t_stride_T + off[u]);
           if (STREAM_S)
-            nxtS[u] = load_pack<TIn, VEC, true>(S + (int64_t)(t + 1) * t_stride_S + off[u]);
+            nxtS[u] = load_field<MODE, false, TIn, VEC, true>(S, (int64_t)(t + 1) * t_stride_S + off[u]);
         }
       }
     }
@@ -659,8 +677,8 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
     // evaluated once for the NTI time steps (eos_device.hpp TPart/SPart)
     Pack<TIn, VEC> hT = {}, hS = {};
     if (alive) {
-      if (HELD_T) hT = load_pack<TIn, VEC>((VAR == kVarAll ? T0 : T) + off);
-      if (HELD_S) hS = load_pack<TIn, VEC>((VAR == kVarAll ? S0 : S) + off);
+      if (HELD_T) hT = load_field<MODE, true, TIn, VEC>(VAR == kVarAll ? T0 : T, off);
+      if (HELD_S) hS = load_field<MODE, false, TIn, VEC>(VAR == kVarAll ? S0 : S, off);
     }
     RV pfold = RV{};
     if constexpr (Ops::fused) pfold = (R)pz;
@@ -682,8 +700,8 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
       b[j] = {};
       if (alive && t0 + j < nt) {  // the ragged last chunk issues no surplus loads
         const int64_t t = t0 + j;
-        if (STREAM_T) a[j] = load_pack<TIn, VEC, true>(T + t * t_stride_T + off);
-        if (STREAM_S) b[j] = load_pack<TIn, VEC, true>(S + t * t_stride_S + off);
+        if (STREAM_T) a[j] = load_field<MODE, true, TIn, VEC, true>(T, t * t_stride_T + off);
+        if (STREAM_S) b[j] = load_field<MODE, false, TIn, VEC, true>(S, t * t_stride_S + off);
       }
     }
 #pragma unroll
@@ -921,16 +939,35 @@ constexpr int kNTIGen = 8;           // generic scalar path
 
 constexpr int kKnownFlags = MLX_FLAG_SKIP_DRY | MLX_FLAG_FMA | MLX_FLAG_TCHUNK_MASK;
 
-int check_dtype(int dtype) {
+inline bool mixed_dtype(int dtype) {
+  return dtype == MLX_DTYPE_T32_S64 || dtype == MLX_DTYPE_T64_S32;
+}
+// element size of theta (is_T) / salinity in memory
+inline size_t elem_size(int dtype, bool is_T) {
+  if (dtype == MLX_DTYPE_F64) return 8;
+  if (dtype == MLX_DTYPE_T32_S64) return is_T ? 4 : 8;
+  if (dtype == MLX_DTYPE_T64_S32) return is_T ? 8 : 4;
+  return 4;
+}
+
+// `mixed_ok`: the steric kernels (K1 / K2) take theta and salinity of different dtypes; the
+// pointwise maps do not (mlx_eos_map_promote covers every combination there)
+int check_dtype(int dtype, bool mixed_ok) {
+  if (mixed_dtype(dtype)) {
+    if (!mixed_ok)
+      return fail(MLX_E_ENUM, "theta/salinity of different dtypes: use mlx_eos_map_promote");
+    return 0;
+  }
   if (dtype != MLX_DTYPE_F64 && dtype != MLX_DTYPE_F32 && dtype != MLX_DTYPE_F32_UPCAST)
-    return fail(MLX_E_ENUM, "dtype must be MLX_DTYPE_F64, _F32 or _F32_UPCAST");
+    return fail(MLX_E_ENUM, "dtype must be one of MLX_DTYPE_*");
   return 0;
 }
 
 int check_common(const void* T, const void* S, int dtype, const double* p, int p_mode, int eos,
-                 int64_t nt, int64_t nz, int64_t plane, int64_t sT, int64_t sS) {
+                 int64_t nt, int64_t nz, int64_t plane, int64_t sT, int64_t sS,
+                 bool mixed_ok = false) {
   if (!T || !S) return fail(MLX_E_NULL, "T and S must not be NULL");
-  if (int rc = check_dtype(dtype)) return rc;
+  if (int rc = check_dtype(dtype, mixed_ok)) return rc;
   if (eos != MLX_EOS_WRIGHT && eos != MLX_EOS_LINEAR) return fail(MLX_E_ENUM, "unknown eos");
   if (p_mode < MLX_P_SCALAR || p_mode > MLX_P_FULL4D) return fail(MLX_E_ENUM, "unknown p_mode");
   if (!p && eos == MLX_EOS_WRIGHT) return fail(MLX_E_NULL, "p must not be NULL for the Wright EOS");
@@ -947,8 +984,8 @@ int check_common(const void* T, const void* S, int dtype, const double* p, int p
     int64_t span;
     if (!mul_fits(nt - 1, sT > sS ? sT : sS, &span)) return fail(MLX_E_SHAPE, "time stride too large");
   }
-  const size_t es = (dtype == MLX_DTYPE_F64) ? 8 : 4;
-  if (!aligned(T, es) || !aligned(S, es)) return fail(MLX_E_ALIGN, "T/S not element-aligned");
+  if (!aligned(T, elem_size(dtype, true)) || !aligned(S, elem_size(dtype, false)))
+    return fail(MLX_E_ALIGN, "T/S not element-aligned");
   if (p && !aligned(p, 8)) return fail(MLX_E_ALIGN, "p not 8-byte aligned");
   return 0;
 }
@@ -960,6 +997,7 @@ inline int vec_of(int dtype) { return (dtype == MLX_DTYPE_F64) ? kVec64 : kVec32
 bool fast_layout(int dtype, int p_mode, int eos, int64_t plane, int64_t sT, int64_t sS,
                  std::initializer_list<const void*> ptrs) {
   const int vec = vec_of(dtype);
+  if (mixed_dtype(dtype)) return false;  // scalar loads of two element sizes: the generic twin
   if (eos != MLX_EOS_WRIGHT || p_mode != MLX_P_ZPROF) return false;
   if (plane % vec || sT % vec || sS % vec) return false;
   for (const void* q : ptrs)
@@ -991,7 +1029,9 @@ template <typename TIn, int VEC, int U, int VAR, int MODE, bool GEN>
 void k1_flags(const K1Args& a, bool skip, bool fma) {
   constexpr int FM = MODE;   // (faithful float32 keeps its float32 polynomial under MLX_FLAG_FMA)
   constexpr bool S1 = !GEN;  // the generic twin has no skipping instantiation
-  if (fma) {
+  if constexpr (IsMixed<MODE>::value) {  // exact arithmetic only (the entry points refuse the flag)
+    k1_go<TIn, VEC, U, VAR, MODE, GEN, false, false>(a);
+  } else if (fma) {
     if (skip && S1) k1_go<TIn, VEC, U, VAR, FM, GEN, S1, true>(a);
     else k1_go<TIn, VEC, U, VAR, FM, GEN, false, true>(a);
   } else {
@@ -1023,6 +1063,8 @@ void k1_dispatch(const K1Args& a, int dtype, bool fast, int var, bool skip, bool
   } else {
     if (dtype == MLX_DTYPE_F64) k1_var<double, 1, kUGen, kF64, true>(a, var, skip, fma);
     else if (dtype == MLX_DTYPE_F32) k1_var<float, 1, kUGen, kF32Faithful, true>(a, var, skip, fma);
+    else if (dtype == MLX_DTYPE_T32_S64) k1_var<double, 1, kUGen, kMixT32, true>(a, var, skip, fma);
+    else if (dtype == MLX_DTYPE_T64_S32) k1_var<double, 1, kUGen, kMixS32, true>(a, var, skip, fma);
     else k1_var<float, 1, kUGen, kF32Upcast, true>(a, var, skip, fma);
   }
 }
@@ -1048,13 +1090,15 @@ int steric_global_impl(const void* T, const void* S, const void* T0, const void*
                        const char* name) {
   const int nout = (var == kVarAll) ? 4 : 1;
   if (flags & ~kKnownFlags) return fail(MLX_E_ENUM, "unknown flag bits");
-  if (int rc = check_common(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS)) return rc;
+  if (int rc = check_common(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS, true)) return rc;
+  if (mixed_dtype(dtype) && (flags & MLX_FLAG_FMA))
+    return fail(MLX_E_ENUM, "MLX_FLAG_FMA is not available for theta/salinity of different dtypes");
   if (!vol0 || !out) return fail(MLX_E_NULL, "vol0 and the output must not be NULL");
   if (!aligned(vol0, 8) || !aligned(out, 8)) return fail(MLX_E_ALIGN, "vol0/out not 8-byte aligned");
   if (var == kVarAll) {
     if (!T0 || !S0) return fail(MLX_E_NULL, "T0 and S0 must not be NULL");
-    const size_t es = (dtype == MLX_DTYPE_F64) ? 8 : 4;
-    if (!aligned(T0, es) || !aligned(S0, es)) return fail(MLX_E_ALIGN, "T0/S0 not element-aligned");
+    if (!aligned(T0, elem_size(dtype, true)) || !aligned(S0, elem_size(dtype, false)))
+      return fail(MLX_E_ALIGN, "T0/S0 not element-aligned");
   }
   if (!workspace) return fail(MLX_E_NULL, "workspace must not be NULL");
   const size_t need = (size_t)nout * mlx_steric_global_workspace_bytes(nt, nz, plane);
@@ -1112,7 +1156,9 @@ template <typename TIn, int VEC, int NTI, int VAR, int MODE, bool GEN>
 void k2_flags(const K2Args& a, bool skip, bool fma) {
   constexpr int FM = MODE;
   constexpr bool S1 = !GEN;
-  if (fma) {
+  if constexpr (IsMixed<MODE>::value) {  // exact arithmetic only
+    k2_go<TIn, VEC, NTI, VAR, MODE, GEN, false, false>(a);
+  } else if (fma) {
     if (skip && S1) k2_go<TIn, VEC, NTI, VAR, FM, GEN, S1, true>(a);
     else k2_go<TIn, VEC, NTI, VAR, FM, GEN, false, true>(a);
   } else {
@@ -1150,7 +1196,9 @@ int steric_local_impl(const void* T, const void* S, const void* T0, const void* 
                       double* eta_out, int64_t eta_vstride, void* stream) {
   if (flags & ~(MLX_FLAG_SKIP_DRY | MLX_FLAG_FMA)) return fail(MLX_E_ENUM, "unknown flag bits");
   const bool skip = (flags & MLX_FLAG_SKIP_DRY) != 0, fma = (flags & MLX_FLAG_FMA) != 0;
-  if (int rc = check_common(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS)) return rc;
+  if (int rc = check_common(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS, true)) return rc;
+  if (mixed_dtype(dtype) && fma)
+    return fail(MLX_E_ENUM, "MLX_FLAG_FMA is not available for theta/salinity of different dtypes");
   if (!rho0m || !vol0_surface || !eta_out)
     return fail(MLX_E_NULL, "rho0m, vol0_surface and eta_out must not be NULL");
   if (!dz && (!z_i || !deptho))
@@ -1161,8 +1209,8 @@ int steric_local_impl(const void* T, const void* S, const void* T0, const void* 
     if (q && !aligned(q, 8)) return fail(MLX_E_ALIGN, "operands not 8-byte aligned");
   if (var == kVarAll) {
     if (!T0 || !S0) return fail(MLX_E_NULL, "T0 and S0 must not be NULL");
-    const size_t es = (dtype == MLX_DTYPE_F64) ? 8 : 4;
-    if (!aligned(T0, es) || !aligned(S0, es)) return fail(MLX_E_ALIGN, "T0/S0 not element-aligned");
+    if (!aligned(T0, elem_size(dtype, true)) || !aligned(S0, elem_size(dtype, false)))
+      return fail(MLX_E_ALIGN, "T0/S0 not element-aligned");
     int64_t n3, n4;
     if (!mul_fits(nz, plane, &n3) || !mul_fits(nt, n3, &n4)) return fail(MLX_E_SHAPE, "overflow");
     if (eta_vstride < nt * plane || (delta_rho_out && drho_vstride < n4))
@@ -1207,6 +1255,10 @@ int steric_local_impl(const void* T, const void* S, const void* T0, const void* 
     if (f64) k2_var<double, 1, kNTIGen, 1, kNTIGenAll, kF64, true>(a, var, skip, fma);
     else if (dtype == MLX_DTYPE_F32)
       k2_var<float, 1, kNTIGen, 1, kNTIGenAll, kF32Faithful, true>(a, var, skip, fma);
+    else if (dtype == MLX_DTYPE_T32_S64)
+      k2_var<double, 1, kNTIGen, 1, kNTIGenAll, kMixT32, true>(a, var, skip, fma);
+    else if (dtype == MLX_DTYPE_T64_S32)
+      k2_var<double, 1, kNTIGen, 1, kNTIGenAll, kMixS32, true>(a, var, skip, fma);
     else k2_var<float, 1, kNTIGen, 1, kNTIGenAll, kF32Upcast, true>(a, var, skip, fma);
   }
   return hip_status(hipGetLastError(), "k_steric_local launch");
@@ -1492,7 +1544,7 @@ int mlx_synth_field(void* out, int dtype, int64_t nt, int64_t nz, int64_t ny, in
       return fail(MLX_E_SHAPE, "global index overflows");
   }
   if (field_id < 0 || field_id > 15) return fail(MLX_E_ENUM, "field_id must be 0..15");
-  if (int rc = check_dtype(dtype)) return rc;
+  if (int rc = check_dtype(dtype, false)) return rc;
   if (!aligned(out, dtype == MLX_DTYPE_F64 ? 8 : 4) || (mask3d && !aligned(mask3d, 8)))
     return fail(MLX_E_ALIGN, "out/mask3d not element-aligned");
   const int64_t n = nt * nz * ny * nx;  // <= the global counter checked above

@@ -76,6 +76,12 @@ static inline double rho_from_terms(double al0, double p0, double lam, double p)
 
 /* one theta/S value of either storage type */
 typedef struct { double d; float f; int is_f32_faithful; } Val;
+/* dtype of ONE field (theta: is_T) for a MLX_DTYPE_* code; the mixed codes give each field its own */
+static inline int field_dtype(int dtype, int is_T) {
+  if (dtype == MLX_DTYPE_T32_S64) return is_T ? MLX_DTYPE_F32 : MLX_DTYPE_F64;
+  if (dtype == MLX_DTYPE_T64_S32) return is_T ? MLX_DTYPE_F64 : MLX_DTYPE_F32;
+  return dtype;
+}
 static inline Val load(const void *base, int64_t i, int dtype) {
   Val v;
   if (dtype == MLX_DTYPE_F64) { v.d = ((const double *)base)[i]; v.f = 0.0f; v.is_f32_faithful = 0; }
@@ -83,7 +89,39 @@ static inline Val load(const void *base, int64_t i, int dtype) {
   return v;
 }
 
+/* theta and salinity of different dtypes (MLX_DTYPE_T32_S64 / _T64_S32): numpy keeps every
+ * sub-expression of eos/wright.py:44-46 that involves ONE field in that field's dtype and joins the
+ * two in float64 */
+static inline double density_mixed(Val T, Val S, double p) {
+  double a01, tb, tc, a2s, b04, b5s, c04, c5s;
+  if (T.is_f32_faithful) {
+    a01 = (double)((float)A0 + (float)A1 * T.f);
+    tb = (double)((float)B1 + T.f * ((float)B2 + (float)B3 * T.f));
+    tc = (double)((float)C1 + T.f * ((float)C2 + (float)C3 * T.f));
+  } else {
+    a01 = A0 + A1 * T.d;
+    tb = B1 + T.d * (B2 + B3 * T.d);
+    tc = C1 + T.d * (C2 + C3 * T.d);
+  }
+  if (S.is_f32_faithful) {
+    a2s = (double)((float)A2 * S.f);
+    b04 = (double)((float)B0 + (float)B4 * S.f);
+    b5s = (double)((float)B5 * S.f);
+    c04 = (double)((float)C0 + (float)C4 * S.f);
+    c5s = (double)((float)C5 * S.f);
+  } else {
+    a2s = A2 * S.d;
+    b04 = B0 + B4 * S.d;
+    b5s = B5 * S.d;
+    c04 = C0 + C4 * S.d;
+    c5s = C5 * S.d;
+  }
+  const double al0 = a01 + a2s, p0 = b04 + T.d * (tb + b5s), lam = c04 + T.d * (tc + c5s);
+  return rho_from_terms(al0, p0, lam, p);
+}
+
 static inline double density(Val T, Val S, double p) {
+  if (T.is_f32_faithful != S.is_f32_faithful) return density_mixed(T, S, p);
   if (T.is_f32_faithful) {
     float a, b, c;
     terms32(T.f, S.f, &a, &b, &c);
@@ -135,6 +173,11 @@ static inline double drho_dsal(Val T, Val S, double p) { /* eos/wright.py:108-11
   return I2 * (lam * (B4 + B5 * T.d) - pp0 * (pp0 * A2 + (C4 + C5 * T.d)));
 }
 static inline double linear_density(Val T, Val S) { /* eos/linear.py:55-56 */
+  if (T.is_f32_faithful != S.is_f32_faithful) { /* products in their field's dtype, the rest float64 */
+    const double dt = T.is_f32_faithful ? (double)(-0.2f * T.f) : -0.2 * T.d;
+    const double ds = S.is_f32_faithful ? (double)(0.8f * S.f) : 0.8 * S.d;
+    return 1000.0 + (dt + ds);
+  }
   if (T.is_f32_faithful) return (double)(1000.0f + ((-0.2f * T.f) + (0.8f * S.f)));
   return 1000.0 + ((-0.2 * T.d) + (0.8 * S.d));
 }
@@ -174,11 +217,14 @@ static inline double pressure(const double *p, int p_mode, int64_t t, int64_t z,
 static inline double nan0(double x) { return (x == x) ? x : 0.0; }
 static inline double canonical_nan(void) { return NAN; }
 
-static int check_common(const void *T, const void *S, int dtype, const double *p, int p_mode,
-                        int eos, int64_t nt, int64_t nz, int64_t plane, int64_t sT, int64_t sS) {
+static int check_common_m(const void *T, const void *S, int dtype, const double *p, int p_mode,
+                          int eos, int64_t nt, int64_t nz, int64_t plane, int64_t sT, int64_t sS,
+                          int mixed_ok) {
   if (!T || !S) return fail(MLX_E_NULL, "T and S must not be NULL");
-  if (dtype != MLX_DTYPE_F64 && dtype != MLX_DTYPE_F32 && dtype != MLX_DTYPE_F32_UPCAST)
-    return fail(MLX_E_ENUM, "dtype must be MLX_DTYPE_F64, _F32 or _F32_UPCAST");
+  if (dtype == MLX_DTYPE_T32_S64 || dtype == MLX_DTYPE_T64_S32) {
+    if (!mixed_ok) return fail(MLX_E_ENUM, "theta/salinity of different dtypes: use mlx_eos_map_promote");
+  } else if (dtype != MLX_DTYPE_F64 && dtype != MLX_DTYPE_F32 && dtype != MLX_DTYPE_F32_UPCAST)
+    return fail(MLX_E_ENUM, "dtype must be one of MLX_DTYPE_*");
   if (eos != MLX_EOS_WRIGHT && eos != MLX_EOS_LINEAR) return fail(MLX_E_ENUM, "unknown eos");
   if (p_mode < MLX_P_SCALAR || p_mode > MLX_P_FULL4D) return fail(MLX_E_ENUM, "unknown p_mode");
   if (!p && eos == MLX_EOS_WRIGHT) return fail(MLX_E_NULL, "p must not be NULL for the Wright EOS");
@@ -186,6 +232,11 @@ static int check_common(const void *T, const void *S, int dtype, const double *p
   if (nt <= 0 || nz <= 0 || plane <= 0) return fail(MLX_E_SHAPE, "nt, nz, plane must be > 0");
   if (sT < 0 || sS < 0) return fail(MLX_E_SHAPE, "time strides must be >= 0");
   return 0;
+}
+/* the pointwise maps: no mixed theta/salinity dtypes (mlx_eos_map_promote's job) */
+static int check_common(const void *T, const void *S, int dtype, const double *p, int p_mode,
+                        int eos, int64_t nt, int64_t nz, int64_t plane, int64_t sT, int64_t sS) {
+  return check_common_m(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS, 0);
 }
 
 int mlx_version(void) { return MLX_ABI_VERSION; }
@@ -217,7 +268,7 @@ static int eos_map_impl(const void *T, const void *S, int dtype, const double *p
   for (int64_t t = 0; t < nt; ++t)
     for (int64_t z = 0; z < nz; ++z)
       for (int64_t i = 0; i < plane; ++i) {
-        const Val a = load(T, t * sT + z * plane + i, dtype), b = load(S, t * sS + z * plane + i, dtype);
+        const Val a = load(T, t * sT + z * plane + i, field_dtype(dtype, 1)), b = load(S, t * sS + z * plane + i, field_dtype(dtype, 0));
         out[(t * nz + z) * plane + i] = eos_eval(eos, func, a, b, pressure(pp, pm, t, z, i, nz, plane), aux);
       }
   return 0;
@@ -256,7 +307,7 @@ static int global_impl(const void *T, const void *S, const void *T0, const void 
                        double *out) {
   if (flags & MLX_FLAG_FMA) return fail(MLX_E_ENUM, "the host build computes exact arithmetic only");
   if (flags & ~(MLX_FLAG_SKIP_DRY | MLX_FLAG_TCHUNK_MASK)) return fail(MLX_E_ENUM, "unknown flag bits");
-  int rc = check_common(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS);
+  int rc = check_common_m(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS, 1);
   if (rc) return rc;
   if (!vol0 || !out) return fail(MLX_E_NULL, "vol0 and the output must not be NULL");
   if (rows == 4 && (!T0 || !S0)) return fail(MLX_E_NULL, "T0 and S0 must not be NULL");
@@ -271,10 +322,10 @@ static int global_impl(const void *T, const void *S, const void *T0, const void 
         const int64_t c = z * plane + i;
         const double v = vol0[c];
         const double pr = pressure(pp, pm, t, z, i, nz, plane);
-        const Val a = load(T, t * sT + c, dtype), b = load(S, t * sS + c, dtype);
+        const Val a = load(T, t * sT + c, field_dtype(dtype, 1)), b = load(S, t * sS + c, field_dtype(dtype, 0));
         acc[0] += nan0(eos_eval(eos, MLX_FUNC_DENSITY, a, b, pr, 0.0) * v); /* derived.py:435 */
         if (rows == 4) {
-          const Val a0 = load(T0, c, dtype), b0 = load(S0, c, dtype);
+          const Val a0 = load(T0, c, field_dtype(dtype, 1)), b0 = load(S0, c, field_dtype(dtype, 0));
           acc[1] += nan0(eos_eval(eos, MLX_FUNC_DENSITY, a, b0, pr, 0.0) * v);
           acc[2] += nan0(eos_eval(eos, MLX_FUNC_DENSITY, a0, b, pr, 0.0) * v);
           acc[3] += nan0(a.d * v);
@@ -333,7 +384,7 @@ static int local_impl(const void *T, const void *S, const void *T0, const void *
                       int64_t eta_vs) {
   if (flags & MLX_FLAG_FMA) return fail(MLX_E_ENUM, "the host build computes exact arithmetic only");
   if (flags & ~MLX_FLAG_SKIP_DRY) return fail(MLX_E_ENUM, "unknown flag bits");
-  int rc = check_common(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS);
+  int rc = check_common_m(T, S, dtype, p, p_mode, eos, nt, nz, plane, sT, sS, 1);
   if (rc) return rc;
   if (!rho0m || !surf || !eta) return fail(MLX_E_NULL, "rho0m, vol0_surface and eta_out must not be NULL");
   if (!dz && (!z_i || !deptho)) return fail(MLX_E_NULL, "either dz or both z_i and deptho must be given");
@@ -350,11 +401,11 @@ static int local_impl(const void *T, const void *S, const void *T0, const void *
         const int64_t c = z * plane + i;
         const double dzc = dz ? dz[c] : dz_default(deptho[i], z_i[z], z_i[z + 1]);
         const double pr = pressure(pp, pm, t, z, i, nz, plane);
-        const Val a = load(T, t * sT + c, dtype), b = load(S, t * sS + c, dtype);
+        const Val a = load(T, t * sT + c, field_dtype(dtype, 1)), b = load(S, t * sS + c, field_dtype(dtype, 0));
         double rho[3];
         rho[0] = eos_eval(eos, MLX_FUNC_DENSITY, a, b, pr, 0.0);
         if (nvar == 3) {
-          const Val a0 = load(T0, c, dtype), b0 = load(S0, c, dtype);
+          const Val a0 = load(T0, c, field_dtype(dtype, 1)), b0 = load(S0, c, field_dtype(dtype, 0));
           rho[1] = eos_eval(eos, MLX_FUNC_DENSITY, a, b0, pr, 0.0);
           rho[2] = eos_eval(eos, MLX_FUNC_DENSITY, a0, b, pr, 0.0);
         }

@@ -62,13 +62,16 @@ def _c(a, dtype=None):
 
 def _pair(T, S, f32_mode):
     T, S = _c(T), _c(S)
-    assert T.dtype == S.dtype and T.dtype in _DT
+    assert T.dtype in _DT and S.dtype in _DT
     nz, ny, nx = T.shape[-3:]
     nt = max(T.shape[0] if T.ndim == 4 else 1, S.shape[0] if S.ndim == 4 else 1)
     n3 = nz * ny * nx
     sT = n3 if T.ndim == 4 else 0
     sS = n3 if S.ndim == 4 else 0
-    dt = abi.DTYPE_F64 if T.dtype == np.float64 else F32_MODES[f32_mode]
+    if T.dtype != S.dtype:  # theta / salinity of different dtypes (K1 / K2 only)
+        dt = abi.DTYPE_T32_S64 if T.dtype == np.float32 else abi.DTYPE_T64_S32
+    else:
+        dt = abi.DTYPE_F64 if T.dtype == np.float64 else F32_MODES[f32_mode]
     return T, S, nt, nz, ny, nx, sT, sS, dt
 
 

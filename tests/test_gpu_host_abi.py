@@ -15,20 +15,23 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("dtype,f32_mode", [(np.float64, "faithful"), (np.float32, "faithful"),
-                                            (np.float32, "upcast")])
+                                            (np.float32, "upcast"),
+                                            ((np.float32, np.float64), "faithful"),
+                                            ((np.float64, np.float32), "faithful")])
 @pytest.mark.parametrize("shape", [(9, 6, 12, 40), (4, 3, 7, 9)])
 def test_hip_library_matches_the_host_build(shape, dtype, f32_mode):
     nt, nz, ny, nx = shape
     g = synthetic.make_grid(ny, nx, nz)
     r = np.random.default_rng(17)
     mask = np.isnan(g["volcello"])
-    T = np.where(mask[None], np.nan, r.uniform(-2, 32, shape)).astype(dtype)
-    S = np.where(mask[None], np.nan, r.uniform(30, 40, shape)).astype(dtype)
+    mixed = isinstance(dtype, tuple)  # theta and salinity of different dtypes: K1 / K2 only
+    T = np.where(mask[None], np.nan, r.uniform(-2, 32, shape)).astype(dtype[0] if mixed else dtype)
+    S = np.where(mask[None], np.nan, r.uniform(30, 40, shape)).astype(dtype[1] if mixed else dtype)
     pres = o.pressure_from_depth(g["z_l"])
     vol = g["volcello"]
     dT, dS, dvol = torch.from_numpy(T).cuda(), torch.from_numpy(S).cuda(), torch.from_numpy(vol).cuda()
     kw = dict(f32_mode=f32_mode)
-    for func in ("density", "drho_dtemp", "drho_dsal", "alpha", "beta"):
+    for func in () if mixed else ("density", "drho_dtemp", "drho_dsal", "alpha", "beta"):
         assert_bit_equal(core.eos_map(dT, dS, pres, func=func, **kw).cpu().numpy(),
                          h.eos_map(T, S, pres, func=func, **kw), func)
     rows = core.steric_global_decomp(dT, dS, dT[0], dS[0], dvol, pres, **kw).cpu().numpy()

@@ -342,19 +342,26 @@ def _case_fields(shape, dtype, seed=3):
     g = synthetic.make_grid(ny, nx, nz)
     r = np.random.default_rng(seed)
     mask = np.isnan(g["volcello"])
-    T = np.where(mask[None], np.nan, r.uniform(-2, 32, shape)).astype(dtype)
-    S = np.where(mask[None], np.nan, r.uniform(30, 40, shape)).astype(dtype)
+    dT, dS = dtype if isinstance(dtype, tuple) else (dtype, dtype)  # (theta, salinity) dtypes
+    T = np.where(mask[None], np.nan, r.uniform(-2, 32, shape)).astype(dT)
+    S = np.where(mask[None], np.nan, r.uniform(30, 40, shape)).astype(dS)
     return g, T, S
+
+
+T32_S64, T64_S32 = (np.float32, np.float64), (np.float64, np.float32)  # fields of different dtypes
 
 
 @pytest.mark.parametrize("skip_dry", [False, True])
 @pytest.mark.parametrize("dtype,f32_mode", [(np.float64, "faithful"), (np.float32, "faithful"),
-                                            (np.float32, "upcast")])
+                                            (np.float32, "upcast"), (T32_S64, "faithful"),
+                                            (T64_S32, "faithful"), (T32_S64, "upcast")])
 @pytest.mark.parametrize("shape", [(37, 5, 12, 40), (9, 3, 7, 9), (3, 4, 2, 1024)])
 def test_decomposition_rows_equal_single_variant_launches(shape, dtype, f32_mode, skip_dry):
     """mlx_steric_global_decomp: rows 0-2 bit-identical to three mlx_steric_global calls (same
     tiling, same order), row 3 = sum(theta*vol0) vs numpy; 12x40 / 2x1024 planes take the dwordx4
-    kernel, 7x9 the scalar twin; nt=37 spans two 32-step time chunks."""
+    kernel, 7x9 the scalar twin; nt=37 spans two 32-step time chunks.  A pair of dtypes = theta and
+    salinity stored with different precisions (MLX_DTYPE_T32_S64 / _T64_S32: numpy's promotion per
+    sub-expression, exact arithmetic whatever the default policy says; "upcast": both widened)."""
     g, T, S = _case_fields(shape, dtype)
     dT, dS = torch.from_numpy(T).cuda(), torch.from_numpy(S).cuda()
     vol0 = torch.from_numpy(g["volcello"]).cuda()
@@ -669,7 +676,10 @@ def test_config5_f32_properties():
                                                   (np.float32, "faithful", "exact"),
                                                   (np.float32, "upcast", "exact"),
                                                   (np.float64, "faithful", "fused"),
-                                                  (np.float32, "faithful", "fused")])
+                                                  (np.float32, "faithful", "fused"),
+                                                  (T32_S64, "faithful", "exact"),
+                                                  (T64_S32, "faithful", "exact"),
+                                                  (T64_S32, "upcast", "exact")])
 @pytest.mark.parametrize("shape", [(19, 5, 12, 40), (9, 3, 7, 9), (5, 4, 6, 10)])
 def test_local_decomposition_fields_equal_single_variant_launches(shape, dtype, f32_mode, arith,
                                                                    want_delta_rho):

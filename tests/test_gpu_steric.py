@@ -246,6 +246,43 @@ def test_float32_inputs_match_numpy_mixed_precision(variant, shape, f32_mode, mo
     assert_rel(masso, ogres["masso"], RTOL_SUM, f"masso(t) float32 {variant}")
 
 
+@pytest.mark.parametrize("dtypes", [(np.float32, np.float64), (np.float64, np.float32)])
+@pytest.mark.parametrize("shape", [(6, 9, 14, 20), (5, 4, 7, 9)])
+@pytest.mark.parametrize("variant", ["steric", "thermosteric", "halosteric"])
+def test_thetao_and_so_of_different_dtypes(variant, shape, dtypes):
+    """A dataset whose thetao and so were written with different precisions.  The reference hands
+    both to numpy as they are, so every sub-expression of the EOS takes the dtype numpy's promotion
+    gives it (one field's part float32, the other's float64, joined in float64): rho0, delta_rho
+    and eta bit for bit, the global sums to 1e-10, local and global, every variant."""
+    d = _masked_dataset(*shape)
+    for k, dt in zip(("thetao", "so"), dtypes):
+        d[k] = DataArray(d[k].values.astype(dt), d[k].dims)
+    res, ref = steric(d, variant=variant)
+    ores, oref = _oracle(d, variant=variant)
+    assert_bit_equal(ref["rho"].values, oref["rho"], "rho0, mixed dtypes")
+    assert_bit_equal(res["delta_rho"].values, ores["delta_rho"], "delta_rho, mixed dtypes")
+    assert_bit_equal(res[variant].values, ores[variant], "eta, mixed dtypes")
+    gres, gref = steric(d, variant=variant, domain="global")
+    ogres, ogref = _oracle(d, variant=variant, domain="global")
+    assert float(gres[variant][0]) == 0.0
+    assert_rel(gref["masso"].values, ogref["masso"], RTOL_SUM, "masso0, mixed dtypes")
+    href = float(gres["reference_height"])
+    assert np.allclose(gres[variant].values / href, ogres["expansion_coeff"], rtol=0, atol=1e-12)
+
+
+def test_mixed_dtypes_in_the_one_pass_extension(monkeypatch):
+    from momlevel_amd import steric_variants
+
+    d = _masked_dataset(6, 5, 14, 20)
+    d["thetao"] = DataArray(d["thetao"].values.astype(np.float32), d["thetao"].dims)
+    for domain in ("local", "global"):
+        results, _ = steric_variants(d, domain=domain)
+        for variant in ("steric", "thermosteric", "halosteric"):
+            single, _ = steric(d, variant=variant, domain=domain)
+            assert_bit_equal(np.asarray(results[variant][variant].values),
+                             np.asarray(single[variant].values), f"{domain} {variant}")
+
+
 def test_device_resident_inputs_give_device_outputs():
     d = _masked_dataset()
     dd = d.copy()

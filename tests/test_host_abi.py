@@ -89,10 +89,17 @@ def _case(shape, dtype, seed=3):
     return g, T, S
 
 
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32, (np.float32, np.float64),
+                                   (np.float64, np.float32)])
 @pytest.mark.parametrize("shape", [(7, 5, 12, 20), (3, 4, 7, 9)])
 def test_fused_passes_match_the_numpy_oracle(shape, dtype):
-    g, T, S = _case(shape, dtype)
+    """(a pair of dtypes: theta and salinity stored with different precisions -- numpy's promotion
+    per sub-expression, MLX_DTYPE_T32_S64 / _T64_S32)"""
+    if isinstance(dtype, tuple):
+        g, T, S = _case(shape, np.float64)
+        T, S = T.astype(dtype[0]), S.astype(dtype[1])
+    else:
+        g, T, S = _case(shape, dtype)
     pres = o.pressure_from_depth(g["z_l"])
     pb = pres[:, None, None]
     vol = g["volcello"]
