@@ -82,7 +82,10 @@ def kernel_source_sha():
 
     h = hashlib.sha256()
     root = os.path.dirname(os.path.abspath(__file__))
-    for rel in ("momlevel_amd/csrc/momlevel_hip.hip", "momlevel_amd/csrc/eos_device.hpp"):
+    # (what the translation unit of the timed kernels includes; momlevel_promote.hip is a separate
+    # unit with the untimed any-dtype EOS map)
+    for rel in ("momlevel_amd/csrc/momlevel_hip.hip", "momlevel_amd/csrc/eos_device.hpp",
+                "momlevel_amd/csrc/mlx_internal.hpp"):
         with open(os.path.join(root, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

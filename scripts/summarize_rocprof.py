@@ -89,7 +89,8 @@ def main(src, prefix, kernel="k_steric_global"):
 
     h = hashlib.sha256()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for rel in ("momlevel_amd/csrc/momlevel_hip.hip", "momlevel_amd/csrc/eos_device.hpp"):
+    for rel in ("momlevel_amd/csrc/momlevel_hip.hip", "momlevel_amd/csrc/eos_device.hpp",
+                "momlevel_amd/csrc/mlx_internal.hpp"):
         with open(os.path.join(root, rel), "rb") as f:
             h.update(f.read())
     summary["kernel_source_sha"] = h.hexdigest()[:16]
