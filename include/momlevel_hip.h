@@ -155,9 +155,10 @@ int mlx_eos_map(const void *T, const void *S, int dtype,
  *                                during the call; stride ignored.
  * func: any MLX_FUNC_* (MLX_FUNC_IBH: out = p * (-1.0 / (rho * gravity)), dynamic.py:34-36, gravity a
  * python float; ignored otherwise).  The linear EOS never reads p: it may be NULL there and takes no
- * part in the promotion.  out is float64 storage of n cells holding numpy's values exactly;
- * *out_kind (host, may be NULL) receives MLX_KIND_F32 when numpy's result dtype is float32 (every
- * value is then a float32 value) and MLX_KIND_F64 otherwise.
+ * part in the promotion.  The result comes back IN NUMPY'S RESULT DTYPE: out is a device buffer of
+ * n*8 bytes, 8-byte aligned; *out_kind (host, required) receives MLX_KIND_F32 when numpy's result
+ * is float32 -- out then holds n float32 values (its first n*4 bytes) -- and MLX_KIND_F64 when out
+ * holds n float64 values.  (The kind depends on the operand kinds, eos and func only.)
  * ------------------------------------------------------------------------------- */
 #define MLX_KIND_F64  0
 #define MLX_KIND_F32  1
@@ -166,7 +167,7 @@ int mlx_eos_map_promote(const void *T, int kind_T, int64_t stride_T,
                         const void *S, int kind_S, int64_t stride_S,
                         const void *p, int kind_p, int64_t stride_p,
                         int eos, int func, double gravity, int64_t n,
-                        double *out, int *out_kind, void *stream);
+                        void *out, int *out_kind, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * dynamic.inverse_barometer (src/momlevel/dynamic.py:34-36): out = p * (-1.0 / (rho(T,S,p) * gravity))

@@ -216,8 +216,7 @@ def eos_map(T, S, p, eos="wright", func="density", f32_mode="faithful", arith=No
         if pt is not None and pt.numel() > 1:
             pt = {P_ZPROF: lambda q: q.reshape(1, nz, 1, 1), P_FULL3D: lambda q: q.reshape(1, nz, ny, nx),
                   P_FULL4D: lambda q: q}[p_mode](pt).expand(full).reshape(-1)
-        out, _ = eos_map_promote(ops[0], ops[1], pt, eos=eos, func=func)
-        out = out.reshape(full)
+        out = eos_map_promote(ops[0], ops[1], pt, eos=eos, func=func).reshape(full)
         return out[0] if squeeze else out
     flags = (_arith_flag(arith, "k0", dt)
              if (func == "density" and eos.lower() == "wright") else 0)
@@ -251,9 +250,8 @@ def eos_map_promote(T, S, p, eos="wright", func="density", gravity=9.8):
     combinations mlx_eos_map does not cover.  Each operand is a python float / int (a WEAK scalar:
     it takes the dtype of the arrays it meets) or a float32 / float64 device tensor of n elements or
     of ONE element (used for every cell); ``p`` may be None for the linear EOS.  ``func`` may also
-    be "inverse_barometer" (``gravity`` a python float).  Returns ``(out, is_f32)``: a float64
-    device tensor of n elements holding numpy's values exactly, and whether numpy's result dtype is
-    float32."""
+    be "inverse_barometer" (``gravity`` a python float).  Returns a device tensor of n elements in
+    numpy's result dtype (float32 when no float64 array takes part) holding numpy's values."""
     import ctypes
 
     require_device()
@@ -292,7 +290,9 @@ def eos_map_promote(T, S, p, eos="wright", func="density", gravity=9.8):
         rc = _lib.load().mlx_eos_map_promote(*args, EOS_IDS[eos.lower()], fid, float(gravity), n,
                                              _ptr(out), ctypes.byref(kind), _stream(device))
     _lib.check(rc, "mlx_eos_map_promote")
-    return out, kind.value == _lib.KIND_F32
+    if kind.value == _lib.KIND_F32:  # the kernel stored n float32 values at the start of the buffer
+        return out.view(torch.float32)[:n]
+    return out
 
 
 def skip_dry_default():

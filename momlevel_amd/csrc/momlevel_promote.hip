@@ -16,6 +16,9 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <initializer_list>
+#include <type_traits>
+
 #include "../../include/momlevel_hip.h"
 #include "eos_promote.hpp"
 #include "mlx_internal.hpp"
@@ -47,16 +50,102 @@ __device__ __forceinline__ np::Weak promote_load<np::Weak>(const PromoteOperand&
   return np::Weak{o.weak};
 }
 
-template <typename TT, typename TS, typename TP>
+// The result is stored in numpy's result dtype: `out` is n float32 values when the expression is
+// float32 (wave-uniform: a property of the types and of (eos, func)), n float64 values otherwise.
+//
+// VEC cells per thread, chosen by the host so that the WIDEST array operand (or the result) of a
+// thread is one 16-byte access: 4 cells when everything is float32, 2 as soon as a float64 array
+// takes part (its floats then come as 8-byte loads) -- a wave moves 1 KiB per widest load
+// instruction instead of 256 / 512 B, which is what a pointwise map's bandwidth depends on
+// (cdna_hip_programming.md G2; measured: 0.51 -> 0.75 of the HBM peak on calc_pdens' combination).
+// Needs every array operand and the result 16-byte aligned; unaligned views take VEC = 1, and the
+// last, partial group of a launch goes cell by cell.
+template <typename X, int VEC>
+struct PromoteVals {
+  X v[VEC];
+};
+
+typedef float promote_f4 __attribute__((ext_vector_type(4)));
+
+template <typename X, int VEC>
+__device__ __forceinline__ PromoteVals<X, VEC> promote_load_group(const PromoteOperand& o, int64_t i0) {
+  PromoteVals<X, VEC> r;
+  if constexpr (std::is_same<X, np::Weak>::value) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) r.v[k] = np::Weak{o.weak};
+  } else {
+    const X* base = static_cast<const X*>(o.ptr);
+    if (o.stride == 0) {
+      const X x = base[0];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) r.v[k] = x;
+    } else if constexpr (sizeof(X) * VEC == 16) {  // 4 floats / 2 doubles: one 16-byte load
+      const promote_f4 raw = __builtin_nontemporal_load(reinterpret_cast<const promote_f4*>(base + i0));
+      __builtin_memcpy(&r, &raw, 16);
+    } else if constexpr (sizeof(X) * VEC == 8) {   // 2 floats beside doubles: one 8-byte load
+      const double raw = __builtin_nontemporal_load(reinterpret_cast<const double*>(base + i0));
+      __builtin_memcpy(&r, &raw, 8);
+    } else {
+      static_assert(VEC == 1, "groups are 8 or 16 bytes per operand");
+      r.v[0] = base[i0];
+    }
+  }
+  return r;
+}
+
+template <typename TT, typename TS, typename TP, int VEC>
 __global__ __launch_bounds__(kPromoteBlock) void k_eos_promote(PromoteOperand T, PromoteOperand S,
                                                                PromoteOperand p, int eos, int func,
                                                                double gravity, int64_t n,
-                                                               double* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * kPromoteBlock + threadIdx.x;
-  if (i >= n) return;
-  bool is_f32;
-  out[i] = np::eval<TT, TS, TP>(eos, func, promote_load<TT>(T, i), promote_load<TS>(S, i),
-                                promote_load<TP>(p, i), gravity, &is_f32);
+                                                               void* __restrict__ out) {
+  const int64_t i0 = ((int64_t)blockIdx.x * kPromoteBlock + threadIdx.x) * VEC;
+  if (i0 >= n) return;
+  bool is_f32 = false;
+  if (i0 + VEC <= n) {
+    const PromoteVals<TT, VEC> a = promote_load_group<TT, VEC>(T, i0);
+    const PromoteVals<TS, VEC> b = promote_load_group<TS, VEC>(S, i0);
+    const PromoteVals<TP, VEC> c = promote_load_group<TP, VEC>(p, i0);
+    double r[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k)
+      r[k] = np::eval<TT, TS, TP>(eos, func, a.v[k], b.v[k], c.v[k], gravity, &is_f32);
+    if (is_f32) {
+      PromoteVals<float, VEC> f;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) f.v[k] = (float)r[k];  // exact: r holds float32 values
+      float* dst = static_cast<float*>(out) + i0;
+      if constexpr (VEC == 4) {
+        promote_f4 raw;
+        __builtin_memcpy(&raw, &f, 16);
+        __builtin_nontemporal_store(raw, reinterpret_cast<promote_f4*>(dst));
+      } else if constexpr (VEC == 2) {
+        double raw;
+        __builtin_memcpy(&raw, &f, 8);
+        __builtin_nontemporal_store(raw, reinterpret_cast<double*>(dst));
+      } else {
+        dst[0] = f.v[0];
+      }
+    } else {
+      double* dst = static_cast<double*>(out) + i0;
+      if constexpr (VEC == 1) {
+        dst[0] = r[0];
+      } else {
+#pragma unroll
+        for (int q = 0; q < VEC / 2; ++q) {
+          promote_f4 raw;
+          __builtin_memcpy(&raw, &r[2 * q], 16);
+          __builtin_nontemporal_store(raw, reinterpret_cast<promote_f4*>(dst) + q);
+        }
+      }
+    }
+    return;
+  }
+  for (int64_t i = i0; i < n; ++i) {  // the launch's last, partial group
+    const double r = np::eval<TT, TS, TP>(eos, func, promote_load<TT>(T, i), promote_load<TS>(S, i),
+                                          promote_load<TP>(p, i), gravity, &is_f32);
+    if (is_f32) static_cast<float*>(out)[i] = (float)r;
+    else static_cast<double*>(out)[i] = r;
+  }
 }
 
 namespace {
@@ -74,17 +163,33 @@ struct PromoteCall {
   int eos, func;
   double gravity;
   int64_t n;
-  double* out;
+  void* out;
   hipStream_t st;
   bool is_f32;
+  bool aligned16;  // every array operand and the result 16-byte aligned: several cells per thread
 };
+
+template <typename TT, typename TS, typename TP, int VEC>
+void promote_launch(PromoteCall& c) {
+  const int64_t groups = (c.n + VEC - 1) / VEC, blocks = (groups + kPromoteBlock - 1) / kPromoteBlock;
+  hipLaunchKernelGGL((k_eos_promote<TT, TS, TP, VEC>), dim3((unsigned)blocks), dim3(kPromoteBlock), 0,
+                     c.st, c.T, c.S, c.p, c.eos, c.func, c.gravity, c.n, c.out);
+}
 
 template <typename TT, typename TS, typename TP>
 void promote_go(PromoteCall& c) {
   c.is_f32 = result_is_f32<TT, TS, TP>(c.eos, c.func);
-  const int64_t blocks = (c.n + kPromoteBlock - 1) / kPromoteBlock;
-  hipLaunchKernelGGL((k_eos_promote<TT, TS, TP>), dim3((unsigned)blocks), dim3(kPromoteBlock), 0,
-                     c.st, c.T, c.S, c.p, c.eos, c.func, c.gravity, c.n, c.out);
+  // a float64 array among the operands (the result is then float64 too): 2 cells = 16 bytes of it
+  constexpr bool ANY_F64 = std::is_same<TT, double>::value || std::is_same<TS, double>::value ||
+                           std::is_same<TP, double>::value;
+  if (!c.aligned16) {
+    promote_launch<TT, TS, TP, 1>(c);
+  } else if constexpr (ANY_F64) {
+    promote_launch<TT, TS, TP, 2>(c);
+  } else {  // float32 arrays and python floats only
+    if (c.is_f32) promote_launch<TT, TS, TP, 4>(c);
+    else promote_launch<TT, TS, TP, 2>(c);  // (a float64 result of float32 operands: full_like(weak T))
+  }
 }
 
 template <typename TT, typename TS>
@@ -140,13 +245,13 @@ int promote_operand(const void* ptr, int kind, int64_t stride, const char* what,
 extern "C" int mlx_eos_map_promote(const void* T, int kind_T, int64_t stride_T, const void* S,
                                    int kind_S, int64_t stride_S, const void* p, int kind_p,
                                    int64_t stride_p, int eos, int func, double gravity, int64_t n,
-                                   double* out, int* out_kind, void* stream) {
+                                   void* out, int* out_kind, void* stream) {
   using namespace mlx;
   if (eos != MLX_EOS_WRIGHT && eos != MLX_EOS_LINEAR) return detail::fail(MLX_E_ENUM, "unknown eos");
   if (func < MLX_FUNC_DENSITY || func > MLX_FUNC_IBH) return detail::fail(MLX_E_ENUM, "unknown func");
   if (n <= 0) return detail::fail(MLX_E_SHAPE, "n must be > 0");
   if (n > ((int64_t)1 << 38)) return detail::fail(MLX_E_SHAPE, "n too large");
-  if (!out) return detail::fail(MLX_E_NULL, "out must not be NULL");
+  if (!out || !out_kind) return detail::fail(MLX_E_NULL, "out and out_kind must not be NULL");
   if (reinterpret_cast<uintptr_t>(out) % 8) return detail::fail(MLX_E_ALIGN, "out not 8-byte aligned");
   PromoteCall c;
   const bool p_read = (eos == MLX_EOS_WRIGHT) || func == MLX_FUNC_IBH;
@@ -168,9 +273,12 @@ extern "C" int mlx_eos_map_promote(const void* T, int kind_T, int64_t stride_T, 
   c.out = out;
   c.st = static_cast<hipStream_t>(stream);
   c.is_f32 = false;
+  c.aligned16 = (reinterpret_cast<uintptr_t>(out) % 16) == 0;
+  for (const PromoteOperand* o : {&c.T, &c.S, &c.p})
+    if (o->ptr && o->stride == 1 && reinterpret_cast<uintptr_t>(o->ptr) % 16) c.aligned16 = false;
   if (kind_T == MLX_KIND_F64) promote_s<double>(c, kind_S, kind_p);
   else if (kind_T == MLX_KIND_F32) promote_s<float>(c, kind_S, kind_p);
   else promote_s<np::Weak>(c, kind_S, kind_p);
-  if (out_kind) *out_kind = c.is_f32 ? MLX_KIND_F32 : MLX_KIND_F64;
+  *out_kind = c.is_f32 ? MLX_KIND_F32 : MLX_KIND_F64;
   return detail::hip_status(hipGetLastError(), "mlx_eos_map_promote launch");
 }

@@ -101,11 +101,8 @@ def _evaluate_promoted(eos, func, T, S, p, gravity, device, on_device, scalar_in
         if isinstance(t, torch.Tensor):
             t = t.reshape(1) if t.numel() == 1 else t.expand(shape).contiguous().reshape(-1)
         flat.append(t)
-    out, is_f32 = core.eos_map_promote(flat[0], flat[1], flat[2], eos=eos, func=func,
-                                       gravity=9.8 if gravity is None else gravity)
-    out = out.reshape(shape)
-    if is_f32:
-        out = out.float()  # exact: every value is a float32 value
+    out = core.eos_map_promote(flat[0], flat[1], flat[2], eos=eos, func=func,
+                               gravity=9.8 if gravity is None else gravity).reshape(shape)
     if on_device:
         return out
     res = hostio.to_host(out)

@@ -124,7 +124,7 @@ def eos_map_promote(T, S, p, eos="wright", func="density", gravity=9.8):
     fid = abi.FUNC_IBH if func == "inverse_barometer" else abi.FUNC_IDS[func]
     _check(load().mlx_eos_map_promote(*args, abi.EOS_IDS[eos], fid, float(gravity), n, _p(out),
                                       ctypes.byref(kind), None), "mlx_eos_map_promote")
-    return out.astype(np.float32) if kind.value == abi.KIND_F32 else out
+    return out.view(np.float32)[:n].copy() if kind.value == abi.KIND_F32 else out
 
 
 def steric_global(T, S, vol0, p, eos="wright", f32_mode="faithful", flags=0):

@@ -38,18 +38,23 @@ struct Call {
   int eos, func;
   double gravity;
   int64_t n;
-  double *out;
+  void *out;
   bool is_f32;
 };
 
 template <typename TT, typename TS, typename TP>
 void go(Call &c) {
-  bool f32 = false;
-#pragma omp parallel for schedule(static) lastprivate(f32)
-  for (int64_t i = 0; i < c.n; ++i)
-    c.out[i] = mlx::np::eval<TT, TS, TP>(c.eos, c.func, load<TT>(c.T, i), load<TS>(c.S, i),
-                                         load<TP>(c.p, i), c.gravity, &f32);
+  bool f32 = false;  // a property of the types and of (eos, func): the same for every cell
+  (void)mlx::np::eval<TT, TS, TP>(c.eos, c.func, TT{1}, TS{1}, TP{1}, 1.0, &f32);
   c.is_f32 = f32;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < c.n; ++i) {
+    bool unused;
+    const double r = mlx::np::eval<TT, TS, TP>(c.eos, c.func, load<TT>(c.T, i), load<TS>(c.S, i),
+                                               load<TP>(c.p, i), c.gravity, &unused);
+    if (f32) static_cast<float *>(c.out)[i] = (float)r;  // numpy's result dtype; exact
+    else static_cast<double *>(c.out)[i] = r;
+  }
 }
 template <typename TT, typename TS>
 void by_p(Call &c, int kp) {
@@ -87,13 +92,13 @@ int operand(const void *ptr, int kind, int64_t stride, Operand *o) {
 extern "C" int mlx_eos_map_promote(const void *T, int kind_T, int64_t stride_T, const void *S,
                                    int kind_S, int64_t stride_S, const void *p, int kind_p,
                                    int64_t stride_p, int eos, int func, double gravity, int64_t n,
-                                   double *out, int *out_kind, void *stream) {
+                                   void *out, int *out_kind, void *stream) {
   (void)stream;
   if (eos != MLX_EOS_WRIGHT && eos != MLX_EOS_LINEAR) return mlxh_fail(MLX_E_ENUM, "unknown eos");
   if (func < MLX_FUNC_DENSITY || func > MLX_FUNC_IBH) return mlxh_fail(MLX_E_ENUM, "unknown func");
   if (n <= 0) return mlxh_fail(MLX_E_SHAPE, "n must be > 0");
   if (n > ((int64_t)1 << 38)) return mlxh_fail(MLX_E_SHAPE, "n too large");
-  if (!out) return mlxh_fail(MLX_E_NULL, "out must not be NULL");
+  if (!out || !out_kind) return mlxh_fail(MLX_E_NULL, "out and out_kind must not be NULL");
   if (reinterpret_cast<uintptr_t>(out) % 8) return mlxh_fail(MLX_E_ALIGN, "out not 8-byte aligned");
   Call c;
   if (int rc = operand(T, kind_T, stride_T, &c.T)) return rc;
@@ -114,6 +119,6 @@ extern "C" int mlx_eos_map_promote(const void *T, int kind_T, int64_t stride_T, 
   if (kind_T == MLX_KIND_F64) by_s<double>(c, kind_S, kind_p);
   else if (kind_T == MLX_KIND_F32) by_s<float>(c, kind_S, kind_p);
   else by_s<Weak>(c, kind_S, kind_p);
-  if (out_kind) *out_kind = c.is_f32 ? MLX_KIND_F32 : MLX_KIND_F64;
+  *out_kind = c.is_f32 ? MLX_KIND_F32 : MLX_KIND_F64;
   return 0;
 }

@@ -5,7 +5,7 @@ combinations real data produces, and the mixed-dtype K1 / K2 generic twins.
     python scripts/promote_probe.py [--nt 4] > gpurun_out/promote_probe.log
 
 Prints one JSON line per case: ms (median of 5), Gcells/s, algorithmic GB/s (operand bytes read +
-8 B written per cell for the maps; theta + S bytes for K1; + 8 B delta_rho for K2)."""
+the result written in numpy's dtype, 4 or 8 B per cell, for the maps; theta + S bytes for K1; + 8 B delta_rho for K2)."""
 import argparse
 import json
 import os
@@ -65,7 +65,8 @@ def main():
     ):
         func = "alpha" if "alpha" in label else "density"
         ops = [T.reshape(-1), S.reshape(-1), p]
-        nbytes = n * (sum(esz[x.dtype] for x in ops if isinstance(x, torch.Tensor)) + 8)
+        all32 = all(x.dtype == torch.float32 for x in ops if isinstance(x, torch.Tensor))
+        nbytes = n * (sum(esz[x.dtype] for x in ops if isinstance(x, torch.Tensor)) + (4 if all32 else 8))
         report(label, timed(lambda: core.eos_map_promote(*ops, func=func)), nbytes)
     report("tuned K0 density f64 (mlx_eos_map, z-profile pressure)",
            timed(lambda: core.eos_map(f["T", torch.float64], f["S", torch.float64], pz)), n * 24)

@@ -198,7 +198,7 @@ int main(int argc, char** argv) {
         int out_kind = -1;
         check(mlx_eos_map_promote(ops[0], kinds[0], stride(1), ops[1], kinds[1], stride(1), ops[2],
                                   kinds[2], stride(1), eos, corrupt() ? (int)(rnd() % 12) - 3 : (int)(rnd() % 6),
-                                  9.8, dim(), (double*)ptr(), (rnd() % 2) ? &out_kind : nullptr,
+                                  9.8, dim(), ptr(), (rnd() % 8) ? &out_kind : nullptr,
                                   nullptr),
               "mlx_eos_map_promote");
         break;
