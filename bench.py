@@ -713,6 +713,17 @@ def f32_timings(vol0, pres, g, dev, nt, synth_kw):
     out["default"] = dict({k: out["faithful_fused"][k] for k in ("steric", "thermosteric",
                                                                   "halosteric", "one_pass")},
                           local_eta_only=out["faithful"]["local_eta_only"])
+    # derived.calc_pdens on float32 fields (derived.py:477: a python-float pressure, so numpy keeps
+    # the whole expression float32): the any-dtype map, 8 B read + 4 B written per cell
+    np_steps = min(nt, 40)
+    pd_cells = np_steps * nz * ny * nx
+    Tp, Sp = T[:np_steps].reshape(-1), S[:np_steps].reshape(-1)
+    ms = _time(lambda: core.eos_map_promote(Tp, Sp, 101325.0))
+    out["default"]["calc_pdens_map"] = {
+        "ms": round(ms, 3), "steps": np_steps, "Mcells/s": round(pd_cells / ms / 1e3, 1),
+        "GB/s": round(12 * pd_cells / ms / 1e6, 1),
+        "frac_of_8TBs": round(12 * pd_cells / ms / 1e6 / HBM_PEAK_GBS, 4),
+        "algorithmic_bytes_per_cell": 12, "kernel": "k_eos_promote<float, float, Weak, 4>"}
     # the default calls (no mode arguments) are those, and one whole slab agrees with numpy
     # evaluated on the float32 arrays (= what momlevel computes on float32 input)
     t = nt // 2
@@ -728,7 +739,12 @@ def f32_timings(vol0, pres, g, dev, nt, synth_kw):
                                    ((Tn, Sn), (Tn, S0n), (T0n, Sn))):
         ref = o.calc_masso(o.calc_rho(a_, b_, pn), g["volcello"])
         errs[name] = float(abs(row[t] - ref) / abs(ref))
-    out["parity"] = {"k1_default_is_faithful_fused": bool(torch.equal(rows, k1_default)),
+    pd = hostio.to_host(core.eos_map_promote(T[t].reshape(-1), S[t].reshape(-1), 101325.0))
+    pd_ref = o.wright_density(Tn, Sn, 101325.0).reshape(-1)  # float32 throughout
+    pd_same = bool(pd.dtype == pd_ref.dtype == np.float32
+                   and np.array_equal(pd, pd_ref, equal_nan=True))
+    out["parity"] = {"calc_pdens_float32_slab_bit_identical_to_numpy": pd_same,
+                     "k1_default_is_faithful_fused": bool(torch.equal(rows, k1_default)),
                      "faithful_fused_vs_faithful_exact_max_rel": float(
                          ((k1_default[:3] - exact[:3]).abs() / exact[:3].abs()).max().item()),
                      "time_step_checked": t,
