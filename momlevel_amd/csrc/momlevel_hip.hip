@@ -650,6 +650,16 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
   Pack<double, VEC> r0n = load_pack<double, VEC>(rho0m + col);
   for (int z = 0; z < nz; ++z) {
     const int64_t off = (int64_t)z * plane + col;
+    // The time strides pass through an empty asm in every iteration: the compiler then computes each
+    // load's and store's scalar offset (t0+j)*stride where it is used instead of hoisting
+    // 3*NTI loop-invariant 64-bit offsets out of the z loop -- which needs more scalar registers
+    // than the wave has (the float64 kernel spilled ~150 of them into VGPR lanes, v_writelane /
+    // v_readlane + hazard nops in the hot loop: scripts/isa_count.py).
+    int64_t sT = t_stride_T, sS = t_stride_S, sD = n3;
+    asm volatile("" : "+s"(sT), "+s"(sS), "+s"(sD));
+    int64_t oT = (int64_t)t0 * sT, oS = (int64_t)t0 * sS, oD = (int64_t)t0 * sD;  // of step t0 + j
+    int nvalid = nt - t0;  // steps of this (possibly ragged) chunk: likewise compared where used
+    asm volatile("" : "+s"(nvalid));
     const Pack<double, VEC> r0 = r0n;
     if (z + 1 < nz) r0n = load_pack<double, VEC>(rho0m + off + plane);
     Pack<double, VEC> dzv;
@@ -698,15 +708,16 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
     for (int j = 0; j < NTI; ++j) {
       a[j] = {};
       b[j] = {};
-      if (alive && t0 + j < nt) {  // the ragged last chunk issues no surplus loads
-        const int64_t t = t0 + j;
-        if (STREAM_T) a[j] = load_field<MODE, true, TIn, VEC, true>(T, t * t_stride_T + off);
-        if (STREAM_S) b[j] = load_field<MODE, false, TIn, VEC, true>(S, t * t_stride_S + off);
+      if (alive && j < nvalid) {  // the ragged last chunk issues no surplus loads
+        if (STREAM_T) a[j] = load_field<MODE, true, TIn, VEC, true>(T, oT + off);
+        if (STREAM_S) b[j] = load_field<MODE, false, TIn, VEC, true>(S, oS + off);
       }
+      oT += sT;
+      oS += sS;
     }
 #pragma unroll
     for (int j = 0; j < NTI; ++j) {
-      if (t0 + j < nt) {
+      if (j < nvalid) {
         Pack<double, VEC> d[NOUT];
         // dry lanes (SKIP) run the same arithmetic on zeros: rho - NaN is NaN and the NaN term is
         // skipped, exactly as if theta/S had been loaded.  Only their LOADS are masked -- a
@@ -764,10 +775,11 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
 #pragma unroll
             for (int k = 0; k < VEC; ++k)
               d[o].v[k] = is_nan(d[o].v[k]) ? canonical_nan() : d[o].v[k];  // canonical payload
-            store_pack<VEC, true>(drho_out + o * drho_vstride + (int64_t)(t0 + j) * n3 + off, d[o]);
+            store_pack<VEC, true>(drho_out + o * drho_vstride + oD + off, d[o]);
           }
         }
       }
+      oD += sD;
     }
   }
   const Pack<double, VEC> surf = load_pack<double, VEC>(vol0_surface + col);
