@@ -126,6 +126,17 @@ __device__ __forceinline__ void store_pack(double* __restrict__ p, const Pack<do
   }
 }
 
+// 16 bytes per lane HBM -> LDS with no VGPR destination (global_load_lds_dwordx4 ... nt): lane l of
+// the wave writes lds_slice + 16*l, lds_slice being the wave's (uniform) 1 KiB slice.  Asynchronous:
+// counted by vmcnt; the data is in LDS after the caller's own s_waitcnt.  (The builtin exists in the
+// device pass only.)
+__device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_slice) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void*)lds_slice, 16, 0,
+                                   2 /* nt */);
+#endif
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
   // fixed-order butterfly-free tree: lane i += lane i+off, off = 32..1; lane 0 holds the sum
 #pragma unroll
@@ -272,10 +283,27 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
 
   // Register double buffering of the streams -- except in the float64 all-variants kernel, whose
   // 9 held doubles per cell leave no room for a second set of packs: it would drop to one wave
-  // per SIMD.  That kernel is VALU-bound (~100 ops per cell), two waves per SIMD cover each
-  // other's load latency.
+  // per SIMD.  That kernel prefetches THROUGH LDS instead (GLDS): the next step's packs are fetched
+  // by global_load_lds_dwordx4 -- an asynchronous copy HBM -> LDS with no VGPR destination
+  // (cdna_hip_programming.md section 5: "in a kernel already at the VGPR cap ... glds") -- while
+  // the current step, read out of the same LDS buffer into the one register set, is evaluated.
+  // Each wave reads back exactly the 1 KiB slices its own lanes fetched (destination = wave-uniform
+  // base + lane*16), so no barrier is involved: vmcnt(0) before the read-out, lgkmcnt(0) before the
+  // buffer is overwritten by the next step's copies.
   constexpr bool PREFETCH = !(VAR == kVarAll && sizeof(TIn) == 8 && !GENERIC);
+  constexpr bool GLDS = !PREFETCH;
+  static_assert(!GLDS || sizeof(TIn) * VEC == 16, "one 16-byte LDS-DMA per pack");
+  __shared__ f4_t stage[GLDS ? 2 * U : 1][kBlock];  // [field*U + u][thread]: 32 KiB
   Pack<TIn, VEC> curT[U], curS[U], nxtT[PREFETCH ? U : 1], nxtS[PREFETCH ? U : 1];
+  if constexpr (GLDS) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (alive[u]) {
+        lds_dma16(T + (int64_t)tb * t_stride_T + off[u], &stage[u][tid & ~63]);
+        lds_dma16(S + (int64_t)tb * t_stride_S + off[u], &stage[U + u][tid & ~63]);
+      }
+    }
+  }
 #pragma unroll
   for (int u = 0; u < (PREFETCH ? U : 0); ++u) {
     nxtT[u] = {};
@@ -287,14 +315,21 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
   }
 
   for (int t = tb; t < te; ++t) {
-    if constexpr (!PREFETCH) {
+    if constexpr (GLDS) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this step's packs have landed in LDS
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        curT[u] = {};
-        curS[u] = {};
-        if (alive[u]) {
-          if (STREAM_T) curT[u] = load_field<MODE, true, TIn, VEC, true>(T, (int64_t)t * t_stride_T + off[u]);
-          if (STREAM_S) curS[u] = load_field<MODE, false, TIn, VEC, true>(S, (int64_t)t * t_stride_S + off[u]);
+      for (int u = 0; u < U; ++u) {  // (a dry pack's slot holds stale data: its lanes skip the sums)
+        __builtin_memcpy(&curT[u], &stage[u][tid], 16);
+        __builtin_memcpy(&curS[u], &stage[U + u][tid], 16);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // read out before the buffer is reused
+      if (t + 1 < te) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (alive[u]) {
+            lds_dma16(T + (int64_t)(t + 1) * t_stride_T + off[u], &stage[u][tid & ~63]);
+            lds_dma16(S + (int64_t)(t + 1) * t_stride_S + off[u], &stage[U + u][tid & ~63]);
+          }
         }
       }
     }
