@@ -356,6 +356,14 @@ def _streamed_pair(variants, T, S, T0, S0):
     return (T if need_T else T0), (S if need_S else S0)
 
 
+def _reference_matches(T, S, T0, S0):
+    """The one-pass kernels take the reference fields in the streamed fields' dtypes.  A reference
+    state of another precision (steric(dset, reference=...) with a reference written elsewhere)
+    mixes dtypes per variant -- numpy promotes each sub-expression -- so those runs take one launch
+    per variant, where every (theta, so) pair gets the kernel of its own dtype combination."""
+    return _stream_dtype(T0) == _stream_dtype(T) and _stream_dtype(S0) == _stream_dtype(S)
+
+
 def _variant_operands(variant, Tc, Sc, T0, S0):
     """(theta, S) of one variant for the current chunk (steric.py:115-125)."""
     return (T0 if variant == "halosteric" else Tc), (S0 if variant == "thermosteric" else Sc)
@@ -376,7 +384,9 @@ def global_masso_variants(T, S, T0, S0, vol0, pres, variants, eos="wright", f32_
         pres = to_device(pres, dev, torch.float64)
     T0 = to_device(T0, dev, _stream_dtype(T0))
     S0 = to_device(S0, dev, _stream_dtype(S0))
-    one_pass = len(variants) >= 2 or with_heat
+    same = _reference_matches(T, S, T0, S0)
+    one_pass = (len(variants) >= 2 and same) or with_heat
+    heat_only = one_pass and not same  # the heat row does not depend on the reference fields
     Ts, Ss = (T, S) if one_pass else _streamed_pair(variants, T, S, T0, S0)
     chunks = TimeChunks(Ts, Ss, dev, steps=steps,
                         extra_bytes_per_step=_pressure_bytes_per_step(pres))
@@ -388,9 +398,10 @@ def global_masso_variants(T, S, T0, S0, vol0, pres, variants, eos="wright", f32_
         if one_pass:
             rows = core.steric_global_decomp(Tc, Sc, T0.to(Tc.dtype), S0.to(Sc.dtype), vol0, pc,
                                              eos=eos, f32_mode=f32_mode, skip_dry=skip_dry)
-            for v in names:
+            for v in (["heat"] if heat_only else names):
                 out[v][t0:t1] = rows[core.DECOMP_ROWS.index(v)]
-            continue
+            if not heat_only:
+                continue
         for v in variants:
             Tv, Sv = _variant_operands(v, Tc, Sc, T0, S0)
             out[v][t0:t1] = core.steric_global_masso(Tv, Sv, vol0, pc, eos=eos,
@@ -452,7 +463,8 @@ def local_steric_variants(T, S, T0, S0, rho0, vol0, pres, rhozero, variants, z_i
     # read once: 16 B read + 3 x 8 B written per cell instead of 56 B); every field bit-identical
     # to its single-variant launch
     rows = core.LOCAL_DECOMP_ROWS
-    one_pass = set(variants) == set(rows) and len(variants) == 3 and T.ndim == 4 and S.ndim == 4
+    one_pass = (set(variants) == set(rows) and len(variants) == 3 and T.ndim == 4 and S.ndim == 4
+                and _reference_matches(T, S, T0, S0))
     direct = one_pass and not out_host and not annual  # the kernel writes the final tensors
     if direct:
         eta_all = torch.empty((3, nt, ny, nx), dtype=torch.float64, device=dev)

@@ -270,6 +270,35 @@ def test_thetao_and_so_of_different_dtypes(variant, shape, dtypes):
     assert np.allclose(gres[variant].values / href, ogres["expansion_coeff"], rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("domain", ["local", "global"])
+def test_reference_state_of_another_precision(domain):
+    """steric(dset, reference=...) with a float64 reference state and float32 fields (a reference
+    written by an earlier run): thermosteric pairs float32 theta with the float64 reference
+    salinity, halosteric the other way round, steric is all float32 -- numpy promotes per variant.
+    Single calls and the one-pass extension (which then takes one launch per variant)."""
+    from momlevel_amd import steric_variants
+
+    d64 = _masked_dataset(5, 6, 14, 20)
+    _, ref64 = steric(d64)
+    d32 = d64.copy()
+    for k in ("thetao", "so"):
+        d32[k] = DataArray(d64[k].values.astype(np.float32), d64[k].dims)
+    oref = o.setup_reference_state(d64["thetao"].values, d64["so"].values, d64["volcello"].values,
+                                   d64["areacello"].values, d64["z_l"].values)
+    many, _ = steric_variants(d32, reference=ref64, domain=domain)
+    for variant in ("steric", "thermosteric", "halosteric"):
+        res, _ = steric(d32, reference=ref64, variant=variant, domain=domain)
+        ores, _ = _oracle(d32, reference=oref, variant=variant, domain=domain)
+        if domain == "local":
+            assert_bit_equal(res["delta_rho"].values, ores["delta_rho"], f"delta_rho {variant}")
+            assert_bit_equal(res[variant].values, ores[variant], f"eta {variant}")
+        else:
+            href = float(res["reference_height"])
+            assert np.allclose(res[variant].values / href, ores["expansion_coeff"], rtol=0, atol=1e-12)
+        assert_bit_equal(np.asarray(many[variant][variant].values), np.asarray(res[variant].values),
+                         f"one-pass extension, {variant}")
+
+
 def test_mixed_dtypes_in_the_one_pass_extension(monkeypatch):
     from momlevel_amd import steric_variants
 
