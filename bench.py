@@ -44,7 +44,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-from momlevel_amd import core, engine, hostio, parallel, synthetic  # noqa: E402
+from momlevel_amd import _lib, core, engine, hostio, parallel, synthetic  # noqa: E402
 
 # BASELINE.json's metric string, verbatim
 METRIC = "Mcells/s for fused Wright-EOS+steric at 1440\u00d71080\u00d775; % HBM roofline"
@@ -106,6 +106,61 @@ def measured_traffic(cells_per_launch):
         except (OSError, KeyError, ValueError):
             pass
     return None, None
+
+
+# VALU issue peak of the chip, in lane-instructions per second: 256 CUs x 4 SIMDs x 16 lanes per
+# clock (a wave64 instruction occupies its SIMD for 4 clocks) x 2.4 GHz (MI355X_MICROARCH.md).
+# float64 instructions measured 4.5-4.7 clocks and v_rcp_f64 15.5 (profiles/r01_tune_ops_*.log), so a
+# kernel of float64 arithmetic saturates its SIMDs at ~0.85 of this figure.
+VALU_PEAK_LANE_INSTR_PER_S = 256 * 4 * 16 * 2.4e9
+
+
+def valu_profiles():
+    """{bench key: VALU instructions per cell} from the round's committed SQ_INSTS_VALU passes
+    (profiles/r04_*variants_summary.json, written by scripts/summarize_variants.py) -- quoted, like
+    roofline.traffic, only while the sha of the kernel sources matches the profiled ones."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    found, sources = {}, []
+    for name in ("r04_variants_summary.json", "r04_f32_variants_summary.json"):
+        try:
+            with open(os.path.join(here, "profiles", name)) as f:
+                summ = json.load(f)
+            if summ.get("kernel_source_sha") != kernel_source_sha():
+                continue
+            prefix = "config5_f32." if "f32" in name else ""
+            for k in summ["kernels"]:
+                if k.get("bench_key") and "valu_wave_instr_per_cell" in k:
+                    found[prefix + k["bench_key"]] = k["valu_wave_instr_per_cell"]
+            sources.append(f"profiles/{name}")
+        except (OSError, KeyError, ValueError):
+            pass
+    return found, sources
+
+
+def add_valu_roofline(line):
+    """For every timed kernel the committed counter profile covers: VALU instructions per cell and
+    the fraction of the chip's VALU issue peak that rate amounts to -- the roofline that bounds the
+    float32 and one-pass kernels (HBM traffic 1.03-1.08 x algorithmic, far below the HBM peak)."""
+    instr, sources = valu_profiles()
+    for key, per_cell in instr.items():
+        node = line
+        for part in key.split("."):
+            node = node.get(part) if isinstance(node, dict) else None
+        if not isinstance(node, dict):
+            continue
+        rate = node.get("Mcells/s")
+        if rate is None and key == "roofline":
+            rate = node["achieved"] / node["algorithmic_bytes_per_cell"] * 1e3  # GB/s / B -> Mcells/s
+        if rate is None:
+            continue
+        node["valu_instr_per_cell"] = per_cell
+        node["frac_of_valu_peak"] = round(per_cell * rate * 1e6 / VALU_PEAK_LANE_INSTR_PER_S, 4)
+    line["valu_roofline"] = {
+        "peak_lane_instr_per_s": VALU_PEAK_LANE_INSTR_PER_S,
+        "definition": "valu_instr_per_cell (SQ_INSTS_VALU x 64 / cells, committed profile of these "
+                      "kernel sources) x cells/s / (256 CU x 4 SIMD x 16 lanes x 2.4 GHz)",
+        "sources": sources or None,
+    }
 
 
 def fit_nt(nt, nz, ny, nx, device, itemsize=8):
@@ -266,10 +321,16 @@ def cpu_baseline_fused(T, S, g, pres, gpu_masso, slabs=2):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: become the launcher -- N fresh rank processes (what
+        # torch.distributed.run would start), before this process makes any GPU call; rank 0's JSON
+        # line is relayed, the exit code is the worst rank's.  (device_count() does not initialise
+        # the GPU; with fewer GPUs than ranks the ranks rehearse over gloo and say so.)
+        sys.exit(parallel.launch_local_ranks(
+            a.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+            visible_gpus=torch.cuda.device_count()))
     rank, world, local_rank = parallel.init_from_env()
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         a.gpus = world
     core.require_device()
     import torch.distributed as dist
@@ -360,6 +421,7 @@ def main():
     if world > 1:
         elapsed = float(allreduce_scalar(elapsed, dist.ReduceOp.MAX, torch.float64))
 
+    k1_kernel = _lib.last_kernel()  # the instantiation the timed region's last K1 call launched
     cells_rank = nt * nz * th * tw
     cells_job = cells_rank * world
     # K1 time of one pass over the record = the sum over its chunk launches (one launch at N=1)
@@ -415,7 +477,11 @@ def main():
                     f"in {n_launches} time chunks of <= {chunk_steps} steps with one RCCL all-reduce "
                     "per chunk ("
                     + ("NOT BASELINE.json configs[3]: the record was shortened to fit free HBM, see "
-                       "nt_requested; " if shrunk else "BASELINE.json configs[3]; ")
+                       "nt_requested; " if shrunk else
+                       "BASELINE.json configs[3]; " if (world == 8 and nt == 1200
+                                                        and (nz, ny, nx) == GRID) else
+                       f"configs[3]'s tiling at {world} GPUs -- configs[3] itself is 8 GPUs x 1200 "
+                       "steps; ")
                     + "weak scaling: bytes per GPU are fixed, the record grows with N)"),
                 "grid_xyz": [nx, ny, nz],
                 "nt_per_gpu_resident": nt,
@@ -429,13 +495,18 @@ def main():
                 "collective": ("none" if world == 1 else
                                f"{n_launches} all_reduce per step: {chunk_steps}(+3 in the first) f64 "
                                "each, asynchronous, overlapped with the next chunk's kernel"),
+                "backend": (None if world == 1 else
+                            "nccl (RCCL)" if dist.get_backend() == "nccl" else
+                            dist.get_backend() + " (REHEARSAL: the ranks share GPUs and the exchange "
+                            "is staged through the host; not an xGMI measurement)"),
                 "time_chunks": n_launches,
                 "input_dtype": a.input_dtype,
                 "hbm_resident_gb": round(2 * cells_rank * (4 if f32 else 8) / 1e9, 1),
             },
             "roofline": {
-                "kernel": ("k_steric_global<float,4,2,0,1,false,false,false>" if f32
-                           else "k_steric_global<double,2,4,0,0,false,false,true>"),
+                "kernel": k1_kernel,  # mlx_last_kernel() after the timed launches
+                "kernel_template_arguments": "<element type, cells per pack, packs per thread, "
+                                             "variant, dtype mode, generic, skip_dry, fma>",
                 "arith": core.arith_default("k1", tdtype) + " (the product default for this dtype)",
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
@@ -461,10 +532,26 @@ def main():
             "eta_t0_is_zero": bool(out["eta"][0] == 0.0),
         }
         line.update(extras)
+        add_valu_roofline(line)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def local_slab_check(o, Tn, Sn, rho0, g, pres, drho_gpu, eta_gpu):
+    """steric.py:151-166 on ONE time slab in numpy (the oracle's functions): delta_rho =
+    where(volcello_ref notnull, rho - rho0, NaN), eta = -1/rhozero * nansum(dz * delta_rho) masked by
+    the surface cell -- against the GPU's delta_rho / eta of that step.  -> bit-identical?"""
+    vol = g["volcello"]
+    rho = o.calc_rho(Tn, Sn, pres)
+    dref = np.where(~np.isnan(vol), rho - rho0, np.nan)
+    dz = o.calc_dz(g["z_l"], g["z_i"], g["deptho"])
+    eref = np.where(~np.isnan(vol[0]), (-1.0 / 1035.0) * o.nansum(dz * dref, axis=0), np.nan)
+    ok = bool(np.array_equal(eta_gpu, eref, equal_nan=True))
+    if drho_gpu is not None:
+        ok = ok and bool(np.array_equal(drho_gpu, dref, equal_nan=True))
+    return ok
 
 
 def _time(fn, reps=3):
@@ -488,10 +575,13 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
     out = {}
     B1 = T.element_size()  # bytes per cell of ONE streamed field: 8 (float64) or 4 (float32)
 
-    def rate(ms, bytes_per_cell, n=cells):
-        return {"Mcells/s": round(n / ms / 1e3, 1), "ms": round(ms, 3),
-                f"GB/s_at_{bytes_per_cell}B_per_cell": round(bytes_per_cell * n / ms / 1e6, 1),
-                "frac_of_8TBs": round(bytes_per_cell * n / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    def rate(ms, bytes_per_cell, n=cells, kernel=True):
+        r = {"Mcells/s": round(n / ms / 1e3, 1), "ms": round(ms, 3),
+             f"GB/s_at_{bytes_per_cell}B_per_cell": round(bytes_per_cell * n / ms / 1e6, 1),
+             "frac_of_8TBs": round(bytes_per_cell * n / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        if kernel:  # the K1 / K2 instantiation the timed call launched (mlx_last_kernel)
+            r["kernel"] = _lib.last_kernel()
+        return r
 
     # K1's arithmetic: the product default for this dtype (fused on float64, exact on float32;
     # core.arith_default) carries the plain key, the other policy its name as a suffix
@@ -572,6 +662,13 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
             r["frac_of_read_write_probe"] = round(pms_b / ms_b, 4)
             r["read_write_probe_GB/s"] = round(24 * done_b / pms_b / 1e6, 1)
         out["local_with_delta_rho_large_chunks"] = r
+        # The held-field instantiations of the local pass (what momlevel.thermosteric(ds) /
+        # halosteric(ds) run with the default domain="local", steric.py:150-166): one streamed
+        # field in, delta_rho out -- 8 B read + 8 B written per cell at float64 (+ the held slab and
+        # rho0m once per level and time block of the thread: 16/NTI B) -- against the probe with THAT
+        # mix (1 stream in, 1 out), and the eta-only forms against the one-stream read probe.
+        out.update(local_held_timings(T, S, rho0m, vol0, pres, zi, dep, eta, dbig, starts_b, big,
+                                      g, B1))
         del dbig
         torch.cuda.empty_cache()
     chunk = min(nt, 16)
@@ -612,7 +709,7 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
                 del rho
 
         kms = _time(run_k0, reps=2)
-        out["calc_rho_map"] = rate(kms, 2 * B1 + 8, done)
+        out["calc_rho_map"] = rate(kms, 2 * B1 + 8, done, kernel=False)
         if B1 == 8:
             out["calc_rho_map"]["frac_of_read_write_probe"] = round(pms / kms, 4)
         ms_skip = _time(lambda: run(True), reps=2)
@@ -654,6 +751,83 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
     return out
 
 
+def local_held_timings(T, S, rho0m, vol0, pres, zi, dep, eta, dbuf, starts, steps, g, B1,
+                        with_steric=False):
+    """K2's held-field instantiations (+ the steric one for float32 records, ``with_steric``) with
+    and without delta_rho on the resident record, in chunks of ``steps`` into the reused float64
+    buffer ``dbuf``; each against the stream probe with its own read:write mix, and one slab of each
+    variant against the oracle (numpy on the arrays' own dtype)."""
+    from oracle import momlevel_numpy as o  # the checker
+
+    nt, nz, ny, nx = T.shape
+    n3 = nz * ny * nx
+    done = len(starts) * steps * n3
+    out = {}
+
+    def rate(ms, bpc, n):
+        return {"Mcells/s": round(n / ms / 1e3, 1), "ms": round(ms, 3),
+                "algorithmic_bytes_per_cell": bpc,
+                "GB/s": round(bpc * n / ms / 1e6, 1),
+                "frac_of_8TBs": round(bpc * n / ms / 1e6 / HBM_PEAK_GBS, 4),
+                "kernel": _lib.last_kernel()}
+
+    def ops(variant, t0, t1):
+        Tv = T[0] if variant == "halosteric" else T[t0:t1]
+        Sv = S[0] if variant == "thermosteric" else S[t0:t1]
+        return Tv, Sv
+
+    def run(variant, want):
+        for t0 in starts:
+            Tv, Sv = ops(variant, t0, t0 + steps)
+            core.steric_local(Tv, Sv, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=zi, deptho=dep,
+                              want_delta_rho=want, delta_rho_out=dbuf if want else None,
+                              eta_out=eta[t0:t0 + steps], skip_dry=False)
+
+    def probe(nin, write):
+        for t0 in starts:
+            a = T[t0:t0 + steps]
+            core.stream_probe_mix(a, S[t0:t0 + steps] if nin == 2 else None,
+                                  out=dbuf if write else None, write=write)
+
+    probes = {}
+
+    def probe_ms(nin, write):
+        if (nin, write) not in probes:
+            probes[(nin, write)] = _time(lambda: probe(nin, write), reps=2)
+        return probes[(nin, write)]
+
+    variants = (("steric",) if with_steric else ()) + ("thermosteric", "halosteric")
+    pn = pres.cpu().numpy()
+    T0n, S0n = hostio.to_host(T[0]), hostio.to_host(S[0])
+    rho0n = o.calc_rho(T0n, S0n, pn)
+    t_chk = starts[-1] + steps - 1  # last step of the last chunk: still in dbuf after the run
+    for variant in variants:
+        nin = 2 if variant == "steric" else 1
+        for want in (True, False):
+            if variant == "halosteric" and not want:
+                continue
+            ms = _time(lambda: run(variant, want), reps=2)
+            bpc = nin * B1 + (8 if want else 0)
+            r = rate(ms, bpc, done)
+            pms = probe_ms(nin, want)
+            r["probe"] = (f"mlx_stream_probe_mix: {nin} x {'float64' if B1 == 8 else 'float32'} in"
+                          + (", 1 x float64 out" if want else ", read-only"))
+            r["probe_GB/s"] = round(bpc * done / pms / 1e6, 1)
+            r["frac_of_matching_probe"] = round(pms / ms, 4)
+            r["chunk_steps"], r["launches"] = steps, len(starts)
+            if want:  # one slab against the oracle: the last step the run left in the buffer
+                Tn = T0n if variant == "halosteric" else hostio.to_host(T[t_chk])
+                Sn = S0n if variant == "thermosteric" else hostio.to_host(S[t_chk])
+                r["slab_bit_identical_to_oracle"] = local_slab_check(
+                    o, Tn, Sn, rho0n, g, pn, hostio.to_host(dbuf[steps - 1]),
+                    hostio.to_host(eta[t_chk]))
+                r["time_step_checked"] = int(t_chk)
+            key = "local_" + ("" if variant == "steric" else variant + "_") + (
+                "with_delta_rho" if want else "eta_only")
+            out[key] = r
+    return out
+
+
 def f32_timings(vol0, pres, g, dev, nt, synth_kw):
     """BASELINE.json configs[4]: float32 theta/S (what MOM6 writes) at the roofline grid, resident;
     global variants, the one-pass decomposition (+ heat) and the local eta pass.  "faithful" =
@@ -675,7 +849,7 @@ def f32_timings(vol0, pres, g, dev, nt, synth_kw):
         return {"ms": round(ms, 3), "Mcells/s": round(cells / ms / 1e3, 1),
                 "GB/s": round(bpc * cells / ms / 1e6, 1),
                 "frac_of_8TBs": round(bpc * cells / ms / 1e6 / HBM_PEAK_GBS, 4),
-                "algorithmic_bytes_per_cell": bpc}
+                "algorithmic_bytes_per_cell": bpc, "kernel": _lib.last_kernel()}
 
     modes = {"faithful_fused": dict(f32_mode="faithful", arith="fused"),
              "faithful": dict(f32_mode="faithful", arith="exact"),
@@ -713,6 +887,21 @@ def f32_timings(vol0, pres, g, dev, nt, synth_kw):
     out["default"] = dict({k: out["faithful_fused"][k] for k in ("steric", "thermosteric",
                                                                   "halosteric", "one_pass")},
                           local_eta_only=out["faithful"]["local_eta_only"])
+    # The local pass WITH delta_rho on the float32 record -- the reference's one recorded real-size
+    # call is momlevel.thermosteric(ds) on float32 thetao/so with the default domain="local"
+    # (examples/example.ipynb cell 6; steric.py:150-166): K2 VAR 2 / MLX_DTYPE_F32 with the float64
+    # delta_rho store, 4 B read + 8 B written per cell.  The float64 delta_rho of all steps fits
+    # beside the 112 GB record: one launch per variant.
+    free, _ = torch.cuda.mem_get_info(dev)
+    steps_d = int(min(nt, max(0, free - (6 << 30)) // (nz * ny * nx * 8)))
+    if steps_d >= 6:
+        steps_d = steps_d // 6 * 6  # whole time blocks of the float32 K2 thread
+        dbuf = torch.empty((steps_d, nz, ny, nx), dtype=torch.float64, device=dev)
+        out["default"].update(local_held_timings(
+            T, S, rho0m, vol0, pres, zi, dep, eta, dbuf, range(0, nt - steps_d + 1, steps_d),
+            steps_d, g, 4, with_steric=True))
+        del dbuf
+        torch.cuda.empty_cache()
     # derived.calc_pdens on float32 fields (derived.py:477: a python-float pressure, so numpy keeps
     # the whole expression float32): the any-dtype map, 8 B read + 4 B written per cell
     np_steps = min(nt, 40)

@@ -38,11 +38,12 @@
 extern "C" {
 #endif
 
-#define MLX_ABI_VERSION 4 /* 2: mlx_eos_map takes flags; mlx_steric_global_decomp, mlx_steric_local_decomp,
+#define MLX_ABI_VERSION 5 /* 2: mlx_eos_map takes flags; mlx_steric_global_decomp, mlx_steric_local_decomp,
                              mlx_stream_probe;
                              MLX_FLAG_FMA, MLX_FLAG_TCHUNK; MLX_P_FULL4D in K1/K2
                              3: mlx_build_kind; a NULL p (linear EOS) requires p_mode MLX_P_SCALAR
-                             4: mlx_eos_map_promote (MLX_KIND_*); MLX_DTYPE_T32_S64 / _T64_S32 in K1/K2 */
+                             4: mlx_eos_map_promote (MLX_KIND_*); MLX_DTYPE_T32_S64 / _T64_S32 in K1/K2
+                             5: mlx_stream_probe_mix, mlx_last_kernel */
 
 /* argument-error codes (negative) */
 #define MLX_E_NULL     (-1) /* a required pointer is NULL                      */
@@ -122,6 +123,14 @@ int mlx_last_error(char *buf, size_t n);
 #define MLX_BUILD_HIP  1
 #define MLX_BUILD_HOST 2
 int mlx_build_kind(void);
+
+/* Name of the kernel instantiation the calling thread's last mlx_steric_global* / mlx_steric_local*
+ * call launched, with its template arguments, e.g. "k_steric_global<double,2,4,0,0,false,false,true>"
+ * = <element type, cells per 16-byte pack, packs (K1) or time steps (K2) per thread, variant
+ * (0 steric, 1 halosteric, 2 thermosteric, 3 all), dtype mode, generic twin, MLX_FLAG_SKIP_DRY,
+ * MLX_FLAG_FMA> -- what a profile of that call lists.  bench.py quotes it; same contract as
+ * mlx_last_error (copies into buf, returns the length). */
+int mlx_last_kernel(char *buf, size_t n);
 
 /* ---------------------------------------------------------------------------------
  * K0  pointwise EOS map.  Replaces eos.wright.density/drho_dtemp/drho_dsal/alpha/beta
@@ -312,6 +321,16 @@ int mlx_calc_dz(const double *z_i, const double *depth, int64_t nz, int64_t plan
  * mlx_steric_local with delta_rho (24 B/cell) as a fraction of this box-specific ceiling.
  * ------------------------------------------------------------------------------- */
 int mlx_stream_probe(const double *a, const double *b, int64_t n, double *out, void *stream);
+
+/* The same aid for the read:write mixes of the other local passes: one (b == NULL) or two streams
+ * of n elements of `dtype` (MLX_DTYPE_F64 or MLX_DTYPE_F32; 16-byte aligned, n a whole number of
+ * 16-byte packs) in and, if write_out != 0, out[i] = (double)a[i] (+ (double)b[i]) as one float64
+ * stream out (16-byte aligned, n doubles).  write_out == 0: read-only -- out must hold one double
+ * and is left untouched.  A held-field pass with delta_rho is 1 in / 1 out (8 + 8 B per cell at
+ * float64, 4 + 8 B at float32), the float32 steric pass with delta_rho 2 in / 1 out (8 + 8 B).
+ * bench.py reports each local instantiation as a fraction of the probe with ITS mix. */
+int mlx_stream_probe_mix(const void *a, const void *b, int dtype, int64_t n, double *out,
+                         int write_out, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * Synthetic MOM6-shaped fields for bench.py and the full-size tests (not a

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("MOMLEVEL_AMD_LIB") or os.path.join(HERE, "libmomlevel
 _ORACLE_DIR = os.path.join(os.path.dirname(HERE), "oracle")
 
 # ---- constants mirrored from include/momlevel_hip.h --------------------------------
-ABI_VERSION = 4
+ABI_VERSION = 5
 EOS_WRIGHT, EOS_LINEAR = 0, 1
 FUNC_DENSITY, FUNC_DRHO_DTEMP, FUNC_DRHO_DSAL, FUNC_ALPHA, FUNC_BETA, FUNC_IBH = 0, 1, 2, 3, 4, 5
 P_SCALAR, P_ZPROF, P_FULL3D, P_FULL4D = 0, 1, 2, 3
@@ -56,6 +56,7 @@ SIGNATURES = {
     "mlx_version": (_int, []),
     "mlx_last_error": (_int, [ctypes.c_char_p, _sz]),
     "mlx_build_kind": (_int, []),
+    "mlx_last_kernel": (_int, [ctypes.c_char_p, _sz]),
     "mlx_eos_map": (
         _int,
         [_vp, _vp, _int, _vp, _int, _int, _int, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp],
@@ -97,6 +98,7 @@ SIGNATURES = {
     "mlx_masso": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "mlx_group_weighted_mean": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "mlx_stream_probe": (_int, [_vp, _vp, _i64, _vp, _vp]),
+    "mlx_stream_probe_mix": (_int, [_vp, _vp, _int, _i64, _vp, _int, _vp]),
     "mlx_calc_dz": (_int, [_vp, _vp, _i64, _i64, _dbl, _dbl, _int, _int, _vp, _vp]),
     "mlx_synth_field": (
         _int,
@@ -155,6 +157,13 @@ def load():
 def last_error():
     buf = ctypes.create_string_buffer(512)
     load().mlx_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def last_kernel():
+    """The kernel instantiation this thread's last K1 / K2 call launched (mlx_last_kernel)."""
+    buf = ctypes.create_string_buffer(160)
+    load().mlx_last_kernel(buf, 160)
     return buf.value.decode(errors="replace")
 
 

@@ -403,6 +403,23 @@ def stream_probe(a, b, out=None):
     return out
 
 
+def stream_probe_mix(a, b=None, out=None, write=True):
+    """Measurement aid: one (``b`` None) or two float32 / float64 streams in, one float64 stream out
+    (``write``) or none -- the read:write mix of a held-field / float32 local pass; see
+    mlx_stream_probe_mix.  Returns ``out`` (a 1-element tensor, untouched, when ``write`` is False)."""
+    require_device()
+    dt = _dtype_code(a, "faithful")
+    if b is not None and (b.dtype != a.dtype or b.numel() != a.numel()):
+        raise ValueError("a and b must agree in dtype and size")
+    if out is None:
+        out = torch.empty(a.shape if write else (1,), dtype=torch.float64, device=a.device)
+    with _on(a.device):
+        rc = _lib.load().mlx_stream_probe_mix(_ptr(a), _ptr(b), dt, a.numel(), _ptr(out),
+                                              int(bool(write)), _stream(a.device))
+    _lib.check(rc, "mlx_stream_probe_mix")
+    return out
+
+
 def fold_mask(rho0, vol0):
     """rho0m = where(vol0 notnull, rho0, NaN) -- prepared once per reference state."""
     require_device()

@@ -534,6 +534,42 @@ __global__ __launch_bounds__(kBlock) void k_stream_probe(const double* __restric
   }
 }
 
+// The same probe for the read:write mixes of the OTHER instantiations of the local kernel: NIN
+// streams of TIn in (16-byte nt loads: 2 doubles or 4 floats per lane) and, if WRITE, one float64
+// stream out (16-byte nt stores) -- a held-field pass with delta_rho is 1 stream in / 1 out (8 B +
+// 8 B per cell at float64, 4 B + 8 B at float32), the float32 steric pass 2 in / 1 out (8 B + 8 B),
+// the eta-only passes read-only.  Without WRITE the values are summed into a per-thread sink that is
+// stored only if it equals a value no data produces (keeps the loads alive, writes nothing).
+template <typename TIn, int NIN, bool WRITE>
+__global__ __launch_bounds__(kBlock) void k_stream_probe_mix(const TIn* __restrict__ a,
+                                                             const TIn* __restrict__ b,
+                                                             int64_t npacks,
+                                                             double* __restrict__ out) {
+  constexpr int VEC = 16 / sizeof(TIn);
+  double sink = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < npacks;
+       i += (int64_t)gridDim.x * kBlock) {
+    const Pack<TIn, VEC> x = load_pack<TIn, VEC, true>(a + VEC * i);
+    Pack<double, VEC> r;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) r.v[k] = (double)x.v[k];
+    if constexpr (NIN == 2) {
+      const Pack<TIn, VEC> y = load_pack<TIn, VEC, true>(b + VEC * i);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) r.v[k] += (double)y.v[k];
+    }
+    if constexpr (WRITE) {
+      store_pack<VEC, true>(out + VEC * i, r);
+    } else {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) sink += r.v[k];
+    }
+  }
+  if constexpr (!WRITE) {
+    if (sink == 0x1.23456789abcdep+1000) out[0] = sink;
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // K0: pointwise EOS map.  grid = (ceil(plane/(kBlock*VEC*U)), nz, nt)
 // ------------------------------------------------------------------------------------
@@ -928,6 +964,14 @@ namespace {
 using namespace mlx;
 
 thread_local char g_err[512] = "";
+// the instantiation the calling thread's last K1 / K2 dispatch launched (mlx_last_kernel)
+thread_local char g_kernel[160] = "";
+
+template <typename T>
+const char* type_name() {
+  return sizeof(T) == 8 ? "double" : "float";
+}
+inline const char* tf(bool b) { return b ? "true" : "false"; }
 
 int fail(int code, const char* msg) {
   snprintf(g_err, sizeof(g_err), "%s", msg);
@@ -1066,6 +1110,8 @@ struct K1Args {
 
 template <typename TIn, int VEC, int U, int VAR, int MODE, bool GEN, bool SKIP, bool FMA>
 void k1_go(const K1Args& a) {
+  snprintf(g_kernel, sizeof(g_kernel), "k_steric_global<%s,%d,%d,%d,%d,%s,%s,%s>",
+           type_name<TIn>(), VEC, U, VAR, MODE, tf(GEN), tf(SKIP), tf(FMA));
   hipLaunchKernelGGL((k_steric_global<TIn, VEC, U, VAR, MODE, GEN, SKIP, FMA>), a.grid,
                      dim3(kBlock), 0, a.st, (const TIn*)a.T, (const TIn*)a.S, (const TIn*)a.T0,
                      (const TIn*)a.S0, a.vol0, a.p, a.p_mode, a.eos, a.nt, a.t_chunk, a.plane,
@@ -1192,6 +1238,8 @@ struct K2Args {
 
 template <typename TIn, int VEC, int NTI, int VAR, int MODE, bool GEN, bool SKIP, bool FMA>
 void k2_go(const K2Args& a) {
+  snprintf(g_kernel, sizeof(g_kernel), "k_steric_local<%s,%d,%d,%d,%d,%s,%s,%s>",
+           type_name<TIn>(), VEC, NTI, VAR, MODE, tf(GEN), tf(SKIP), tf(FMA));
   hipLaunchKernelGGL((k_steric_local<TIn, VEC, NTI, VAR, MODE, GEN, SKIP, FMA>), a.grid,
                      dim3(kBlock), 0, a.st, (const TIn*)a.T, (const TIn*)a.S, (const TIn*)a.T0,
                      (const TIn*)a.S0, a.rho0m, a.surf, a.dz, a.z_i, a.deptho, a.p, a.p_mode, a.eos,
@@ -1326,6 +1374,14 @@ int mlx_last_error(char* buf, size_t n) {
 }
 
 int mlx_build_kind(void) { return MLX_BUILD_HIP; }
+
+int mlx_last_kernel(char* buf, size_t n) {
+  if (buf && n) {
+    strncpy(buf, g_kernel, n - 1);
+    buf[n - 1] = 0;
+  }
+  return (int)strlen(g_kernel);
+}
 
 // ---------------------------------------------------------------------------- K0
 static int eos_map_impl(const void* T, const void* S, int dtype, const double* p, int p_mode,
@@ -1574,6 +1630,33 @@ int mlx_stream_probe(const double* a, const double* b, int64_t n, double* out, v
   hipLaunchKernelGGL(k_stream_probe, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(kBlock), 0,
                      (hipStream_t)stream, a, b, n / 2, out);
   return hip_status(hipGetLastError(), "k_stream_probe launch");
+}
+
+int mlx_stream_probe_mix(const void* a, const void* b, int dtype, int64_t n, double* out,
+                         int write_out, void* stream) {
+  if (!a || !out) return fail(MLX_E_NULL, "a and out must not be NULL");
+  if (dtype != MLX_DTYPE_F64 && dtype != MLX_DTYPE_F32)
+    return fail(MLX_E_ENUM, "dtype must be MLX_DTYPE_F64 or MLX_DTYPE_F32");
+  const int vec = (dtype == MLX_DTYPE_F64) ? 2 : 4;
+  if (n <= 0 || n % vec) return fail(MLX_E_SHAPE, "n must be > 0 and a whole number of 16-byte packs");
+  if (!aligned(a, 16) || (b && !aligned(b, 16)) || !aligned(out, write_out ? 16 : 8))
+    return fail(MLX_E_ALIGN, "operands must be 16-byte aligned");
+  const int64_t npacks = n / vec;
+  const int64_t want = ceil_div(npacks, kBlock);
+  const dim3 grid((unsigned)(want < 65536 ? want : 65536));
+  hipStream_t st = (hipStream_t)stream;
+#define MLX_LAUNCH_PROBE(TIN, NIN, WRITE)                                                        \
+  hipLaunchKernelGGL((k_stream_probe_mix<TIN, NIN, WRITE>), grid, dim3(kBlock), 0, st,            \
+                     (const TIN*)a, (const TIN*)b, npacks, out)
+  if (dtype == MLX_DTYPE_F64) {
+    if (b) { if (write_out) MLX_LAUNCH_PROBE(double, 2, true); else MLX_LAUNCH_PROBE(double, 2, false); }
+    else { if (write_out) MLX_LAUNCH_PROBE(double, 1, true); else MLX_LAUNCH_PROBE(double, 1, false); }
+  } else {
+    if (b) { if (write_out) MLX_LAUNCH_PROBE(float, 2, true); else MLX_LAUNCH_PROBE(float, 2, false); }
+    else { if (write_out) MLX_LAUNCH_PROBE(float, 1, true); else MLX_LAUNCH_PROBE(float, 1, false); }
+  }
+#undef MLX_LAUNCH_PROBE
+  return hip_status(hipGetLastError(), "k_stream_probe_mix launch");
 }
 
 int mlx_synth_field(void* out, int dtype, int64_t nt, int64_t nz, int64_t ny, int64_t nx,

@@ -54,6 +54,74 @@ def init_from_env(backend=None):
     return rank, world, local_rank
 
 
+def rank_environments(n, environ=None, port=None, visible_gpus=None):
+    """The environments of ``n`` ranks of one node, as torch.distributed.run would set them:
+    RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_ADDR (127.0.0.1: the container
+    hostname may not resolve) / MASTER_PORT (a free port unless given).  With fewer visible GPUs than
+    ranks (``visible_gpus``; a rehearsal box) and no MOMLEVEL_AMD_DIST_BACKEND set, the ranks are
+    told to use gloo -- RCCL cannot put two ranks on one GPU."""
+    import socket
+
+    base = dict(os.environ if environ is None else environ)
+    if port is None:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                MASTER_PORT=str(port))
+    if (visible_gpus is not None and visible_gpus < n
+            and not base.get("MOMLEVEL_AMD_DIST_BACKEND")):
+        base["MOMLEVEL_AMD_DIST_BACKEND"] = "gloo"
+    return [dict(base, RANK=str(r), LOCAL_RANK=str(r)) for r in range(n)]
+
+
+def launch_local_ranks(n, argv, environ=None, visible_gpus=None, out=None, grace=30.0):
+    """Run ``argv`` as ``n`` fresh rank processes on this node and wait for them: rank 0's stdout is
+    relayed line by line to ``out`` (default sys.stdout), the other ranks' stdout goes to stderr.
+    Returns the worst exit code; when a rank fails, the survivors get ``grace`` seconds and are then
+    terminated (exactly the processes started here).  The CALLER must not have touched the GPU:
+    the ranks are children of this process (``python bench.py --gpus N`` without torchrun)."""
+    import subprocess
+    import sys
+    import threading
+    import time
+
+    out = sys.stdout if out is None else out
+    procs = []
+    try:
+        for env in rank_environments(n, environ, visible_gpus=visible_gpus):
+            first = env["RANK"] == "0"
+            # (file descriptor 2 itself: sys.stderr may be a capturing wrapper without one)
+            procs.append(subprocess.Popen(list(argv), env=env,
+                                          stdout=subprocess.PIPE if first else 2,
+                                          text=first or None))
+    except BaseException:
+        for p in procs:  # never leave half a job behind
+            p.kill()
+        raise
+
+    def relay():
+        for line in procs[0].stdout:
+            out.write(line)
+            out.flush()
+
+    pump = threading.Thread(target=relay, daemon=True)
+    pump.start()
+    deadline = None
+    while any(p.poll() is None for p in procs):
+        if deadline is None and any(p.poll() not in (None, 0) for p in procs):
+            deadline = time.time() + grace  # a rank died: the others are stuck in a collective
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            deadline = float("inf")
+        time.sleep(0.05)
+    pump.join(timeout=10)
+    codes = [p.returncode for p in procs]
+    return max((abs(c) for c in codes), default=0)
+
+
 def pack_partials(masso, volo, masso0, area_sum):
     """-> one float64 vector [masso(0..nt-1), volo, masso0, area_sum] on masso's device."""
     tail = torch.stack([

@@ -251,6 +251,11 @@ int mlx_last_error(char *buf, size_t n) {
   return (int)strlen(g_err);
 }
 
+int mlx_last_kernel(char *buf, size_t n) { /* the host build launches no kernels */
+  if (buf && n) buf[0] = 0;
+  return 0;
+}
+
 /* ---- K0 ------------------------------------------------------------------------------------- */
 static int eos_map_impl(const void *T, const void *S, int dtype, const double *p, int p_mode,
                         int eos, int func, double aux, int64_t nt, int64_t nz, int64_t plane,
@@ -529,6 +534,23 @@ int mlx_stream_probe(const double *a, const double *b, int64_t n, double *out, v
   if (!a || !b || !out) return fail(MLX_E_NULL, "a, b, out must not be NULL");
   if (n <= 0 || n % 2) return fail(MLX_E_SHAPE, "n must be > 0 and even");
   for (int64_t i = 0; i < n; ++i) out[i] = a[i] + b[i];
+  return 0;
+}
+
+int mlx_stream_probe_mix(const void *a, const void *b, int dtype, int64_t n, double *out,
+                         int write_out, void *stream) {
+  (void)stream;
+  if (!a || !out) return fail(MLX_E_NULL, "a and out must not be NULL");
+  if (dtype != MLX_DTYPE_F64 && dtype != MLX_DTYPE_F32)
+    return fail(MLX_E_ENUM, "dtype must be MLX_DTYPE_F64 or MLX_DTYPE_F32");
+  if (n <= 0 || n % (dtype == MLX_DTYPE_F64 ? 2 : 4))
+    return fail(MLX_E_SHAPE, "n must be > 0 and a whole number of 16-byte packs");
+  if (!write_out) return 0; /* the read-only probe leaves nothing behind */
+  for (int64_t i = 0; i < n; ++i) {
+    double r = (dtype == MLX_DTYPE_F64) ? ((const double *)a)[i] : (double)((const float *)a)[i];
+    if (b) r += (dtype == MLX_DTYPE_F64) ? ((const double *)b)[i] : (double)((const float *)b)[i];
+    out[i] = r;
+  }
   return 0;
 }
 

@@ -15,7 +15,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from momlevel_amd import core, hostio, synthetic  # noqa: E402
+from momlevel_amd import _lib, core, hostio, synthetic  # noqa: E402
 
 
 def main():
@@ -48,8 +48,9 @@ def main():
     k1 = lambda a, b, **kw: core.steric_global_masso(a, b, vol0, pres, skip_dry=False, **kw)  # noqa: E731
     dec = lambda **kw: core.steric_global_decomp(T, S, T[0], S[0], vol0, pres, skip_dry=False, **kw)  # noqa: E731
 
-    def k2(want, skip=False, **kw):
-        return core.steric_local(T, S, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=zi, deptho=dep,
+    def k2(want, skip=False, Tv=None, Sv=None, **kw):
+        return core.steric_local(T if Tv is None else Tv, S if Sv is None else Sv, rho0m, vol0[0],
+                                 pres, -1.0 / 1035.0, z_i=zi, deptho=dep,
                                  want_delta_rho=want, delta_rho_out=drho if want else None,
                                  eta_out=eta, skip_dry=skip, **kw)
 
@@ -77,12 +78,47 @@ def main():
          lambda: core.steric_global_masso(T, S, vol0, pres, skip_dry=True, arith="exact")),
         ("K2 local + delta_rho, dry lines skipped", 2 * B + 8, "k_steric_local",
          lambda: k2(True, skip=True)),
+        # the held-field instantiations of the local pass: what thermosteric(ds) / halosteric(ds)
+        # run with the default domain="local" (steric.py:150-166; examples/example.ipynb cell 6)
+        ("K2 local thermosteric + delta_rho", B + 8, "k_steric_local",
+         lambda: k2(True, Sv=S[0])),
+        ("K2 local halosteric + delta_rho", B + 8, "k_steric_local",
+         lambda: k2(True, Tv=T[0])),
+        ("K2 local thermosteric, eta only", B, "k_steric_local",
+         lambda: k2(False, Sv=S[0])),
     ]
+    # bench.py's keys for the same cases (its VALU roofline quotes these profiles' instruction counts)
+    f32 = a.dtype == "f32"
+    bench_keys = {
+        "K1 steric": "steric_global_exact" if not f32 else "faithful.steric",
+        "K1 thermosteric": "thermosteric_global_exact" if not f32 else "faithful.thermosteric",
+        "K1 halosteric": "halosteric_global_exact" if not f32 else "faithful.halosteric",
+        "K1 steric, fused arithmetic": "roofline" if not f32 else "faithful_fused.steric",
+        "K1 thermosteric, fused arithmetic": ("thermosteric_global" if not f32
+                                              else "faithful_fused.thermosteric"),
+        "K1 halosteric, fused arithmetic": ("halosteric_global" if not f32
+                                            else "faithful_fused.halosteric"),
+        "K1 all variants + heat, one pass": ("decomposition_one_pass_exact" if not f32
+                                             else "faithful.one_pass"),
+        "K1 all variants + heat, one pass, fused arithmetic": (
+            "decomposition_one_pass" if not f32 else "faithful_fused.one_pass"),
+        "K2 local eta only": "local_eta_only" if not f32 else "default.local_eta_only",
+        "K2 local + delta_rho": ("local_with_delta_rho_large_chunks" if not f32
+                                 else "default.local_with_delta_rho"),
+        "K2 all variants, one pass (3 x delta_rho + eta)": "local_decomposition_one_pass",
+        "K2 local thermosteric + delta_rho": ("local_thermosteric_with_delta_rho" if not f32
+                                              else "default.local_thermosteric_with_delta_rho"),
+        "K2 local halosteric + delta_rho": ("local_halosteric_with_delta_rho" if not f32
+                                            else "default.local_halosteric_with_delta_rho"),
+        "K2 local thermosteric, eta only": ("local_thermosteric_eta_only" if not f32
+                                            else "default.local_thermosteric_eta_only"),
+    }
     if a.plan_out:
         with open(a.plan_out, "w") as f:
             json.dump({"grid": [nx, ny, nz], "nt": nt, "dtype": a.dtype, "cells_per_launch": cells,
                        "cases": [{"case": c[0], "algorithmic_bytes_per_cell": c[1],
-                                  "kernel": c[2], "launches": a.reps + 1} for c in cases]}, f,
+                                  "kernel": c[2], "launches": a.reps + 1,
+                                  "bench_key": bench_keys.get(c[0])} for c in cases]}, f,
                       indent=1)
     for name, bpc, _kernel, fn in cases:
         fn()
@@ -96,7 +132,8 @@ def main():
             torch.cuda.synchronize()
             ms.append(e0.elapsed_time(e1))
         m = float(np.mean(ms))
-        print(json.dumps({"kernel": name, "cells_per_launch": cells, "algorithmic_bytes_per_cell": bpc,
+        print(json.dumps({"kernel": name, "instantiation": _lib.last_kernel(),
+                          "cells_per_launch": cells, "algorithmic_bytes_per_cell": bpc,
                           "mean_ms": round(m, 3), "Mcells/s": round(cells / m / 1e3, 1),
                           "GB/s": round(bpc * cells / m / 1e6, 1),
                           "frac_of_8TBs": round(bpc * cells / m / 1e6 / 8000.0, 4)}), flush=True)

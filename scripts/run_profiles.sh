@@ -5,7 +5,7 @@
 # condensed into profiles/ by scripts/summarize_rocprof.py and scripts/summarize_variants.py
 # (run those in the build container afterwards, or here).
 set -e -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 B=gpurun_out/prof_${TAG}

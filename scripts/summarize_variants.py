@@ -21,6 +21,20 @@ import sys
 MAIN = ("k_steric_global", "k_steric_local")
 
 
+def kernel_source_sha():
+    """sha256 (first 16 hex digits) of the HIP sources of the timed kernels -- the same files, in the
+    same order, as bench.py's kernel_source_sha()"""
+    import hashlib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for rel in ("momlevel_amd/csrc/momlevel_hip.hip", "momlevel_amd/csrc/eos_device.hpp",
+                "momlevel_amd/csrc/mlx_internal.hpp"):
+        with open(os.path.join(root, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def one(pattern):
     hits = sorted(glob.glob(pattern, recursive=True))
     return hits[0] if hits else None
@@ -54,6 +68,8 @@ def main(src, prefix):
     cells = plan["cells_per_launch"]
     summary = {
         "grid": "{}x{}x{}, nt={} resident, {}".format(*plan["grid"], plan["nt"], plan["dtype"]),
+        # bench.py quotes these instruction counts only while the kernel sources are the profiled ones
+        "kernel_source_sha": kernel_source_sha(),
         "cells_per_launch": cells,
         "notes": __doc__.split("Expects")[1].strip().replace("\n", " "),
         "kernels": [],
@@ -82,7 +98,8 @@ def main(src, prefix):
         if f:
             passes[tag] = chunk(by_dispatch(f, counter), plan)
     for i, c in enumerate(plan["cases"]):
-        k = {"kernel": c["case"], "algorithmic_bytes_per_cell": c["algorithmic_bytes_per_cell"]}
+        k = {"kernel": c["case"], "algorithmic_bytes_per_cell": c["algorithmic_bytes_per_cell"],
+             "bench_key": c.get("bench_key")}
         if tr:
             part = tr[i][1:] or tr[i]  # first launch of a case is the warm-up
             ms = sum(d["ns"] for d in part) / len(part) / 1e6

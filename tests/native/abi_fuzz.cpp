@@ -227,10 +227,14 @@ int main(int argc, char** argv) {
               "mlx_calc_dz");
         break;
       default:
-        if (rnd() % 2)
+        if (rnd() % 3 == 0)
           check(mlx_stream_probe((const double*)ptr(), (const double*)ptr(), dim(), (double*)ptr(),
                                  nullptr),
                 "mlx_stream_probe");
+        else if (rnd() % 2)
+          check(mlx_stream_probe_mix(ptr(), ptr(), dtype, dim(), (double*)ptr(), (int)(rnd() % 2),
+                                     nullptr),
+                "mlx_stream_probe_mix");
         else
           check(mlx_synth_field(ptr(), dtype, nt, nz, dim(), dim(), dim(), dim(), dim(), dim(),
                                 dim(), rnd(), small_enum(), -2.0, 34.0, (const double*)ptr(),

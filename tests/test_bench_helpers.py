@@ -57,3 +57,80 @@ def test_p_process_cpu_baseline_plumbing():
     assert line["cores"] == 2 and line["kind"] == "port" and line["unit"] == "Mcells/s"
     assert line["masso_max_rel_err_vs_gpu"] == 0.0  # the workers replay the same fields exactly
     assert "cpu" in line and line["value"] > 0
+
+
+def test_rank_environments_are_what_torchrun_would_set():
+    from momlevel_amd import parallel
+
+    envs = parallel.rank_environments(4, environ={"PATH": "/bin"}, port=29123, visible_gpus=8)
+    assert [e["RANK"] for e in envs] == ["0", "1", "2", "3"]
+    assert [e["LOCAL_RANK"] for e in envs] == ["0", "1", "2", "3"]
+    for e in envs:
+        assert e["WORLD_SIZE"] == e["LOCAL_WORLD_SIZE"] == "4"
+        assert e["MASTER_ADDR"] == "127.0.0.1" and e["MASTER_PORT"] == "29123"
+        assert e["PATH"] == "/bin" and "MOMLEVEL_AMD_DIST_BACKEND" not in e  # 8 GPUs: RCCL
+    # fewer GPUs than ranks: the rehearsal backend, unless the caller chose one
+    assert all(e["MOMLEVEL_AMD_DIST_BACKEND"] == "gloo"
+               for e in parallel.rank_environments(2, environ={}, visible_gpus=1))
+    assert all(e["MOMLEVEL_AMD_DIST_BACKEND"] == "nccl" for e in parallel.rank_environments(
+        2, environ={"MOMLEVEL_AMD_DIST_BACKEND": "nccl"}, visible_gpus=1))
+    # a free port is picked when none is given, the same for every rank
+    ports = {e["MASTER_PORT"] for e in parallel.rank_environments(3, environ={})}
+    assert len(ports) == 1 and 1024 < int(ports.pop()) < 65536
+
+
+def test_self_launcher_runs_the_ranks_and_relays_rank_zero():
+    """`python bench.py --gpus N` without torchrun: bench.py starts its own N rank processes
+    (parallel.launch_local_ranks) before touching the GPU.  Here the ranks are a two-line program
+    that does what bench.py's ranks do first -- parallel.init_from_env() -- and then all-reduces
+    its rank over gloo; rank 0 prints one JSON line."""
+    import io
+    import sys
+
+    from momlevel_amd import parallel
+
+    prog = (
+        "import json, os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from momlevel_amd import parallel\n"
+        "rank, world, local = parallel.init_from_env()\n"
+        "t = torch.tensor([float(rank + 1)]); dist.all_reduce(t)\n"
+        "print('noise from rank', rank) if rank else print(json.dumps({'n_gpus': world, "
+        "'sum': t.item(), 'backend': dist.get_backend()}), flush=True)\n"
+        "dist.barrier(); dist.destroy_process_group()\n"
+        "sys.exit(3 if (rank == 1 and os.environ.get('FAIL_RANK_1')) else 0)\n")
+    out = io.StringIO()
+    rc = parallel.launch_local_ranks(2, [sys.executable, "-c", prog], visible_gpus=0, out=out)
+    assert rc == 0
+    lines = [l for l in out.getvalue().splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"n_gpus": 2, "sum": 3.0, "backend": "gloo"}
+    assert "noise from rank 1" not in out.getvalue()  # only rank 0's stdout is relayed
+    # the worst rank's exit code is the launcher's
+    env = dict(os.environ, FAIL_RANK_1="1")
+    assert parallel.launch_local_ranks(2, [sys.executable, "-c", prog], environ=env,
+                                       visible_gpus=0, out=io.StringIO()) == 3
+
+
+def test_bench_main_becomes_the_launcher_before_any_gpu_call(monkeypatch):
+    """--gpus 2 without WORLD_SIZE: main() hands over to the launcher with its own command line and
+    never reaches require_device()"""
+    import sys
+
+    import pytest
+
+    seen = {}
+
+    def fake_launch(n, argv, visible_gpus=None, **kw):
+        seen.update(n=n, argv=argv, visible_gpus=visible_gpus)
+        return 0
+
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(bench.parallel, "launch_local_ranks", fake_launch)
+    monkeypatch.setattr(bench.core, "require_device",
+                        lambda: (_ for _ in ()).throw(AssertionError("GPU touched")))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--nt", "10", "--steps", "2"])
+    with pytest.raises(SystemExit) as exc:
+        bench.main()
+    assert exc.value.code == 0
+    assert seen["n"] == 2 and seen["argv"][1].endswith("bench.py")
+    assert seen["argv"][2:] == ["--gpus", "2", "--nt", "10", "--steps", "2"]

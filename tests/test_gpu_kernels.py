@@ -573,6 +573,22 @@ def test_stream_probe_adds():
     assert torch.equal(core.stream_probe(a, b), a + b)
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("two", [False, True])
+def test_stream_probe_mix(dtype, two):
+    """the probes with the other local passes' read:write mixes (mlx_stream_probe_mix): one or two
+    streams of either dtype in, one float64 stream out, or read-only (nothing written)"""
+    n = 4096 * 6 + 12  # whole 16-byte packs, ragged against the block size
+    a = torch.rand(n, dtype=dtype, device="cuda")
+    b = torch.rand(n, dtype=dtype, device="cuda") if two else None
+    want = a.double() + (b.double() if two else 0.0)
+    assert torch.equal(core.stream_probe_mix(a, b), want)
+    keep = torch.full((1,), 7.0, dtype=torch.float64, device="cuda")
+    assert core.stream_probe_mix(a, b, out=keep, write=False) is keep and keep.item() == 7.0
+    with pytest.raises(core.MomlevelHipError):
+        core.stream_probe_mix(a[:n - 1], None)  # not a whole number of packs
+
+
 # ---------------------------------------------------------------------------------------------
 # full-size launches (BASELINE.json configs[2] and configs[4]); memory is freed between them
 # ---------------------------------------------------------------------------------------------
