@@ -137,10 +137,28 @@ def valu_profiles():
     return found, sources
 
 
-def add_valu_roofline(line):
+def measure_valu_probe(dev):
+    """This box's float64 VALU issue rate, lane-instructions per second: mlx_valu_probe (nothing but
+    independent v_fma_f64 chains), best of three launches of ~10 ms."""
+    core.valu_probe(256, dev)
+    torch.cuda.synchronize(dev)
+    best = 0.0
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        n = core.valu_probe(4096, dev)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        best = max(best, n / (e0.elapsed_time(e1) * 1e-3))
+    return best
+
+
+def add_valu_roofline(line, f64_probe=None):
     """For every timed kernel the committed counter profile covers: VALU instructions per cell and
     the fraction of the chip's VALU issue peak that rate amounts to -- the roofline that bounds the
-    float32 and one-pass kernels (HBM traffic 1.03-1.08 x algorithmic, far below the HBM peak)."""
+    float32 and one-pass kernels (HBM traffic 1.03-1.08 x algorithmic, far below the HBM peak).
+    ``f64_probe``: the live float64 issue rate of this box (measure_valu_probe) -- the practical
+    ceiling, as stream_read_probe is for the HBM roofline."""
     instr, sources = valu_profiles()
     for key, per_cell in instr.items():
         node = line
@@ -155,8 +173,14 @@ def add_valu_roofline(line):
             continue
         node["valu_instr_per_cell"] = per_cell
         node["frac_of_valu_peak"] = round(per_cell * rate * 1e6 / VALU_PEAK_LANE_INSTR_PER_S, 4)
+        if f64_probe:
+            node["frac_of_f64_fma_probe"] = round(per_cell * rate * 1e6 / f64_probe, 4)
     line["valu_roofline"] = {
         "peak_lane_instr_per_s": VALU_PEAK_LANE_INSTR_PER_S,
+        "f64_fma_probe_lane_instr_per_s": f64_probe and round(f64_probe, -9),
+        "f64_fma_probe": "mlx_valu_probe: independent v_fma_f64 chains, nothing else -- this box's "
+                         "float64 issue ceiling (a v_rcp_f64 costs 3.3 such instructions, so a "
+                         "kernel with one reciprocal per cell saturates a little below 1.0)",
         "definition": "valu_instr_per_cell (SQ_INSTS_VALU x 64 / cells, committed profile of these "
                       "kernel sources) x cells/s / (256 CU x 4 SIMD x 16 lanes x 2.4 GHz)",
         "sources": sources or None,
@@ -532,7 +556,7 @@ def main():
             "eta_t0_is_zero": bool(out["eta"][0] == 0.0),
         }
         line.update(extras)
-        add_valu_roofline(line)
+        add_valu_roofline(line, measure_valu_probe(dev) if world == 1 else None)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -637,7 +661,9 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
     # block: one occupancy round per launch, 7 launches) and the largest the free HBM holds
     # (few launches: ramp and tail paid less often) -- VERDICT r2 weak #5.
     free, _ = torch.cuda.mem_get_info(dev)
-    big = int(min(nt, max(0, free - (6 << 30)) // (nz * ny * nx * 8)) // 16 * 16)
+    big = int(min(nt, max(0, free - (6 << 30)) // (nz * ny * nx * 8)))
+    # whole time blocks of every K2 instantiation (12 or 16 steps per thread at float64)
+    big = big // 48 * 48 if big >= 48 else big // 16 * 16
     if big >= 32:
         dbig = torch.empty((big, nz, ny, nx), dtype=torch.float64, device=dev)
         starts_b = range(0, nt - big + 1, big)
@@ -809,19 +835,20 @@ def local_held_timings(T, S, rho0m, vol0, pres, zi, dep, eta, dbuf, starts, step
             ms = _time(lambda: run(variant, want), reps=2)
             bpc = nin * B1 + (8 if want else 0)
             r = rate(ms, bpc, done)
-            pms = probe_ms(nin, want)
-            r["probe"] = (f"mlx_stream_probe_mix: {nin} x {'float64' if B1 == 8 else 'float32'} in"
-                          + (", 1 x float64 out" if want else ", read-only"))
-            r["probe_GB/s"] = round(bpc * done / pms / 1e6, 1)
-            r["frac_of_matching_probe"] = round(pms / ms, 4)
-            r["chunk_steps"], r["launches"] = steps, len(starts)
             if want:  # one slab against the oracle: the last step the run left in the buffer
+                # (before the probe below reuses the buffer)
                 Tn = T0n if variant == "halosteric" else hostio.to_host(T[t_chk])
                 Sn = S0n if variant == "thermosteric" else hostio.to_host(S[t_chk])
                 r["slab_bit_identical_to_oracle"] = local_slab_check(
                     o, Tn, Sn, rho0n, g, pn, hostio.to_host(dbuf[steps - 1]),
                     hostio.to_host(eta[t_chk]))
                 r["time_step_checked"] = int(t_chk)
+            pms = probe_ms(nin, want)
+            r["probe"] = (f"mlx_stream_probe_mix: {nin} x {'float64' if B1 == 8 else 'float32'} in"
+                          + (", 1 x float64 out" if want else ", read-only"))
+            r["probe_GB/s"] = round(bpc * done / pms / 1e6, 1)
+            r["frac_of_matching_probe"] = round(pms / ms, 4)
+            r["chunk_steps"], r["launches"] = steps, len(starts)
             key = "local_" + ("" if variant == "steric" else variant + "_") + (
                 "with_delta_rho" if want else "eta_only")
             out[key] = r
@@ -895,7 +922,8 @@ def f32_timings(vol0, pres, g, dev, nt, synth_kw):
     free, _ = torch.cuda.mem_get_info(dev)
     steps_d = int(min(nt, max(0, free - (6 << 30)) // (nz * ny * nx * 8)))
     if steps_d >= 6:
-        steps_d = steps_d // 6 * 6  # whole time blocks of the float32 K2 thread
+        steps_d = steps_d // 24 * 24 if steps_d >= 24 else steps_d // 6 * 6  # whole time blocks
+        # of every float32 K2 instantiation (6 or 8 steps per thread)
         dbuf = torch.empty((steps_d, nz, ny, nx), dtype=torch.float64, device=dev)
         out["default"].update(local_held_timings(
             T, S, rho0m, vol0, pres, zi, dep, eta, dbuf, range(0, nt - steps_d + 1, steps_d),

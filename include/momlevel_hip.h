@@ -43,7 +43,7 @@ extern "C" {
                              MLX_FLAG_FMA, MLX_FLAG_TCHUNK; MLX_P_FULL4D in K1/K2
                              3: mlx_build_kind; a NULL p (linear EOS) requires p_mode MLX_P_SCALAR
                              4: mlx_eos_map_promote (MLX_KIND_*); MLX_DTYPE_T32_S64 / _T64_S32 in K1/K2
-                             5: mlx_stream_probe_mix, mlx_last_kernel */
+                             5: mlx_stream_probe_mix, mlx_valu_probe, mlx_last_kernel */
 
 /* argument-error codes (negative) */
 #define MLX_E_NULL     (-1) /* a required pointer is NULL                      */
@@ -331,6 +331,13 @@ int mlx_stream_probe(const double *a, const double *b, int64_t n, double *out, v
  * bench.py reports each local instantiation as a fraction of the probe with ITS mix. */
 int mlx_stream_probe_mix(const void *a, const void *b, int dtype, int64_t n, double *out,
                          int write_out, void *stream);
+
+/* Measurement aid: the box's float64 vector-ALU issue rate.  Launches a kernel of nothing but
+ * independent v_fma_f64 chains (8192 blocks x 256 threads x 8 chains x iters) and stores the number
+ * of lane-instructions it issues in *lane_instructions (host memory); the caller times it.
+ * bench.py prices the instruction-issue-bound kernels (float32 inputs, exact held-field sums, the
+ * one-pass kernels) against this ceiling.  out: one double of device memory, left untouched. */
+int mlx_valu_probe(int64_t iters, double *out, int64_t *lane_instructions, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * Synthetic MOM6-shaped fields for bench.py and the full-size tests (not a

@@ -99,6 +99,7 @@ SIGNATURES = {
     "mlx_group_weighted_mean": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "mlx_stream_probe": (_int, [_vp, _vp, _i64, _vp, _vp]),
     "mlx_stream_probe_mix": (_int, [_vp, _vp, _int, _i64, _vp, _int, _vp]),
+    "mlx_valu_probe": (_int, [_i64, _vp, ctypes.POINTER(ctypes.c_int64), _vp]),
     "mlx_calc_dz": (_int, [_vp, _vp, _i64, _i64, _dbl, _dbl, _int, _int, _vp, _vp]),
     "mlx_synth_field": (
         _int,

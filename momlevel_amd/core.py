@@ -210,7 +210,9 @@ def eos_map(T, S, p, eos="wright", func="density", f32_mode="faithful", arith=No
     pt, p_mode = _pressure(p, nt, nz, ny, nx, T.device, allow4d=True)
     if dt in (DTYPE_T32_S64, DTYPE_T64_S32):
         # thetao and so of different dtypes: numpy's promotion per sub-expression is the promote
-        # kernel's job (one cell per thread over the broadcast operands)
+        # kernel's job (one cell per thread over the broadcast operands); exact arithmetic only --
+        # an explicit arith="fused" is an error here as it is in K1 / K2
+        _arith_flag(arith, "k0", dt)
         full = (nt, nz, ny, nx)
         ops = [(x if x.dim() == 4 else x.unsqueeze(0)).expand(full).reshape(-1) for x in (T, S)]
         if pt is not None and pt.numel() > 1:
@@ -418,6 +420,21 @@ def stream_probe_mix(a, b=None, out=None, write=True):
                                               int(bool(write)), _stream(a.device))
     _lib.check(rc, "mlx_stream_probe_mix")
     return out
+
+
+def valu_probe(iters=4096, device="cuda"):
+    """Measurement aid: enqueue the float64 VALU issue-rate probe (mlx_valu_probe) on ``device``'s
+    current stream; returns the number of v_fma_f64 lane-instructions the launch issues."""
+    require_device()
+    device = torch.device(device)
+    import ctypes
+
+    out = torch.zeros(1, dtype=torch.float64, device=device)
+    n = ctypes.c_int64(0)
+    with _on(device):
+        rc = _lib.load().mlx_valu_probe(int(iters), _ptr(out), ctypes.byref(n), _stream(device))
+    _lib.check(rc, "mlx_valu_probe")
+    return int(n.value)
 
 
 def fold_mask(rho0, vol0):

@@ -156,9 +156,22 @@ __device__ __forceinline__ double rcp_scale_free(double den, double& seed) {
   return __builtin_fma(e, y, y);    // v_div_fmas without the rescale
 }
 
+// Tuning switches of the fused policies (round 4; -DMLX_TUNE_...=0/1 in A/B builds):
+//   MLX_TUNE_BATCH_RCP  one v_rcp_f64 for the denominators of ONE CELL's three variants in the
+//                       one-pass kernels (quotients_batched below);
+//   MLX_TUNE_FMA_ACC    c = fma(rho, vol, c) under the "neither is NaN" mask instead of
+//                       term = rho*vol; c += term unless NaN (accumulate<> below).
+#ifndef MLX_TUNE_BATCH_RCP
+#define MLX_TUNE_BATCH_RCP 0
+#endif
+#ifndef MLX_TUNE_FMA_ACC
+#define MLX_TUNE_FMA_ACC 0
+#endif
+
 struct ExactOps {
   static constexpr bool fused = false;
   static constexpr bool guarded = false;
+  static constexpr bool contracts = false;  // may a*b + c be one fma outside the polynomial?
   // (operands may be a float2 vector mixed with scalar constants: the scalars splat)
   template <typename A, typename B, typename C>
   static __device__ __forceinline__ auto mad(A a, B b, C c) -> decltype(a * b + c) {
@@ -203,6 +216,7 @@ struct ExactFastF32Ops : ExactOps {  // float32-valued al0, p0, lam: the class o
 struct FusedOps {
   static constexpr bool fused = true;
   static constexpr bool guarded = false;
+  static constexpr bool contracts = true;
   template <typename R>
   static __device__ __forceinline__ R mad(R a, R b, R c) {
     return __builtin_fma(a, b, c);
@@ -231,6 +245,7 @@ struct FusedOps {
 struct FusedTailOps {
   static constexpr bool fused = false;  // no pressure folding: p enters in float64, as in numpy
   static constexpr bool guarded = false;
+  static constexpr bool contracts = true;  // the float64 tail
   template <typename A, typename B, typename C>
   static __device__ __forceinline__ auto mad(A a, B b, C c) -> decltype(a * b + c) {
     return a * b + c;  // the float32 polynomial: two roundings (contraction is off)
@@ -352,6 +367,45 @@ __device__ __forceinline__ void quotients(const double* num, const double* den, 
     }
   }
 }
+
+// The quotients of ONE CELL's N variants with a single reciprocal (fused policies only; Montgomery's
+// trick): r = 1/(d0*d1*...), 1/d_i = r * prod_{j != i} d_j, then FusedOps' exact-residual correction
+// per quotient -- N-1 v_rcp_f64 (15.5 cycles each) traded for 3(N-1) multiplications.  The
+// denominators of one cell's variants only: a denominator that is NaN (the cell's theta or S is
+// NaN in THAT variant) is replaced by 1.0 first, so that it cannot take the cell's other variants
+// with it -- its own quotient is NaN regardless, through its numerator.  (Across cells the trick
+// would let one bad cell corrupt its neighbours' results: not done.)  Wright denominators are
+// ~2^19..2^20: the product of three is far from overflow.
+template <int N>
+__device__ __forceinline__ void quotients_batched(const double* num, const double* den, double* out) {
+  double d[N], pre[N], inv[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) d[i] = __builtin_fmax(den[i], 1.0);  // qNaN -> 1.0 (IEEE maxNum)
+  pre[0] = d[0];
+#pragma unroll
+  for (int i = 1; i < N; ++i) pre[i] = pre[i - 1] * d[i];
+  double r = __builtin_amdgcn_rcp(pre[N - 1]);
+  r = __builtin_fma(__builtin_fma(-pre[N - 1], r, 1.0), r, r);
+#pragma unroll
+  for (int i = N - 1; i > 0; --i) {
+    inv[i] = r * pre[i - 1];
+    r = r * d[i];
+  }
+  inv[0] = r;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double q = num[i] * inv[i];
+    out[i] = __builtin_fma(__builtin_fma(-d[i], q, num[i]), inv[i], q);
+  }
+}
+
+// c += rho*vol unless the product is NaN (derived.py:435-438, skipna).  Policies that contract
+// (MLX_FLAG_FMA) take ONE fma under the mask "rho and vol are both numbers" -- two VALU
+// instructions (v_cmp_o_f64 rho, vol; v_fma_f64) instead of three (v_mul; v_cmp_o; v_add).  The
+// mask differs from "rho*vol is a number" only for inf * 0, which the fused policies do not
+// produce on anything resembling sea water (a zero denominator gives NaN there, not inf).
+template <typename Ops, bool PREDICATED>
+__device__ __forceinline__ void accumulate(double& c, double rho, double vol);
 
 // rho from the two parts: eos/wright.py:44-48.  out[i] = density of lane i (Lanes<R>::n cells)
 template <typename Ops, typename R>
@@ -622,6 +676,27 @@ __device__ __forceinline__ void add_skipna(double& c, double term) {
         : "vcc");
   } else {
     c += is_nan(term) ? 0.0 : term;
+  }
+}
+
+template <typename Ops, bool PREDICATED>
+__device__ __forceinline__ void accumulate(double& c, double rho, double vol) {
+  if constexpr (Ops::contracts && MLX_TUNE_FMA_ACC) {
+    if constexpr (PREDICATED) {
+      lanemask_t saved;
+      asm("v_cmp_o_f64 vcc, %2, %3\n\t"
+          "s_and_saveexec_b64 %1, vcc\n\t"
+          "v_fma_f64 %0, %2, %3, %0\n\t"
+          "s_mov_b64 exec, %1"
+          : "+v"(c), "=&s"(saved)
+          : "v"(rho), "v"(vol)
+          : "vcc");
+    } else {
+      const double s = __builtin_fma(rho, vol, c);
+      c = (rho == rho && vol == vol) ? s : c;
+    }
+  } else {
+    add_skipna<PREDICATED>(c, rho * vol);  // derived.py:435: the product, then the skipna sum
   }
 }
 

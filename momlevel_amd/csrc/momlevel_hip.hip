@@ -379,19 +379,34 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
           const TPart<RV> a = t_part<Ops, RV>(Lanes<RV>::make(&curT[u].v[g * W]));
           const SPart<RV> b = s_part<Ops, RV>(Lanes<RV>::make(&curS[u].v[g * W]), pfold);
           double r3[3][W];
-          wright_combine_lanes<Ops, RV>(a, b, pz, r3[0]);
-          wright_combine_lanes<Ops, RV>(a, s0p[u][g], pz, r3[1]);
-          wright_combine_lanes<Ops, RV>(t0p[u][g], b, pz, r3[2]);
+          if constexpr (Ops::contracts && MLX_TUNE_BATCH_RCP) {
+            // one reciprocal per cell for its three variants (eos_device.hpp quotients_batched)
+            double n3[3][W], d3[3][W];
+            wright_numden_lanes<Ops, RV>(a, b, pz, n3[0], d3[0]);
+            wright_numden_lanes<Ops, RV>(a, s0p[u][g], pz, n3[1], d3[1]);
+            wright_numden_lanes<Ops, RV>(t0p[u][g], b, pz, n3[2], d3[2]);
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+              const double nn[3] = {n3[0][w], n3[1][w], n3[2][w]};
+              const double dd[3] = {d3[0][w], d3[1][w], d3[2][w]};
+              double qq[3];
+              quotients_batched<3>(nn, dd, qq);
+              r3[0][w] = qq[0];
+              r3[1][w] = qq[1];
+              r3[2][w] = qq[2];
+            }
+          } else {
+            wright_combine_lanes<Ops, RV>(a, b, pz, r3[0]);
+            wright_combine_lanes<Ops, RV>(a, s0p[u][g], pz, r3[1]);
+            wright_combine_lanes<Ops, RV>(t0p[u][g], b, pz, r3[2]);
+          }
 #pragma unroll
           for (int w = 0; w < W; ++w) {
             const int k = g * W + w;
 #pragma unroll
-            for (int o = 0; o < 3; ++o) {
-              const double term = r3[o][w] * vol[u][k];
-              add_skipna<PRED>(c[o], term);
-            }
-            const double term = (double)curT[u].v[k] * vol[u][k];  // extension: heat content
-            add_skipna<PRED>(c[3], term);
+            for (int o = 0; o < 3; ++o) accumulate<Ops, PRED>(c[o], r3[o][w], vol[u][k]);
+            // extension: heat content
+            accumulate<Ops, PRED>(c[3], (double)curT[u].v[k], vol[u][k]);
           }
         }
         continue;
@@ -416,14 +431,9 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {  // cells in ascending order: the order of summation is fixed
 #pragma unroll
-        for (int o = 0; o < NR; ++o) {
-          const double term = rho[o][k] * vol[u][k];  // derived.py:435
-          add_skipna<PRED>(c[o], term);                     // skipna
-        }
-        if constexpr (VAR == kVarAll) {  // extension: heat-content integrand theta*vol0
-          const double term = (double)curT[u].v[k] * vol[u][k];
-          add_skipna<PRED>(c[3], term);
-        }
+        for (int o = 0; o < NR; ++o) accumulate<Ops, PRED>(c[o], rho[o][k], vol[u][k]);  // derived.py:435
+        if constexpr (VAR == kVarAll)  // extension: heat-content integrand theta*vol0
+          accumulate<Ops, PRED>(c[3], (double)curT[u].v[k], vol[u][k]);
       }
     }
     const int row = (t - tb) % NTC;
@@ -568,6 +578,26 @@ __global__ __launch_bounds__(kBlock) void k_stream_probe_mix(const TIn* __restri
   if constexpr (!WRITE) {
     if (sink == 0x1.23456789abcdep+1000) out[0] = sink;
   }
+}
+
+// VALU issue-rate probe: 8 independent chains of v_fma_f64 per thread and nothing else -- the
+// box's float64 vector-ALU ceiling in lane-instructions per second, against which bench.py prices
+// the kernels that are bound by instruction issue rather than by HBM (every float32 kernel, the
+// exact held-field sums, the one-pass kernels).  kValuProbeBlocks x 256 threads x 8 x iters fmas.
+constexpr int kValuProbeBlocks = 8192;
+__global__ __launch_bounds__(kBlock) void k_valu_probe(double* __restrict__ out, int iters,
+                                                       double x, double y) {
+  double a[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = (double)(threadIdx.x + k);
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = __builtin_fma(a[k], x, y);
+  }
+  double sink = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sink += a[k];
+  if (sink == 0x1.23456789abcdep+1000) out[0] = sink;  // never: keeps the chains alive
 }
 
 // ------------------------------------------------------------------------------------
@@ -1020,13 +1050,32 @@ constexpr int kTChunkHeld = 64;      // held-field variants and the all-variants
                                      // held field are re-read once per chunk -- at 8 B/cell that is
                                      // 10 % extra traffic with 32-step chunks; 64..120 steps measured
                                      // 1-3.5 % faster (profiles/r02_tune_tchunk.log), steric is flat
-constexpr int kNTI64 = 16;           // time steps per K2 thread, f64 (2 columns/thread); 8, 10
-                                     // (3 waves/SIMD) and 12 re-measured in round 3: within noise
-                                     // (profiles/r03_tune_k2_nti64_*.log)
-constexpr int kNTI32 = 6;            // f32 (4 columns/thread): 154 VGPRs = 3 waves/SIMD; 8 steps
-                                     // (186 VGPRs, 2 waves) measured 6 % slower on the eta-only pass,
-                                     // 4 steps slower with delta_rho (profiles/r03_tune_k2_nti32_*.log)
 constexpr int kNTIGen = 8;           // generic scalar path
+
+// Time steps per thread of the single-variant fast K2 kernels, chosen PER INSTANTIATION (round 4):
+// (float64 fields: 2 columns per thread, float32: 4), variant, and whether delta_rho is stored.
+// More steps amortise rho0m / dz / the held field over more cells and keep more bytes in flight per
+// wave; fewer steps need fewer registers (column sums + loads in flight) and run more waves per SIMD.
+// Never changes a result: every (time step, column) sum adds its levels in the same order.
+// Measured on one box, one process per library (scripts/ab_k2.py, profiles/r04_tune_k2_nti_*.log).
+// Tuning builds override the whole table: -DMLX_TUNE_NTI64=n / -DMLX_TUNE_NTI32=n.
+#ifndef MLX_TUNE_NTI64
+#define MLX_TUNE_NTI64 0
+#endif
+#ifndef MLX_TUNE_NTI32
+#define MLX_TUNE_NTI32 0
+#endif
+constexpr int k2_nti(bool f64, int var, bool drho) {
+  if (f64 && MLX_TUNE_NTI64) return MLX_TUNE_NTI64;
+  if (!f64 && MLX_TUNE_NTI32) return MLX_TUNE_NTI32;
+  // float64: 16 steps (8 and 12 measured 0-4 % slower) -- except the held-field passes WITHOUT
+  // delta_rho, 6 % faster at 12: half the streamed bytes of the steric pass per cell, so the
+  // occupancy (3 waves per SIMD instead of 2) weighs more than the amortisation.
+  // float32: 6 steps (3 waves per SIMD; 4 and 8 measured 3-10 % slower) -- except the held-field
+  // passes WITH delta_rho, 3-4 % faster at 8: two thirds of their traffic are the float64 stores.
+  if (f64) return (var != kVarSteric && !drho) ? 12 : 16;
+  return (var != kVarSteric && drho) ? 8 : 6;
+}
 
 constexpr int kKnownFlags = MLX_FLAG_SKIP_DRY | MLX_FLAG_FMA | MLX_FLAG_TCHUNK_MASK;
 
@@ -1262,8 +1311,17 @@ void k2_flags(const K2Args& a, bool skip, bool fma) {
   }
 }
 
-// NTI1: time steps per thread of the single-variant kernels; VEC3/NTI3: columns and time steps per
-// thread of the all-variants kernel (three sets of column sums in registers)
+// a single-variant fast kernel with the time steps per thread of its instantiation (k2_nti)
+template <typename TIn, int VEC, int VAR, int MODE>
+void k2_single(const K2Args& a, bool skip, bool fma) {
+  constexpr bool F64 = sizeof(TIn) == 8;
+  if (a.drho != nullptr) k2_flags<TIn, VEC, k2_nti(F64, VAR, true), VAR, MODE, false>(a, skip, fma);
+  else k2_flags<TIn, VEC, k2_nti(F64, VAR, false), VAR, MODE, false>(a, skip, fma);
+}
+
+// NTI1: time steps per thread of the generic single-variant kernel (the fast ones: k2_nti);
+// VEC3/NTI3: columns and time steps per thread of the all-variants kernel (three sets of column
+// sums in registers)
 template <typename TIn, int VEC, int NTI1, int VEC3, int NTI3, int MODE, bool GEN>
 void k2_var(const K2Args& a, int var, bool skip, bool fma) {
   if (var == kVarAll) {
@@ -1271,9 +1329,9 @@ void k2_var(const K2Args& a, int var, bool skip, bool fma) {
   } else if constexpr (GEN) {  // held fields reach the generic twin as stride-0 streams
     k2_flags<TIn, VEC, NTI1, kVarSteric, MODE, GEN>(a, skip, fma);
   } else {
-    if (var == kVarSteric) k2_flags<TIn, VEC, NTI1, kVarSteric, MODE, GEN>(a, skip, fma);
-    else if (var == kVarHalo) k2_flags<TIn, VEC, NTI1, kVarHalo, MODE, GEN>(a, skip, fma);
-    else k2_flags<TIn, VEC, NTI1, kVarThermo, MODE, GEN>(a, skip, fma);
+    if (var == kVarSteric) k2_single<TIn, VEC, kVarSteric, MODE>(a, skip, fma);
+    else if (var == kVarHalo) k2_single<TIn, VEC, kVarHalo, MODE>(a, skip, fma);
+    else k2_single<TIn, VEC, kVarThermo, MODE>(a, skip, fma);
   }
 }
 
@@ -1329,7 +1387,7 @@ int steric_local_impl(const void* T, const void* S, const void* T0, const void* 
   //  Neither is a default path.)
   const int v = !fast ? 1 : ((var == kVarAll && !f64) ? kVec32All : vec_of(dtype));
   const int nti = (var == kVarAll) ? (fast ? (f64 ? kNTI64All : kNTI32All) : kNTIGenAll)
-                                   : (fast ? (f64 ? kNTI64 : kNTI32) : kNTIGen);
+                                   : (fast ? k2_nti(f64, var, delta_rho_out != nullptr) : kNTIGen);
   if (ceil_div(nt, nti) > 65535) return fail(MLX_E_SHAPE, "nt too large for one call: chunk it");
   const int64_t gx = ceil_div(plane, (int64_t)kBlock * v);
   if (gx > 2147483647LL) return fail(MLX_E_SHAPE, "plane too large");
@@ -1342,10 +1400,10 @@ int steric_local_impl(const void* T, const void* S, const void* T0, const void* 
   a.nz = (int)nz; a.neg_inv_rhozero = neg_inv_rhozero; a.plane = plane; a.sT = sT; a.sS = sS;
   a.drho = delta_rho_out; a.eta = eta_out; a.drho_vstride = drho_vstride; a.eta_vstride = eta_vstride;
   if (fast) {
-    if (f64) k2_var<double, kVec64, kNTI64, kVec64, kNTI64All, kF64, false>(a, var, skip, fma);
+    if (f64) k2_var<double, kVec64, 0, kVec64, kNTI64All, kF64, false>(a, var, skip, fma);
     else if (dtype == MLX_DTYPE_F32)
-      k2_var<float, kVec32, kNTI32, kVec32All, kNTI32All, kF32Faithful, false>(a, var, skip, fma);
-    else k2_var<float, kVec32, kNTI32, kVec32All, kNTI32All, kF32Upcast, false>(a, var, skip, fma);
+      k2_var<float, kVec32, 0, kVec32All, kNTI32All, kF32Faithful, false>(a, var, skip, fma);
+    else k2_var<float, kVec32, 0, kVec32All, kNTI32All, kF32Upcast, false>(a, var, skip, fma);
   } else {
     if (f64) k2_var<double, 1, kNTIGen, 1, kNTIGenAll, kF64, true>(a, var, skip, fma);
     else if (dtype == MLX_DTYPE_F32)
@@ -1657,6 +1715,16 @@ int mlx_stream_probe_mix(const void* a, const void* b, int dtype, int64_t n, dou
   }
 #undef MLX_LAUNCH_PROBE
   return hip_status(hipGetLastError(), "k_stream_probe_mix launch");
+}
+
+int mlx_valu_probe(int64_t iters, double* out, int64_t* lane_instructions, void* stream) {
+  if (!out || !lane_instructions) return fail(MLX_E_NULL, "out and lane_instructions must not be NULL");
+  if (iters <= 0 || iters > (1 << 24)) return fail(MLX_E_SHAPE, "need 0 < iters <= 2^24");
+  if (!aligned(out, 8)) return fail(MLX_E_ALIGN, "out not 8-byte aligned");
+  *lane_instructions = (int64_t)kValuProbeBlocks * kBlock * 8 * iters;  // v_fma_f64, per lane
+  hipLaunchKernelGGL(k_valu_probe, dim3(kValuProbeBlocks), dim3(kBlock), 0, (hipStream_t)stream,
+                     out, (int)iters, 0.999999, 1.0e-6);
+  return hip_status(hipGetLastError(), "k_valu_probe launch");
 }
 
 int mlx_synth_field(void* out, int dtype, int64_t nt, int64_t nz, int64_t ny, int64_t nx,

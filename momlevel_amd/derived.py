@@ -167,6 +167,10 @@ def calc_volo(volcello):
     assert len(volcello.dims) == 3, "Expecting only 3 dimensions for volcello"
     dev = engine.device_of(volcello.data)
     total = core.nansum(engine.to_device(volcello.data, dev, torch.float64))
+    # numpy's sum of a float32 field is a float32: the float64 sum of the same values (mlx_nansum),
+    # rounded ONCE -- closer to the exact sum than numpy's own float32 accumulation
+    if engine.sum_dtype(volcello.data) == np.float32:
+        total = total.to(torch.float32)
     volo = DataArray(total if volcello.is_device else hostio.to_host(total), ())
     volo.attrs = {
         "standard_name": "sea_water_volume",

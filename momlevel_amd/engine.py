@@ -112,7 +112,11 @@ class TimeChunks:
         dt = _stream_dtype(f)
         src = f[t0:t1]
         if isinstance(src, torch.Tensor):
-            return src.to(device=self.device, dtype=dt), None
+            if src.is_cuda:  # (resident fields never come here; another GPU's tensor might)
+                return src.to(device=self.device, dtype=dt), None
+            # a CPU torch tensor is host memory like any numpy array: same staging path, same
+            # stream and event discipline (never the runtime's on-the-fly pinning of caller memory)
+            src = src.detach().contiguous().numpy()
         host = _host_tensor(src, np.float32 if dt == torch.float32 else np.float64)
         with torch.cuda.device(self.device):
             # the chunk belongs to the CONSUMER's stream (the caching allocator ties a block to the
@@ -263,11 +267,23 @@ def global_masso(T, S, vol0, pres, eos="wright", f32_mode="faithful", steps=None
 
 
 def global_finalize(masso, volo, rhoga, area_sum):
-    """steric.py:136-142 on host scalars / a (nt,) vector: (reference_height, eta(t))."""
+    """steric.py:136-142 on host scalars / a (nt,) vector: (reference_height, eta(t), expansion).
+    ``volo`` and ``area_sum`` keep the dtype they come in (numpy scalars / 0-d arrays): with float32
+    volcello and areacello -- what MOM6 writes -- numpy's ``volo / areacello.sum()`` is a float32
+    division and the reference height a float32, which then meets the float64 expansion coefficient
+    as a float64 factor; masso / volo and rhoga are float64 either way."""
     masso = np.asarray(masso, dtype=np.float64)
+    volo, area_sum = np.asarray(volo)[()], np.asarray(area_sum)[()]
     expansion_coeff = np.log(rhoga / (masso / volo))
     reference_height = volo / area_sum
     return reference_height, reference_height * expansion_coeff, expansion_coeff
+
+
+def sum_dtype(x):
+    """numpy's result dtype of ``x.sum()`` for a float field: float32 stays float32 (xarray's skipna
+    sum is np.sum(where(isnull, 0, x)) in the array's own dtype), anything else is float64 here."""
+    dt = x.dtype if hasattr(x, "dtype") else np.asarray(x).dtype
+    return np.float32 if str(dt) in ("torch.float32", "float32") else np.float64
 
 
 # ---------------------------------------------------------------------------------------

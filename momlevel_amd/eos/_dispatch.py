@@ -21,7 +21,8 @@ from .. import core, hostio
 
 def _as_tensor(x, device):
     if isinstance(x, torch.Tensor):
-        return x.to(device)
+        x = x.to(device)
+        return x if x.dtype in (torch.float32, torch.float64) else x.double()  # ints: see _kind
     a = np.asarray(x)
     if a.dtype not in (np.float32, np.float64):
         a = a.astype(np.float64)
@@ -36,13 +37,22 @@ def _is_weak(x):
 
 def _kind(x):
     """"weak" | "f32" | "f64": how the operand enters numpy's promotion (None for a missing p).
-    Anything that is not float32 computes as float64 (integer arrays, float16)."""
+    Integer and boolean ARRAYS compute as float64: numpy (2.x, NEP 50) promotes ``int_array *
+    python_float`` to float64 -- the python float is weak only among floats -- so every
+    sub-expression of such a field is float64, exactly as if it had been converted first (checked
+    against numpy for bool / int16 / uint8 / int32 / int64: tests/test_host_logic.py).  float16
+    arrays are refused: numpy would evaluate their part of the polynomial IN float16 (the weak
+    constants take the array's dtype), which no kernel here reproduces."""
     if x is None:
         return None
     if _is_weak(x):
         return "weak"
     dt = x.dtype if isinstance(x, torch.Tensor) else np.asarray(x).dtype
-    return "f32" if str(dt) in ("torch.float32", "float32") else "f64"
+    name = str(dt).replace("torch.", "")
+    if name in ("float16", "bfloat16", "half"):
+        raise TypeError(f"{name} operands are not supported: numpy evaluates their part of the "
+                        "equation of state in that precision; convert to float32 or float64")
+    return "f32" if name == "float32" else "f64"
 
 
 def _tuned_kernel_covers(kT, kS, kp, eos):

@@ -18,6 +18,7 @@ Nothing here computes: allocation, copies, stream ordering (torch as the device-
 """
 
 import os
+import threading
 
 import numpy as np
 import torch
@@ -28,11 +29,30 @@ RING_DEPTH = 3
 # below this size a transfer is latency-bound and travels through the runtime's own small staging
 # buffers (it never pins caller memory for less than a MiB)
 SMALL_BYTES = 256 << 10
-# the last page of a staging buffer is never handed to the DMA engine: a copy engine that reads a
-# little past the end of its source must find mapped memory there
+# the last 64 KiB of a staging buffer are never handed to the DMA engine.  A PRECAUTION, not the
+# remedy of an established cause: were a copy path ever to touch a little more than the bytes it was
+# asked to move, it would find mapped memory of ours there (the mechanism of the
+# two GPU page faults this project has seen was never determined)
 _SLACK = 64 << 10
 
 _rings = {}
+_rings_lock = threading.Lock()
+
+_range_log = None
+
+
+def _log_range(kind, ptr, nbytes):
+    """MOMLEVEL_AMD_TRANSFER_LOG=<file>: append the address range of every staging / result buffer
+    this module allocates and of every host array it is handed, line-buffered -- so that, should a
+    run abort with a GPU memory access fault, the faulting address can be matched to a transfer
+    (what round 3's log could not do)."""
+    global _range_log
+    path = os.environ.get("MOMLEVEL_AMD_TRANSFER_LOG")
+    if not path:
+        return
+    if _range_log is None or _range_log.name != path:
+        _range_log = open(path, "a", buffering=1)
+    _range_log.write(f"{kind} [{ptr:#x}, {ptr + nbytes:#x}) {nbytes} bytes\n")
 
 
 class _Ring:
@@ -52,14 +72,23 @@ class _Ring:
             self.events[i] = None
         if self.bufs[i] is None or self.bufs[i].numel() < PIECE_BYTES + _SLACK:
             self.bufs[i] = torch.empty(PIECE_BYTES + _SLACK, dtype=torch.uint8, pin_memory=True)
+            _log_range(f"staging ring buffer {i} (page-locked, ours)", self.bufs[i].data_ptr(),
+                       self.bufs[i].numel())
         return i, self.bufs[i]
 
 
 def _ring(device):
-    key = torch.device(device).index if torch.device(device).index is not None else -1
-    if key not in _rings:
-        _rings[key] = _Ring()
-    return _rings[key]
+    """The calling THREAD's staging ring for ``device``: a ring's cursor and buffer events are not
+    shareable, and to_device / to_host may be called from several user threads at once."""
+    key = (threading.get_ident(),
+           torch.device(device).index if torch.device(device).index is not None else -1)
+    with _rings_lock:
+        if key not in _rings:
+            alive = {t.ident for t in threading.enumerate()}
+            for dead in [k for k in _rings if k[0] not in alive]:
+                del _rings[dead]  # (its page-locked buffers go back to torch's pinned allocator)
+            _rings[key] = _Ring()
+        return _rings[key]
 
 
 def _bytes_view(t):
@@ -186,6 +215,7 @@ def upload(host, dev, stream=None, ring=None):
         return
     hb, db = _bytes_view(host), _bytes_view(dev)
     ring = ring if ring is not None else _ring(device)
+    _log_range("upload source (caller's memory: read by host memcpy only)", host.data_ptr(), nbytes)
     step = PIECE_BYTES // 8 * 8
     for off in range(0, nbytes, step):
         n = min(step, nbytes - off)
@@ -234,7 +264,9 @@ def pinned_array(shape, dtype=np.float64):
     nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
     if 0 < nbytes <= PINNED_RESULT_LIMIT:
         try:
-            return torch.empty(tuple(shape), dtype=tdt, pin_memory=True).numpy()
+            t = torch.empty(tuple(shape), dtype=tdt, pin_memory=True)
+            _log_range("result array (page-locked, ours)", t.data_ptr(), nbytes)
+            return t.numpy()
         except RuntimeError:
             pass
     return np.empty(shape, dtype=dtype)
@@ -256,9 +288,14 @@ def download_into(out, dev, stream=None):
             host.copy_(dev.reshape(host.shape), non_blocking=host.is_pinned())
             dev.record_stream(stream)
         return
-    src = dev.contiguous()
+    # (a non-contiguous `dev` is packed ON `stream`: the caller ordered `stream` behind the kernels
+    # that produced `dev`, and the piecewise copies below must not overtake the packing kernel)
+    with torch.cuda.stream(stream):
+        src = dev.contiguous()
     hb, db = _bytes_view(host), _bytes_view(src)
     ring = _ring(device)
+    _log_range("download destination (pageable: written by host memcpy only)", host.data_ptr(),
+               nbytes)
     step = PIECE_BYTES // 8 * 8
     pending = []  # (offset, n, buffer index): DMA enqueued, host copy-out still to do
 

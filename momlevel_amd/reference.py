@@ -88,7 +88,7 @@ def _setup(dset, patm, eos, coord_names, time_index, defer_masso):
                         dict(T0.coords, **({tcoord: dset[tcoord]} if tcoord in dset.variables
                                            else {})), rho_attrs)
         reference["rho"] = rho
-        volo_h = float(volo.item())
+        volo_h = engine.sum_dtype(V0.data)(volo.item())  # numpy: float32 volcello -> float32 volo
         masso_h = masso_t.cpu().numpy()
         masso_dims, masso_val = tdim, masso_h
         rhoga_val = masso_h / np.float64(volo_h)
@@ -99,7 +99,10 @@ def _setup(dset, patm, eos, coord_names, time_index, defer_masso):
         )
         rho = DataArray(rho0 if on_device else hostio.to_host(rho0), cdims, T0.coords, rho_attrs)
         reference["rho"] = rho.transpose(*reference["thetao"].dims)
-        volo_h = float(volo.item())
+        # derived.py:789: volcello.sum() has volcello's dtype -- float32 for the float32 volumes MOM6
+        # writes: the float64 device sum of the same values, rounded once; masso and
+        # rhoga = masso / volo are float64 in numpy too (rho is float64)
+        volo_h = engine.sum_dtype(V0.data)(volo.item())
         masso_h = float("nan") if masso0 is None else float(masso0.item())
         masso_dims, masso_val = (), np.array(masso_h)
         rhoga_val = np.array(np.float64(masso_h) / np.float64(volo_h))

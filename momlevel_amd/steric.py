@@ -94,16 +94,18 @@ def _global_results(ops, reference, variants, dtype, tcoord, coords_for, deferre
         # variant sees (theta0, S0) there, so any of them carries masso0 (same kernel, same bits)
         set_reference_masso(reference, masso[variants[0]][0])
     out = {}
+    # steric.py:138: reference["volo"] / reference["areacello"].sum() in numpy's dtypes -- a float32
+    # areacello sums to a float32 (numpy's own nansum of the 2-D field, on the host), a float32
+    # volcello gave a float32 volo (reference.py): then the reference height is a float32 too
+    area = reference["areacello"].sum().values
+    if area_total is not None:  # tiled run: the all-reduced sum, in the dtype numpy would give it
+        area = np.asarray(area_total, dtype=area.dtype)
     for v in variants:
         reference_height, sealevel, _expansion_coeff = engine.global_finalize(
-            masso[v],
-            np.float64(reference["volo"].values),
-            np.float64(reference["rhoga"].values),
-            np.float64(reference["areacello"].sum().values if area_total is None else area_total),
-        )
+            masso[v], reference["volo"].values, np.float64(reference["rhoga"].values), area)
         result = Dataset()
         result["reference_height"] = DataArray(
-            np.float64(reference_height), (), None,
+            np.asarray(reference_height), (), None,
             {"long_name": "Reference column height", "units": "m"},
         )
         result["reference_height"].encoding["dtype"] = dtype

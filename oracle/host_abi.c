@@ -554,6 +554,14 @@ int mlx_stream_probe_mix(const void *a, const void *b, int dtype, int64_t n, dou
   return 0;
 }
 
+int mlx_valu_probe(int64_t iters, double *out, int64_t *lane_instructions, void *stream) {
+  (void)stream; /* a device measurement aid: nothing to run on the host */
+  if (!out || !lane_instructions) return fail(MLX_E_NULL, "out and lane_instructions must not be NULL");
+  if (iters <= 0 || iters > (1 << 24)) return fail(MLX_E_SHAPE, "need 0 < iters <= 2^24");
+  *lane_instructions = (int64_t)8192 * 256 * 8 * iters;
+  return 0;
+}
+
 static inline uint64_t splitmix64(uint64_t x) {
   uint64_t z = x + 0x9E3779B97F4A7C15ULL;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;

@@ -150,7 +150,9 @@ def eos_func_from_str(eos_str, func_name="density"):
 # derived.py hot subset
 # ----------------------------------------------------------------------------
 def nansum(x, axis=None):
-    """xarray's default ``.sum()``: skipna=True, min_count=None => numpy.nansum."""
+    """xarray's default ``.sum()``: skipna=True, min_count=None => ``np.sum(where(isnull(x), 0, x))``
+    IN THE ARRAY'S OWN DTYPE, which is what numpy.nansum does -- so a float32 volcello / areacello
+    (what MOM6 writes) sums to a float32, accumulated in float32 (derived.py:789, steric.py:138)."""
     return np.nansum(x, axis=axis)
 
 

@@ -50,6 +50,25 @@ def main():
                                    core.steric_global_masso(T[0], S, vol0, pz, **kw)])
             res[tag + "_rows_equal_single_launches"] = bool(torch.equal(rows[:3], singles))
     res["steric_fused"] = best(lambda: core.steric_global_masso(T, S, vol0, pz, arith="fused", skip_dry=False))
+    res["thermo_fused"] = best(lambda: core.steric_global_masso(T, S[0], vol0, pz, arith="fused", skip_dry=False))
+    res["halo_fused"] = best(lambda: core.steric_global_masso(T[0], S, vol0, pz, arith="fused", skip_dry=False))
+    del T, S
+    torch.cuda.empty_cache()
+    # float32 theta/S in numpy's mixed precision, the global sums' default policy (fused tail)
+    T = core.synth_field(shape, torch.float32, seed=synthetic.SEED, field_id=1, lo=-2.0, scale=34.0, mask3d=vol0)
+    S = core.synth_field(shape, torch.float32, seed=synthetic.SEED, field_id=2, lo=30.0, scale=10.0, mask3d=vol0)
+    kw = dict(arith="fused", skip_dry=False)
+    res["f32_steric_fused"] = best(lambda: core.steric_global_masso(T, S, vol0, pz, **kw))
+    res["f32_thermo_fused"] = best(lambda: core.steric_global_masso(T, S[0], vol0, pz, **kw))
+    res["f32_halo_fused"] = best(lambda: core.steric_global_masso(T[0], S, vol0, pz, **kw))
+    res["f32_one_pass_fused"] = best(lambda: core.steric_global_decomp(T, S, T[0], S[0], vol0, pz, **kw))
+    rows = core.steric_global_decomp(T, S, T[0], S[0], vol0, pz, **kw)
+    singles = torch.stack([core.steric_global_masso(T, S, vol0, pz, **kw),
+                           core.steric_global_masso(T, S[0], vol0, pz, **kw),
+                           core.steric_global_masso(T[0], S, vol0, pz, **kw)])
+    res["f32_one_pass_fused_rows_equal_single_launches"] = bool(torch.equal(rows[:3], singles))
+    exact = core.steric_global_decomp(T, S, T[0], S[0], vol0, pz, arith="exact", skip_dry=False)
+    res["f32_fused_vs_exact_max_rel"] = float(((rows[:3] - exact[:3]).abs() / exact[:3].abs()).max().item())
     print(json.dumps(res), flush=True)
 
 

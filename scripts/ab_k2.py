@@ -54,6 +54,12 @@ def main():
             T, S, rho0m, vol0[0], pz, -1.0 / 1035.0, eta_out=eta, delta_rho_out=drho, **kw))
         res[f"{tag}_thermo_eta_only"] = best(lambda: core.steric_local(
             T, S[0], rho0m, vol0[0], pz, -1.0 / 1035.0, want_delta_rho=False, eta_out=eta, **kw))
+        res[f"{tag}_halo_eta_only"] = best(lambda: core.steric_local(
+            T[0], S, rho0m, vol0[0], pz, -1.0 / 1035.0, want_delta_rho=False, eta_out=eta, **kw))
+        res[f"{tag}_thermo_with_delta_rho"] = best(lambda: core.steric_local(
+            T, S[0], rho0m, vol0[0], pz, -1.0 / 1035.0, eta_out=eta, delta_rho_out=drho, **kw))
+        res[f"{tag}_halo_with_delta_rho"] = best(lambda: core.steric_local(
+            T[0], S, rho0m, vol0[0], pz, -1.0 / 1035.0, eta_out=eta, delta_rho_out=drho, **kw))
         res[f"{tag}_eta_only_skip_dry"] = best(lambda: core.steric_local(
             T, S, rho0m, vol0[0], pz, -1.0 / 1035.0, want_delta_rho=False, eta_out=eta,
             z_i=zi, deptho=dep, skip_dry=True))

@@ -231,6 +231,11 @@ int main(int argc, char** argv) {
           check(mlx_stream_probe((const double*)ptr(), (const double*)ptr(), dim(), (double*)ptr(),
                                  nullptr),
                 "mlx_stream_probe");
+        else if (rnd() % 4 == 0) {
+            int64_t n = 0;
+            check(mlx_valu_probe((int64_t)dim(), (double*)ptr(), corrupt() ? nullptr : &n, nullptr),
+                  "mlx_valu_probe");
+        }
         else if (rnd() % 2)
           check(mlx_stream_probe_mix(ptr(), ptr(), dtype, dim(), (double*)ptr(), (int)(rnd() % 2),
                                      nullptr),

@@ -1,6 +1,9 @@
 """GPU: libmomlevel_hip.so against the HOST build of the same ABI (oracle/libmomlevel_host.so) on
-identical inputs -- two independent implementations behind one header: pointwise outputs
-(rho, delta_rho, eta, dz) bit for bit, sums within 1e-12."""
+identical inputs -- two builder-authored implementations behind one header (separately written,
+except mlx_eos_map_promote: its host build compiles the product's own eos_promote.hpp): pointwise
+outputs (rho, delta_rho, eta, dz) bit for bit, sums within 1e-12.  A consistency check between the
+two builds; what pins either of them to the REFERENCE are the golden vectors (test_host_abi.py,
+test_gpu_wright.py, test_gpu_promote.py)."""
 
 import numpy as np
 import pytest

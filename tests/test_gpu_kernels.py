@@ -589,6 +589,20 @@ def test_stream_probe_mix(dtype, two):
         core.stream_probe_mix(a[:n - 1], None)  # not a whole number of packs
 
 
+def test_valu_probe_reports_its_instruction_count():
+    """mlx_valu_probe: 8192 blocks x 256 threads x 8 fma chains x iters lane-instructions, at a rate
+    of the order of the chip's float64 vector peak (256 CUs x 4 SIMDs x 16 lanes per clock)"""
+    assert core.valu_probe(16) == 8192 * 256 * 8 * 16
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    n = core.valu_probe(2048)
+    e1.record()
+    torch.cuda.synchronize()
+    rate = n / (e0.elapsed_time(e1) * 1e-3)
+    assert 5e12 < rate < 6e13, rate
+
+
 # ---------------------------------------------------------------------------------------------
 # full-size launches (BASELINE.json configs[2] and configs[4]); memory is freed between them
 # ---------------------------------------------------------------------------------------------

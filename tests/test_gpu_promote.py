@@ -110,6 +110,25 @@ def test_numpy_scalars_are_not_weak():
     assert type(got) is type(want) is np.float32 and got == want
 
 
+def test_integer_fields_compute_as_float64_and_float16_is_refused():
+    """numpy promotes ``int_array * python_float`` to float64 (the python float is weak only among
+    floats), so an integer or boolean field behaves like its float64 conversion in every
+    sub-expression -- here against numpy itself, with a float32 partner field and every pressure
+    kind.  float16 fields, whose part of the polynomial numpy would evaluate IN float16, raise."""
+    rng = np.random.default_rng(5)
+    S = rng.uniform(30, 40, (4, 6)).astype(np.float32)
+    for dt in (np.int16, np.uint8, np.int64, np.bool_):
+        T = rng.integers(0, 2 if dt is np.bool_ else 30, (4, 6)).astype(dt)
+        for p in (2.0e7, np.float32(2.0e7), np.full((4, 6), 2.0e7)):
+            for name, fn in ORACLE.items():
+                want = fn(T, S, p)
+                got = getattr(wright, name)(T, S, p)
+                assert got.dtype == want.dtype == np.float64, (dt, name)
+                assert_bit_equal(got, want, f"{name}, T {np.dtype(dt).name}")
+    with pytest.raises(TypeError, match="float16"):
+        wright.density(S.astype(np.float16), S, 2.0e7)
+
+
 def test_broadcasting_with_mixed_dtypes():
     """(time, z, y, x) float32 theta against a float64 (z, y, x) salinity slab and a float32
     (z, 1, 1) pressure profile: numpy's broadcasting and promotion together."""

@@ -188,6 +188,70 @@ def _masked_dataset(nt=6, nz=9, ny=14, nx=20, seed=7, dtype=np.float64):
     return d
 
 
+def test_float32_volumes_and_areas_take_numpys_result_dtypes():
+    """MOM6 writes volcello and areacello as float32 too.  numpy then sums them in float32
+    (derived.py:789 ``volcello.sum()``, steric.py:138 ``areacello.sum()``): ``volo`` is a float32,
+    ``reference_height = volo / areacello.sum()`` a float32 division, masso / rhoga stay float64 (rho
+    is float64) and the height series float64.  momlevel_amd returns the same dtypes; ``volo`` is
+    the float64 device sum of the same float32 values rounded ONCE -- closer to the exact sum than
+    numpy's own float32 accumulation (sequential over 8192-element blocks), hence a tolerance, not
+    bit equality: 2e-6 relative, at the OM4 1-degree size of BASELINE.json configs[1]."""
+    from momlevel_amd import derived, synthetic
+
+    nt, nz, ny, nx = 4, 75, 576, 360
+    g = synthetic.make_grid(ny, nx, nz)
+    mask = np.isnan(g["volcello"])
+    kw = dict(seed=synthetic.SEED, mask3d=g["volcello"])
+    d = Dataset()
+    d["time"] = DataArray(np.arange(nt, dtype=float), ("time",))
+    d["z_l"] = DataArray(g["z_l"], ("z_l",))
+    d["z_i"] = DataArray(g["z_i"], ("z_i",))
+    dims = ("time", "z_l", "yh", "xh")
+    d["thetao"] = DataArray(synthetic.field_numpy((nt, nz, ny, nx), field_id=1, lo=-2.0, scale=34.0,
+                                                  **kw).astype(np.float32), dims)
+    d["so"] = DataArray(synthetic.field_numpy((nt, nz, ny, nx), field_id=2, lo=30.0, scale=10.0,
+                                              **kw).astype(np.float32), dims)
+    vol32 = g["volcello"].astype(np.float32)
+    d["volcello"] = DataArray(np.broadcast_to(vol32, (nt, nz, ny, nx)), dims)
+    d["areacello"] = DataArray(g["areacello"].astype(np.float32), ("yh", "xh"))
+    d["deptho"] = DataArray(g["deptho"], ("yh", "xh"))
+    assert not mask.all()
+
+    gres, gref = steric(d, domain="global")
+    ores, oref = _oracle(d, domain="global")  # numpy on the same float32 arrays
+    # dtypes: what numpy gives
+    assert oref["volo"].dtype == np.float32 and ores["reference_height"].dtype == np.float32
+    assert gref["volo"].values.dtype == np.float32
+    assert gres["reference_height"].values.dtype == np.float32
+    for name in ("masso", "rhoga"):
+        assert gref[name].values.dtype == oref[name].dtype == np.float64
+    assert gres["steric"].values.dtype == ores["steric"].dtype == np.float64
+    assert derived.calc_volo(gref["volcello"]).values.dtype == np.float32
+    assert derived.calc_volo(gref["volcello"]).values == gref["volo"].values
+    # values: float64 sum rounded once vs numpy's float32 accumulation
+    exact = np.nansum(vol32.astype(np.float64))
+    assert gref["volo"].values == np.float32(exact)  # the correctly rounded sum
+    assert abs(float(gref["volo"].values) - float(oref["volo"])) <= 2e-6 * exact
+    assert_rel(gres["reference_height"].values, ores["reference_height"], 2e-6, "reference_height")
+    assert_rel(gref["masso"].values, oref["masso"], RTOL_SUM, "masso")  # float64 in both
+    assert_rel(gref["rhoga"].values, oref["rhoga"], 2e-6, "rhoga")
+    assert float(gres["steric"][0]) == 0.0 and float(ores["steric"][0]) == 0.0
+    scale = np.max(np.abs(ores["steric"]))
+    assert scale > 0 and np.max(np.abs(gres["steric"].values - ores["steric"])) <= 2e-6 * scale
+    # the local results do not depend on the volumes' values (the volume only masks): bit-identical
+    sub = d.isel({"time": slice(0, 2)})
+    res, _ = steric(sub)
+    lres, _ = _oracle(sub)
+    assert_bit_equal(res["steric"].values, lres["steric"], "local eta, float32 volcello")
+    assert_bit_equal(res["delta_rho"].values, lres["delta_rho"], "delta_rho, float32 volcello")
+    # float64 volumes with a float32 areacello (and the other way round): numpy's promotion
+    d64 = d.copy()
+    d64["volcello"] = DataArray(np.broadcast_to(g["volcello"], (nt, nz, ny, nx)), dims)
+    r64, ref64 = steric(d64.isel({"time": slice(0, 2)}), domain="global")
+    assert ref64["volo"].values.dtype == np.float64
+    assert r64["reference_height"].values.dtype == np.float64  # float64 / float32 -> float64
+
+
 @pytest.mark.parametrize("variant", ["steric", "thermosteric", "halosteric"])
 @pytest.mark.parametrize("shape", [(6, 9, 14, 20), (3, 5, 7, 9), (17, 4, 6, 16)])
 def test_land_masked_local_and_global(variant, shape):
@@ -522,6 +586,72 @@ def test_uploads_and_downloads_go_through_owned_staging(monkeypatch):
     ring = next(iter(hostio._rings.values()))
     assert all(b is None or b.is_pinned() for b in ring.bufs)
     assert not torch.from_numpy(d["thetao"].values).is_pinned()
+
+
+def test_product_moves_bulk_data_through_owned_pinned_memory_only(monkeypatch):
+    """The stock transfer path, instrumented: inside this test torch's own ``.cpu()`` / ``.cuda()``
+    are in place (the session fixture's rerouting is off) and every host<->device move that goes
+    through a Python-level tensor method -- ``copy_``, ``cpu``, ``cuda``, ``to`` -- is recorded.
+    steric() on host numpy inputs of 88 MiB per field, both domains, several time chunks: every
+    transfer of 256 KiB or more must have page-locked memory OF OURS on its host side (the product
+    never hands the runtime a pageable source or destination it would have to map on the fly), and
+    the caller's arrays are never page-locked.  A spy, run once -- not an attempt to provoke the
+    round-3 fault."""
+    import conftest
+    from momlevel_amd import engine, hostio
+
+    stock_cpu, stock_cuda = conftest.stock_transfers()
+    real_copy, real_to = torch.Tensor.copy_, torch.Tensor.to
+    seen = []  # (method, bytes, host side page-locked?)
+
+    def note(method, host):
+        seen.append((method, host.numel() * host.element_size(), bool(host.is_pinned())))
+
+    def copy_(self, src, *a, **k):
+        if isinstance(src, torch.Tensor) and self.is_cuda != src.is_cuda:
+            note("copy_", src if self.is_cuda else self)
+        return real_copy(self, src, *a, **k)
+
+    def cpu(self, *a, **k):
+        if self.is_cuda:
+            seen.append(("cpu", self.numel() * self.element_size(), False))  # pageable result
+        return stock_cpu(self, *a, **k)
+
+    def cuda(self, *a, **k):
+        if not self.is_cuda:
+            note("cuda", self)
+        return stock_cuda(self, *a, **k)
+
+    def to(self, *a, **k):
+        out = real_to(self, *a, **k)
+        if out.is_cuda != self.is_cuda:
+            if self.is_cuda:
+                seen.append(("to", self.numel() * self.element_size(), False))
+            else:
+                note("to", self)
+        return out
+
+    for name, fn in (("copy_", copy_), ("cpu", cpu), ("cuda", cuda), ("to", to)):
+        monkeypatch.setattr(torch.Tensor, name, fn)
+    monkeypatch.setattr(engine, "chunk_steps", lambda nt, b, dev, budget_bytes=None: 3)
+
+    d = _masked_dataset(nt=8, nz=20, ny=240, nx=288)  # 88 MiB per field
+    assert d["thetao"].values.nbytes >= 64 << 20
+    res, ref = steric(d)
+    gres, _ = steric(d, domain="global")
+    torch.cuda.synchronize()
+    monkeypatch.undo()
+    big = [(m, n, pinned) for m, n, pinned in seen if n >= hostio.SMALL_BYTES]
+    assert len(big) >= 8, seen  # uploads in 64 MiB pieces + result downloads: the spy saw them
+    assert all(pinned for _, _, pinned in big), [b for b in big if not b[2]]
+    assert sum(n for _, n, _ in big) >= 2 * 2 * d["thetao"].values.nbytes  # theta and S, twice
+    for k in ("thetao", "so", "volcello"):
+        assert not torch.from_numpy(np.ascontiguousarray(d[k].values)).is_pinned()
+    # and the numbers are the reference's
+    ores, _ = _oracle(d)
+    assert_bit_equal(res["steric"].values, ores["steric"], "local eta")
+    assert_bit_equal(res["delta_rho"].values, ores["delta_rho"], "delta_rho")
+    assert float(gres["steric"][0]) == 0.0
 
 
 def test_leading_one_pressure_with_several_time_chunks():

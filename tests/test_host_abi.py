@@ -1,6 +1,7 @@
 """CPU: the HOST build of the C ABI (oracle/host_abi.c -> libmomlevel_host.so).
 
-A second, independent restatement of the path in plain C behind the SAME header as the HIP
+A second restatement of the path in plain C (independent of the device code except for
+mlx_eos_map_promote, whose host build compiles the product's own eos_promote.hpp) behind the SAME header as the HIP
 library.  Pinned here against (1) the vectors the reference's own eos/wright.py produced
 (tests/golden/wright_vectors.npz) -- bit for bit, float64 and float32 mixed precision, all five
 functions, broadcast held fields; (2) the reference's goldens through the numpy oracle's steric();

@@ -334,3 +334,27 @@ def test_leading_one_pressure_is_not_time_dependent():
     assert not engine.time_dependent(np.zeros((5, 4, 3)))
     p = np.arange(5.0).reshape(1, 5, 1, 1)
     assert engine.pressure_chunk(p, 2, 4, None) is p
+
+
+def test_operand_kinds_follow_numpys_promotion():
+    """eos/_dispatch._kind: python scalars are weak, float32 arrays float32, and integer / boolean
+    arrays float64 -- numpy promotes ``int_array * python_float`` to float64, so a field of integers
+    behaves exactly like its float64 conversion (checked here against numpy itself on the oracle's
+    op-for-op Wright expression); float16 arrays, whose part numpy would evaluate in float16, are
+    refused"""
+    import pytest
+
+    from momlevel_amd.eos import _dispatch
+    from oracle import momlevel_numpy as o
+
+    S = np.array([35.0, 34.5], np.float32)
+    assert _dispatch._kind(3.5) == "weak" and _dispatch._kind(S) == "f32"
+    assert _dispatch._kind(np.float32(1.0)) == "f32" and _dispatch._kind(np.float64(1.0)) == "f64"
+    for dt in (np.bool_, np.int16, np.uint8, np.int32, np.int64):
+        T = np.array([10, 1]).astype(dt)
+        assert (T * 3.5).dtype == np.float64  # the premise
+        assert _dispatch._kind(T) == "f64"
+        got, want = o.wright_density(T, S, 2.0e7), o.wright_density(T.astype(np.float64), S, 2.0e7)
+        assert got.dtype == want.dtype == np.float64 and np.array_equal(got, want)
+    with pytest.raises(TypeError, match="float16"):
+        _dispatch._kind(np.array([10.0], np.float16))
