@@ -156,16 +156,16 @@ __device__ __forceinline__ double rcp_scale_free(double den, double& seed) {
   return __builtin_fma(e, y, y);    // v_div_fmas without the rescale
 }
 
-// Tuning switches of the fused policies (round 4; -DMLX_TUNE_...=0/1 in A/B builds):
-//   MLX_TUNE_BATCH_RCP  one v_rcp_f64 for the denominators of ONE CELL's three variants in the
-//                       one-pass kernels (quotients_batched below);
-//   MLX_TUNE_FMA_ACC    c = fma(rho, vol, c) under the "neither is NaN" mask instead of
-//                       term = rho*vol; c += term unless NaN (accumulate<> below).
-#ifndef MLX_TUNE_BATCH_RCP
-#define MLX_TUNE_BATCH_RCP 0
-#endif
+// MLX_TUNE_FMA_ACC (round 4, default on; -DMLX_TUNE_FMA_ACC=0 in A/B builds): the contracting
+// policies accumulate c = fma(rho, vol, c) under the "neither is NaN" mask instead of
+// term = rho*vol; c += term unless NaN (accumulate<> below): -1 VALU instruction per cell and sum,
+// 2-3 % on the instruction-issue-bound kernels (profiles/r04_tune_k1_fused.log).
+// (Also measured in round 4 and NOT adopted: one v_rcp_f64 for the three denominators of a cell in
+// the one-pass kernels -- Montgomery's trick, 16 reciprocals fewer and 24 multiplications / maxima
+// more per 8 cells, 0.4-1.3 % faster, and a denominator from one bad cell or variant would reach
+// the others: profiles/r04_batched_reciprocal_negative.txt.)
 #ifndef MLX_TUNE_FMA_ACC
-#define MLX_TUNE_FMA_ACC 0
+#define MLX_TUNE_FMA_ACC 1
 #endif
 
 struct ExactOps {
@@ -184,6 +184,8 @@ struct ExactOps {
   }
   // lanes that must not take this policy's fast quotient at pressure p (a wave-uniform property)
   static __device__ __forceinline__ lanemask_t p_unsafe(double) { return 0; }
+  // the same for a pressure that differs from lane to lane (MLX_P_FULL3D in the fast kernels)
+  static __device__ __forceinline__ lanemask_t p_unsafe_lanes(double) { return 0; }
 };
 
 // ExactOps with the scale-free reciprocal: the SAME bits as ExactOps while no lane objects.  The
@@ -206,10 +208,15 @@ struct ExactFastF32Ops : ExactOps {  // float32-valued al0, p0, lam: the class o
     unsafe |= lanes_not_nan_nor_normal(seed);
     return num * r;
   }
-  static __device__ __forceinline__ lanemask_t p_unsafe(double p) {
+  static __device__ __forceinline__ bool p_ok(double p) {
     const double a = __builtin_fabs(p);
-    const bool ok = !(a > 0x1p+800) && !(a < 0x1p-200 && p != 0.0);  // NaN: every result is NaN anyway
-    return ok ? 0 : ~(lanemask_t)0;
+    return !(a > 0x1p+800) && !(a < 0x1p-200 && p != 0.0);  // NaN: every result is NaN anyway
+  }
+  static __device__ __forceinline__ lanemask_t p_unsafe(double p) {
+    return p_ok(p) ? 0 : ~(lanemask_t)0;
+  }
+  static __device__ __forceinline__ lanemask_t p_unsafe_lanes(double p) {
+    return __builtin_amdgcn_ballot_w64(!p_ok(p));  // (once per thread and level, not per cell)
   }
 };
 
@@ -234,6 +241,7 @@ struct FusedOps {
     return __builtin_fma(__builtin_fma(-den, q, num), r, q);  // exact residual: <= 1 ulp
   }
   static __device__ __forceinline__ lanemask_t p_unsafe(double) { return 0; }
+  static __device__ __forceinline__ lanemask_t p_unsafe_lanes(double) { return 0; }
 };
 
 // MLX_FLAG_FMA on float32 theta/S in numpy's mixed precision (MLX_DTYPE_F32): the POLYNOMIAL stays
@@ -257,6 +265,7 @@ struct FusedTailOps {
     return FusedOps::quotient(num, den, m);
   }
   static __device__ __forceinline__ lanemask_t p_unsafe(double) { return 0; }
+  static __device__ __forceinline__ lanemask_t p_unsafe_lanes(double) { return 0; }
 };
 
 // the policy of MLX_FLAG_FMA for a dtype mode
@@ -331,18 +340,28 @@ __device__ __forceinline__ SPart<R> s_part(R S, R p_fold) {
 
 // numerator (p + p0) and denominator (lam + al0*(p + p0)) of the density from the two parts,
 // eos/wright.py:44-47, for the Lanes<R>::n cells of one arithmetic group
+// (p: one pressure per lane of the group -- the level's for every lane, or each cell's own when the
+// pressure is a (z,y,x) field)
 template <typename Ops, typename R>
-__device__ __forceinline__ void wright_numden_lanes(const TPart<R>& a, const SPart<R>& b, double p,
-                                                    double* num, double* den) {
+__device__ __forceinline__ void wright_numden_lanes(const TPart<R>& a, const SPart<R>& b,
+                                                    const double* p, double* num, double* den) {
   const R al0 = a.a01 + b.a2s;
   const R p0 = Ops::mad(a.t, a.tb + b.b5s, b.b04);
   const R lam = Ops::mad(a.t, a.tc + b.c5s, b.c04);
 #pragma unroll
   for (int i = 0; i < Lanes<R>::n; ++i) {
     if constexpr (Ops::fused) num[i] = Lanes<R>::get(p0, i);  // p is inside b04
-    else num[i] = p + Lanes<R>::get(p0, i);
+    else num[i] = p[i] + Lanes<R>::get(p0, i);
     den[i] = Ops::mad(Lanes<R>::get(al0, i), num[i], Lanes<R>::get(lam, i));  // lam + al0*(p+p0)
   }
+}
+template <typename Ops, typename R>
+__device__ __forceinline__ void wright_numden_lanes(const TPart<R>& a, const SPart<R>& b, double p,
+                                                    double* num, double* den) {
+  double pl[Lanes<R>::n];
+#pragma unroll
+  for (int i = 0; i < Lanes<R>::n; ++i) pl[i] = p;
+  wright_numden_lanes<Ops, R>(a, b, pl, num, den);
 }
 
 // out[i] = num[i] * (1/den[i]) (eos/wright.py:47-48) for a batch of N cells of one thread.  A
@@ -365,37 +384,6 @@ __device__ __forceinline__ void quotients(const double* num, const double* den, 
       for (int i = 0; i < N; ++i) out[i] = SlowOf<Ops>::type::quotient(num[i], den[i], unsafe);
       asm volatile("; end of fallback" ::);
     }
-  }
-}
-
-// The quotients of ONE CELL's N variants with a single reciprocal (fused policies only; Montgomery's
-// trick): r = 1/(d0*d1*...), 1/d_i = r * prod_{j != i} d_j, then FusedOps' exact-residual correction
-// per quotient -- N-1 v_rcp_f64 (15.5 cycles each) traded for 3(N-1) multiplications.  The
-// denominators of one cell's variants only: a denominator that is NaN (the cell's theta or S is
-// NaN in THAT variant) is replaced by 1.0 first, so that it cannot take the cell's other variants
-// with it -- its own quotient is NaN regardless, through its numerator.  (Across cells the trick
-// would let one bad cell corrupt its neighbours' results: not done.)  Wright denominators are
-// ~2^19..2^20: the product of three is far from overflow.
-template <int N>
-__device__ __forceinline__ void quotients_batched(const double* num, const double* den, double* out) {
-  double d[N], pre[N], inv[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) d[i] = __builtin_fmax(den[i], 1.0);  // qNaN -> 1.0 (IEEE maxNum)
-  pre[0] = d[0];
-#pragma unroll
-  for (int i = 1; i < N; ++i) pre[i] = pre[i - 1] * d[i];
-  double r = __builtin_amdgcn_rcp(pre[N - 1]);
-  r = __builtin_fma(__builtin_fma(-pre[N - 1], r, 1.0), r, r);
-#pragma unroll
-  for (int i = N - 1; i > 0; --i) {
-    inv[i] = r * pre[i - 1];
-    r = r * d[i];
-  }
-  inv[0] = r;
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const double q = num[i] * inv[i];
-    out[i] = __builtin_fma(__builtin_fma(-d[i], q, num[i]), inv[i], q);
   }
 }
 
@@ -673,7 +661,9 @@ __device__ __forceinline__ void add_skipna(double& c, double term) {
         "s_mov_b64 exec, %1"
         : "+v"(c), "=&s"(saved)
         : "v"(term)
-        : "vcc");
+        : "vcc", "scc");  // (s_and_saveexec also writes SCC: the compiler must not keep a
+                          //  compare's result live across this block -- found in round 4 when the
+                          //  fma form below moved an s_cmp ... s_cselect pair around such a block)
   } else {
     c += is_nan(term) ? 0.0 : term;
   }
@@ -690,7 +680,7 @@ __device__ __forceinline__ void accumulate(double& c, double rho, double vol) {
           "s_mov_b64 exec, %1"
           : "+v"(c), "=&s"(saved)
           : "v"(rho), "v"(vol)
-          : "vcc");
+          : "vcc", "scc");
     } else {
       const double s = __builtin_fma(rho, vol, c);
       c = (rho == rho && vol == vol) ? s : c;

@@ -173,7 +173,11 @@ __device__ __forceinline__ double wave_sum(double v) {
 // ------------------------------------------------------------------------------------
 constexpr int kVarSteric = 0, kVarHalo = 1, kVarThermo = 2, kVarAll = 3;
 
-template <typename TIn, int VEC, int U, int VAR, int MODE, bool GENERIC, bool SKIP, bool FMA>
+// P3D (fast kernels only): the pressure is a (z,y,x) FIELD (MLX_P_FULL3D: `patm` given as a (yh,xh)
+// DataArray, steric.py:58-60,96) -- each thread keeps its cells' pressures in registers beside vol0,
+// read once with the same 16-byte loads; everything else is the z-profile kernel.
+template <typename TIn, int VEC, int U, int VAR, int MODE, bool GENERIC, bool SKIP, bool FMA,
+          bool P3D = false>
 __global__ __launch_bounds__(kBlock) void k_steric_global(
     const TIn* __restrict__ T, const TIn* __restrict__ S, const TIn* __restrict__ T0,
     const TIn* __restrict__ S0, const double* __restrict__ vol0, const double* __restrict__ p,
@@ -233,18 +237,34 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
       any_wet = any_wet || !is_nan(vol[u][k]);
     }
     alive[u] = !SKIP || any_wet;
-    if (GENERIC && p_mode == MLX_P_FULL3D) {
+    if ((GENERIC && p_mode == MLX_P_FULL3D) || P3D) {
       Pack<double, VEC> q = load_pack<double, VEC>(p + off[u]);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) pc[u][k] = q.v[k];
     }
   }
+  static_assert(!(P3D && GENERIC), "P3D is the fast kernels' form of MLX_P_FULL3D");
+  static_assert(!Ops::fused || W == 1, "pressure folding is per cell");
   double pz = 0.0;
-  if (!GENERIC || p_mode == MLX_P_ZPROF) pz = p[z];
+  if ((!GENERIC && !P3D) || p_mode == MLX_P_ZPROF) pz = p[z];
   if (GENERIC && p_mode == MLX_P_SCALAR) pz = p[0];
-  RV pfold = RV{};  // FusedOps (float64 polynomial) folds the level's pressure into B0
-  if constexpr (Ops::fused) pfold = (R)pz;
-  const lanemask_t pbad = Ops::p_unsafe(pz);  // the level's pressure vetoes the fast quotient?
+  // pressure of cell k of pack u; FusedOps (float64 polynomial) folds it into B0
+  auto p_at = [&](int u, int k) -> double { return P3D ? pc[u][k] : pz; };
+  auto pfold_at = [&](int u, int g) -> RV {
+    RV f = RV{};
+    if constexpr (Ops::fused) f = (R)p_at(u, g * W);
+    return f;
+  };
+  // does the pressure veto the fast quotient (a whole level's, or -- P3D -- any lane's of pack u)?
+  lanemask_t pbad[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    pbad[u] = P3D ? 0 : Ops::p_unsafe(pz);
+    if constexpr (P3D) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) pbad[u] |= Ops::p_unsafe_lanes(pc[u][k]);
+    }
+  }
 
   // held fields: read once; fast path keeps their PART of the polynomial, generic the values
   TPart<RV> t0p[(HELD_T && !GENERIC) ? U : 1][G];
@@ -276,7 +296,8 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
       }
       if constexpr (!GENERIC) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) s0p[u][g] = s_part<Ops, RV>(Lanes<RV>::make(&h.v[g * W]), pfold);
+        for (int g = 0; g < G; ++g)
+          s0p[u][g] = s_part<Ops, RV>(Lanes<RV>::make(&h.v[g * W]), pfold_at(u, g));
       }
     }
   }
@@ -377,29 +398,12 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           const TPart<RV> a = t_part<Ops, RV>(Lanes<RV>::make(&curT[u].v[g * W]));
-          const SPart<RV> b = s_part<Ops, RV>(Lanes<RV>::make(&curS[u].v[g * W]), pfold);
+          const SPart<RV> b = s_part<Ops, RV>(Lanes<RV>::make(&curS[u].v[g * W]), pfold_at(u, g));
           double r3[3][W];
-          if constexpr (Ops::contracts && MLX_TUNE_BATCH_RCP) {
-            // one reciprocal per cell for its three variants (eos_device.hpp quotients_batched)
-            double n3[3][W], d3[3][W];
-            wright_numden_lanes<Ops, RV>(a, b, pz, n3[0], d3[0]);
-            wright_numden_lanes<Ops, RV>(a, s0p[u][g], pz, n3[1], d3[1]);
-            wright_numden_lanes<Ops, RV>(t0p[u][g], b, pz, n3[2], d3[2]);
-#pragma unroll
-            for (int w = 0; w < W; ++w) {
-              const double nn[3] = {n3[0][w], n3[1][w], n3[2][w]};
-              const double dd[3] = {d3[0][w], d3[1][w], d3[2][w]};
-              double qq[3];
-              quotients_batched<3>(nn, dd, qq);
-              r3[0][w] = qq[0];
-              r3[1][w] = qq[1];
-              r3[2][w] = qq[2];
-            }
-          } else {
-            wright_combine_lanes<Ops, RV>(a, b, pz, r3[0]);
-            wright_combine_lanes<Ops, RV>(a, s0p[u][g], pz, r3[1]);
-            wright_combine_lanes<Ops, RV>(t0p[u][g], b, pz, r3[2]);
-          }
+          static_assert(!(P3D && VAR == kVarAll), "the all-variants kernel has no register to spare");
+          wright_combine_lanes<Ops, RV>(a, b, pz, r3[0]);
+          wright_combine_lanes<Ops, RV>(a, s0p[u][g], pz, r3[1]);
+          wright_combine_lanes<Ops, RV>(t0p[u][g], b, pz, r3[2]);
 #pragma unroll
           for (int w = 0; w < W; ++w) {
             const int k = g * W + w;
@@ -418,15 +422,19 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
           TPart<RV> a;
           SPart<RV> b;
           if constexpr (STREAM_T) a = t_part<Ops, RV>(Lanes<RV>::make(&curT[u].v[g * W]));
-          if constexpr (STREAM_S) b = s_part<Ops, RV>(Lanes<RV>::make(&curS[u].v[g * W]), pfold);
+          if constexpr (STREAM_S)
+            b = s_part<Ops, RV>(Lanes<RV>::make(&curS[u].v[g * W]), pfold_at(u, g));
+          double pg[W];
+#pragma unroll
+          for (int w = 0; w < W; ++w) pg[w] = p_at(u, g * W + w);
           if constexpr (VAR == kVarSteric)
-            wright_numden_lanes<Ops, RV>(a, b, pz, &num[g * W], &den[g * W]);
+            wright_numden_lanes<Ops, RV>(a, b, pg, &num[g * W], &den[g * W]);
           if constexpr (VAR == kVarHalo)
-            wright_numden_lanes<Ops, RV>(t0p[u][g], b, pz, &num[g * W], &den[g * W]);
+            wright_numden_lanes<Ops, RV>(t0p[u][g], b, pg, &num[g * W], &den[g * W]);
           if constexpr (VAR == kVarThermo)
-            wright_numden_lanes<Ops, RV>(a, s0p[u][g], pz, &num[g * W], &den[g * W]);
+            wright_numden_lanes<Ops, RV>(a, s0p[u][g], pg, &num[g * W], &den[g * W]);
         }
-        quotients<Ops, VEC>(num, den, rho[0], pbad);
+        quotients<Ops, VEC>(num, den, rho[0], pbad[u]);
       }
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {  // cells in ascending order: the order of summation is fixed
@@ -603,7 +611,8 @@ __global__ __launch_bounds__(kBlock) void k_valu_probe(double* __restrict__ out,
 // ------------------------------------------------------------------------------------
 // K0: pointwise EOS map.  grid = (ceil(plane/(kBlock*VEC*U)), nz, nt)
 // ------------------------------------------------------------------------------------
-template <typename TIn, int VEC, int U, int MODE, int FUNC, bool GENERIC, bool FMA = false>
+template <typename TIn, int VEC, int U, int MODE, int FUNC, bool GENERIC, bool FMA = false,
+          bool P3D = false>
 __global__ __launch_bounds__(kBlock) void k_eos_map(const TIn* __restrict__ T,
                                                     const TIn* __restrict__ S,
                                                     const double* __restrict__ p, int p_mode,
@@ -621,9 +630,10 @@ __global__ __launch_bounds__(kBlock) void k_eos_map(const TIn* __restrict__ T,
   const int64_t tile0 = (int64_t)blockIdx.x * (kBlock * VEC * U);
   const int64_t zoff = (int64_t)z * plane;
   double pz = 0.0;
-  if (!GENERIC || p_mode == MLX_P_ZPROF) pz = p[z];
+  if ((!GENERIC && !P3D) || p_mode == MLX_P_ZPROF) pz = p[z];
   if (GENERIC && p_mode == MLX_P_SCALAR) pz = p[0];
   Pack<TIn, VEC> a[U], b[U];
+  Pack<double, VEC> pq[U];  // P3D: the cells' own pressures (a (z,y,x) field), 16-byte loads
   int64_t off[U];
   bool valid[U];
 #pragma unroll
@@ -633,6 +643,7 @@ __global__ __launch_bounds__(kBlock) void k_eos_map(const TIn* __restrict__ T,
     off[u] = zoff + (valid[u] ? i : 0);
     a[u] = load_pack<TIn, VEC, true>(T + t * t_stride_T + off[u]);
     b[u] = load_pack<TIn, VEC, true>(S + t * t_stride_S + off[u]);
+    if constexpr (P3D) pq[u] = load_pack<double, VEC>(p + off[u]);
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -651,19 +662,29 @@ __global__ __launch_bounds__(kBlock) void k_eos_map(const TIn* __restrict__ T,
       typedef typename PolyType<MODE>::type R;
       typedef typename PolyVec<MODE, VEC>::type RV;
       constexpr int W = Lanes<RV>::n;
-      RV pfold = RV{};
-      if constexpr (Ops::fused) pfold = (R)pz;
+      static_assert(!Ops::fused || W == 1, "pressure folding is per cell");
       double num[VEC], den[VEC];
+      lanemask_t pbad = P3D ? 0 : Ops::p_unsafe(pz);
 #pragma unroll
-      for (int k = 0; k < VEC; k += W)
+      for (int k = 0; k < VEC; k += W) {
+        double pg[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          pg[w] = P3D ? pq[u].v[k + w] : pz;
+          if constexpr (P3D) pbad |= Ops::p_unsafe_lanes(pg[w]);
+        }
+        RV pfold = RV{};
+        if constexpr (Ops::fused) pfold = (R)pg[0];
         wright_numden_lanes<Ops, RV>(t_part<Ops, RV>(Lanes<RV>::make(&a[u].v[k])),
-                                     s_part<Ops, RV>(Lanes<RV>::make(&b[u].v[k]), pfold), pz,
+                                     s_part<Ops, RV>(Lanes<RV>::make(&b[u].v[k]), pfold), pg,
                                      &num[k], &den[k]);
-      quotients<Ops, VEC>(num, den, r.v, Ops::p_unsafe(pz));
+      }
+      quotients<Ops, VEC>(num, den, r.v, pbad);
     } else {
 #pragma unroll
       for (int k = 0; k < VEC; ++k)
-        r.v[k] = eos_eval<MODE, TIn, Ops>(kWright, FUNC, a[u].v[k], b[u].v[k], pz);
+        r.v[k] = eos_eval<MODE, TIn, Ops>(kWright, FUNC, a[u].v[k], b[u].v[k],
+                                          P3D ? pq[u].v[k] : pz);
     }
     if (valid[u]) store_pack<VEC, true>(out + t * nz * plane + off[u], r);
   }
@@ -708,7 +729,9 @@ __device__ __forceinline__ double dz_default(double depth, double ztop, double z
 // out + v*variant_stride (v = 0 steric, 1 thermosteric, 2 halosteric, the order of K1's rows):
 // 16 B read + 3*8 B written per cell instead of 3 x (16 or 8 read + 8 written).  Each field is
 // bit-identical to its single-variant launch (same arithmetic tree, z ascending).
-template <typename TIn, int VEC, int NTI, int VAR, int MODE, bool GENERIC, bool SKIP, bool FMA>
+// P3D (fast kernels): the pressure is a (z,y,x) field, read per level like rho0m (see K1).
+template <typename TIn, int VEC, int NTI, int VAR, int MODE, bool GENERIC, bool SKIP, bool FMA,
+          bool P3D = false>
 __global__ __launch_bounds__(kBlock) void k_steric_local(
     const TIn* __restrict__ T, const TIn* __restrict__ S, const TIn* __restrict__ T0,
     const TIn* __restrict__ S0, const double* __restrict__ rho0m,
@@ -771,9 +794,17 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
 #pragma unroll
       for (int k = 0; k < VEC; ++k) dzv.v[k] = dz_default(depth.v[k], ztop, zbot);
     }
-    if (!GENERIC || p_mode == MLX_P_ZPROF) pz = p[z];
+    if ((!GENERIC && !P3D) || p_mode == MLX_P_ZPROF) pz = p[z];
     Pack<double, VEC> pfull;
-    if (GENERIC && p_mode == MLX_P_FULL3D) pfull = load_pack<double, VEC>(p + off);
+    if ((GENERIC && p_mode == MLX_P_FULL3D) || P3D) pfull = load_pack<double, VEC>(p + off);
+    static_assert(!(P3D && GENERIC), "P3D is the fast kernels' form of MLX_P_FULL3D");
+    static_assert(!Ops::fused || W == 1, "pressure folding is per cell");
+    // the pressure's veto of the fast quotient: the level's, or -- P3D -- any lane's of this pack
+    lanemask_t pbad = P3D ? 0 : Ops::p_unsafe(pz);
+    if constexpr (P3D) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) pbad |= Ops::p_unsafe_lanes(pfull.v[k]);
+    }
 
     // SKIP (MLX_FLAG_SKIP_DRY): where rho0m is NaN in every cell of the pack, delta_rho is NaN and
     // the column sum unchanged whatever theta/S hold -> their loads are masked off, same bits
@@ -791,8 +822,15 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
       if (HELD_T) hT = load_field<MODE, true, TIn, VEC>(VAR == kVarAll ? T0 : T, off);
       if (HELD_S) hS = load_field<MODE, false, TIn, VEC>(VAR == kVarAll ? S0 : S, off);
     }
-    RV pfold = RV{};
-    if constexpr (Ops::fused) pfold = (R)pz;
+    RV pfold[G];  // FusedOps folds the pressure (the level's, or the cell's own) into B0
+    double pg[G][W];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+      for (int w = 0; w < W; ++w) pg[g][w] = P3D ? pfull.v[g * W + w] : pz;
+      pfold[g] = RV{};
+      if constexpr (Ops::fused) pfold[g] = (R)pg[g][0];
+    }
     TPart<RV> hTp[G];
     SPart<RV> hSp[G];
     if constexpr (!GENERIC && HELD_T) {
@@ -801,7 +839,8 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
     }
     if constexpr (!GENERIC && HELD_S) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) hSp[g] = s_part<Ops, RV>(Lanes<RV>::make(&hS.v[g * W]), pfold);
+      for (int g = 0; g < G; ++g)
+        hSp[g] = s_part<Ops, RV>(Lanes<RV>::make(&hS.v[g * W]), pfold[g]);
     }
 
     Pack<TIn, VEC> a[NTI], b[NTI];
@@ -846,19 +885,21 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
             TPart<RV> tp;
             SPart<RV> sp;
             if constexpr (STREAM_T) tp = t_part<Ops, RV>(Lanes<RV>::make(&a[j].v[g * W]));
-            if constexpr (STREAM_S) sp = s_part<Ops, RV>(Lanes<RV>::make(&b[j].v[g * W]), pfold);
+            if constexpr (STREAM_S)
+              sp = s_part<Ops, RV>(Lanes<RV>::make(&b[j].v[g * W]), pfold[g]);
             double* const n0 = &num[0][g * W];
             double* const d0 = &den[0][g * W];
-            if constexpr (VAR == kVarSteric) wright_numden_lanes<Ops, RV>(tp, sp, pz, n0, d0);
-            if constexpr (VAR == kVarHalo) wright_numden_lanes<Ops, RV>(hTp[g], sp, pz, n0, d0);
-            if constexpr (VAR == kVarThermo) wright_numden_lanes<Ops, RV>(tp, hSp[g], pz, n0, d0);
+            const double* const pl = pg[g];
+            if constexpr (VAR == kVarSteric) wright_numden_lanes<Ops, RV>(tp, sp, pl, n0, d0);
+            if constexpr (VAR == kVarHalo) wright_numden_lanes<Ops, RV>(hTp[g], sp, pl, n0, d0);
+            if constexpr (VAR == kVarThermo) wright_numden_lanes<Ops, RV>(tp, hSp[g], pl, n0, d0);
             if constexpr (VAR == kVarAll) {
-              wright_numden_lanes<Ops, RV>(tp, sp, pz, n0, d0);
-              wright_numden_lanes<Ops, RV>(tp, hSp[g], pz, &num[1][g * W], &den[1][g * W]);
-              wright_numden_lanes<Ops, RV>(hTp[g], sp, pz, &num[2][g * W], &den[2][g * W]);
+              wright_numden_lanes<Ops, RV>(tp, sp, pl, n0, d0);
+              wright_numden_lanes<Ops, RV>(tp, hSp[g], pl, &num[1][g * W], &den[1][g * W]);
+              wright_numden_lanes<Ops, RV>(hTp[g], sp, pl, &num[2][g * W], &den[2][g * W]);
             }
           }
-          quotients<Ops, NOUT * VEC>(&num[0][0], &den[0][0], &rho[0][0], Ops::p_unsafe(pz));
+          quotients<Ops, NOUT * VEC>(&num[0][0], &den[0][0], &rho[0][0], pbad);
         }
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
@@ -1134,11 +1175,15 @@ inline int vec_of(int dtype) { return (dtype == MLX_DTYPE_F64) ? kVec64 : kVec32
 
 // the dwordx4 kernels need: Wright EOS, z-profile pressure, whole packs per plane and per time
 // stride, 16-byte aligned operands; everything else takes the generic (scalar) twin
+// (p_mode MLX_P_FULL3D -- `patm` as a (yh,xh) DataArray -- qualifies too where the caller passes
+// the pressure pointer as `p3d`: the fast kernels then read the pressure FIELD with the same
+// 16-byte loads, template argument P3D; a z profile needs no alignment beyond its elements')
 bool fast_layout(int dtype, int p_mode, int eos, int64_t plane, int64_t sT, int64_t sS,
-                 std::initializer_list<const void*> ptrs) {
+                 std::initializer_list<const void*> ptrs, const void* p3d = nullptr) {
   const int vec = vec_of(dtype);
   if (mixed_dtype(dtype)) return false;  // scalar loads of two element sizes: the generic twin
-  if (eos != MLX_EOS_WRIGHT || p_mode != MLX_P_ZPROF) return false;
+  if (eos != MLX_EOS_WRIGHT) return false;
+  if (p_mode != MLX_P_ZPROF && !(p3d && p_mode == MLX_P_FULL3D && aligned(p3d, 16))) return false;
   if (plane % vec || sT % vec || sS % vec) return false;
   for (const void* q : ptrs)
     if (q && !aligned(q, 16)) return false;
@@ -1155,16 +1200,29 @@ struct K1Args {
   int64_t plane, sT, sS;
   double* partials;
   int64_t nblk;
+  bool p3d;  // fast kernels: the pressure is a (z,y,x) field (template argument P3D)
 };
 
-template <typename TIn, int VEC, int U, int VAR, int MODE, bool GEN, bool SKIP, bool FMA>
-void k1_go(const K1Args& a) {
-  snprintf(g_kernel, sizeof(g_kernel), "k_steric_global<%s,%d,%d,%d,%d,%s,%s,%s>",
-           type_name<TIn>(), VEC, U, VAR, MODE, tf(GEN), tf(SKIP), tf(FMA));
-  hipLaunchKernelGGL((k_steric_global<TIn, VEC, U, VAR, MODE, GEN, SKIP, FMA>), a.grid,
+template <typename TIn, int VEC, int U, int VAR, int MODE, bool GEN, bool SKIP, bool FMA,
+          bool P3D>
+void k1_launch(const K1Args& a) {
+  snprintf(g_kernel, sizeof(g_kernel), "k_steric_global<%s,%d,%d,%d,%d,%s,%s,%s%s>",
+           type_name<TIn>(), VEC, U, VAR, MODE, tf(GEN), tf(SKIP), tf(FMA), P3D ? ",true" : "");
+  hipLaunchKernelGGL((k_steric_global<TIn, VEC, U, VAR, MODE, GEN, SKIP, FMA, P3D>), a.grid,
                      dim3(kBlock), 0, a.st, (const TIn*)a.T, (const TIn*)a.S, (const TIn*)a.T0,
                      (const TIn*)a.S0, a.vol0, a.p, a.p_mode, a.eos, a.nt, a.t_chunk, a.plane,
                      a.sT, a.sS, a.partials, a.nblk);
+}
+
+template <typename TIn, int VEC, int U, int VAR, int MODE, bool GEN, bool SKIP, bool FMA>
+void k1_go(const K1Args& a) {
+  if constexpr (!GEN && VAR != kVarAll) {
+    if (a.p3d) {
+      k1_launch<TIn, VEC, U, VAR, MODE, GEN, SKIP, FMA, true>(a);
+      return;
+    }
+  }
+  k1_launch<TIn, VEC, U, VAR, MODE, GEN, SKIP, FMA, false>(a);
 }
 
 template <typename TIn, int VEC, int U, int VAR, int MODE, bool GEN>
@@ -1247,13 +1305,16 @@ int steric_global_impl(const void* T, const void* S, const void* T0, const void*
   if (!aligned(workspace, 8) || workspace_bytes < need)
     return fail(MLX_E_WORKSPACE, "workspace smaller than the *_workspace_bytes() query");
   const bool skip = (flags & MLX_FLAG_SKIP_DRY) != 0, fma = (flags & MLX_FLAG_FMA) != 0;
-  bool fast = fast_layout(dtype, p_mode, eos, plane, sT, sS, {T, S, T0, S0, vol0});
+  // (the all-variants kernel has no registers left for a pressure field: generic twin)
+  bool fast = fast_layout(dtype, p_mode, eos, plane, sT, sS, {T, S, T0, S0, vol0},
+                          var != kVarAll ? p : nullptr);
   if (var != kVarAll) {
     if (sT == 0 && sS == 0) fast = false;  // both held: nothing streams; the generic twin reloads
     else if (sT == 0) { var = kVarHalo; T0 = T; }
     else if (sS == 0) { var = kVarThermo; S0 = S; }
   }
   K1Args a;
+  a.p3d = fast && p_mode == MLX_P_FULL3D;
   const int64_t gx = k1_blocks(fast, dtype, plane);
   a.t_chunk = k1_time_chunk(flags, nt, var);
   if (ceil_div(nt, a.t_chunk) > 65535) return fail(MLX_E_SHAPE, "nt too large for one call: chunk it");
@@ -1283,17 +1344,30 @@ struct K2Args {
   int64_t plane, sT, sS;
   double *drho, *eta;
   int64_t drho_vstride, eta_vstride;
+  bool p3d;  // fast kernels: the pressure is a (z,y,x) field (template argument P3D)
 };
 
-template <typename TIn, int VEC, int NTI, int VAR, int MODE, bool GEN, bool SKIP, bool FMA>
-void k2_go(const K2Args& a) {
-  snprintf(g_kernel, sizeof(g_kernel), "k_steric_local<%s,%d,%d,%d,%d,%s,%s,%s>",
-           type_name<TIn>(), VEC, NTI, VAR, MODE, tf(GEN), tf(SKIP), tf(FMA));
-  hipLaunchKernelGGL((k_steric_local<TIn, VEC, NTI, VAR, MODE, GEN, SKIP, FMA>), a.grid,
+template <typename TIn, int VEC, int NTI, int VAR, int MODE, bool GEN, bool SKIP, bool FMA,
+          bool P3D>
+void k2_launch(const K2Args& a) {
+  snprintf(g_kernel, sizeof(g_kernel), "k_steric_local<%s,%d,%d,%d,%d,%s,%s,%s%s>",
+           type_name<TIn>(), VEC, NTI, VAR, MODE, tf(GEN), tf(SKIP), tf(FMA), P3D ? ",true" : "");
+  hipLaunchKernelGGL((k_steric_local<TIn, VEC, NTI, VAR, MODE, GEN, SKIP, FMA, P3D>), a.grid,
                      dim3(kBlock), 0, a.st, (const TIn*)a.T, (const TIn*)a.S, (const TIn*)a.T0,
                      (const TIn*)a.S0, a.rho0m, a.surf, a.dz, a.z_i, a.deptho, a.p, a.p_mode, a.eos,
                      a.neg_inv_rhozero, a.nt, a.nz, a.plane, a.sT, a.sS, a.drho, a.drho_vstride,
                      a.eta, a.eta_vstride);
+}
+
+template <typename TIn, int VEC, int NTI, int VAR, int MODE, bool GEN, bool SKIP, bool FMA>
+void k2_go(const K2Args& a) {
+  if constexpr (!GEN && VAR != kVarAll) {
+    if (a.p3d) {
+      k2_launch<TIn, VEC, NTI, VAR, MODE, GEN, SKIP, FMA, true>(a);
+      return;
+    }
+  }
+  k2_launch<TIn, VEC, NTI, VAR, MODE, GEN, SKIP, FMA, false>(a);
 }
 
 template <typename TIn, int VEC, int NTI, int VAR, int MODE, bool GEN>
@@ -1373,7 +1447,8 @@ int steric_local_impl(const void* T, const void* S, const void* T0, const void* 
   // both strides must be whole packs too in the all-variants kernel (three fields, one base)
   bool fast = fast_layout(dtype, p_mode, eos, plane, sT, sS,
                           {T, S, T0, S0, rho0m, vol0_surface, eta_out, dz, dz ? nullptr : deptho,
-                           delta_rho_out}) &&
+                           delta_rho_out},
+                          var != kVarAll ? p : nullptr) &&
               !(sT == 0 && sS == 0);
   if (var == kVarAll && fast) {
     const int vec = vec_of(dtype);
@@ -1399,6 +1474,7 @@ int steric_local_impl(const void* T, const void* S, const void* T0, const void* 
   a.deptho = deptho; a.p = p ? p : rho0m; a.p_mode = p_mode; a.eos = eos; a.nt = (int)nt;
   a.nz = (int)nz; a.neg_inv_rhozero = neg_inv_rhozero; a.plane = plane; a.sT = sT; a.sS = sS;
   a.drho = delta_rho_out; a.eta = eta_out; a.drho_vstride = drho_vstride; a.eta_vstride = eta_vstride;
+  a.p3d = fast && p_mode == MLX_P_FULL3D;
   if (fast) {
     if (f64) k2_var<double, kVec64, 0, kVec64, kNTI64All, kF64, false>(a, var, skip, fma);
     else if (dtype == MLX_DTYPE_F32)
@@ -1457,18 +1533,28 @@ static int eos_map_impl(const void* T, const void* S, int dtype, const double* p
   hipStream_t st = (hipStream_t)stream;
   const bool f64 = (dtype == MLX_DTYPE_F64);
   const int vec = vec_of(dtype);
-  const bool fast = fast_layout(dtype, p_mode, eos, plane, sT, sS, {T, S, out}) &&
+  const bool fast = fast_layout(dtype, p_mode, eos, plane, sT, sS, {T, S, out},
+                                func == MLX_FUNC_DENSITY ? p : nullptr) &&
                     (f64 || func == MLX_FUNC_DENSITY) && func != MLX_FUNC_IBH;
+  const bool p3d = fast && p_mode == MLX_P_FULL3D;
   const double* pp = p ? p : out;  // never dereferenced for the linear EOS
   for (int64_t tb = 0; tb < nt; tb += 32768) {
     const int64_t ntc = (nt - tb < 32768) ? (nt - tb) : 32768;
     if (fast) {
       constexpr int U = 2;
       dim3 grid((unsigned)ceil_div(plane, (int64_t)kBlock * vec * U), (unsigned)nz, (unsigned)ntc);
+#define MLX_LAUNCH_K0P(TIN, VEC, MODE, FUNC, FMA, P3D)                                           \
+  hipLaunchKernelGGL((k_eos_map<TIN, VEC, U, MODE, FUNC, false, FMA, P3D>), grid, dim3(kBlock), \
+                     0, st, (const TIN*)T, (const TIN*)S, pp, p_mode, eos, func, nz, plane, sT,  \
+                     sS, tb, aux, out)
+// (the density map takes a (z,y,x) pressure field on the fast path too: P3D)
 #define MLX_LAUNCH_K0(TIN, VEC, MODE, FUNC, FMA)                                                 \
-  hipLaunchKernelGGL((k_eos_map<TIN, VEC, U, MODE, FUNC, false, FMA>), grid, dim3(kBlock), 0,    \
-                     st, (const TIN*)T, (const TIN*)S, pp, p_mode, eos, func, nz, plane, sT, sS, \
-                     tb, aux, out)
+  do {                                                                                           \
+    if constexpr (FUNC == kDensity) {                                                            \
+      if (p3d) { MLX_LAUNCH_K0P(TIN, VEC, MODE, FUNC, FMA, true); break; }                       \
+    }                                                                                            \
+    MLX_LAUNCH_K0P(TIN, VEC, MODE, FUNC, FMA, false);                                            \
+  } while (0)
       if (f64) {
         switch (func) {
           case MLX_FUNC_DENSITY:
@@ -1489,6 +1575,7 @@ static int eos_map_impl(const void* T, const void* S, int dtype, const double* p
         MLX_LAUNCH_K0(float, 4, kF32Upcast, kDensity, false);
       }
 #undef MLX_LAUNCH_K0
+#undef MLX_LAUNCH_K0P
     } else {
       constexpr int U = 4;
       dim3 grid((unsigned)ceil_div(plane, (int64_t)kBlock * U), (unsigned)nz, (unsigned)ntc);

@@ -89,5 +89,57 @@ def main():
         del rho0m, eta, drho
 
 
+def pressure_field_cases(nt):
+    """MLX_P_FULL3D (`patm` as a (yh,xh) DataArray): the 16-byte-load kernels' P3D form (round 4)
+    beside the z-profile launch of the same kernel, float64 and float32 fields."""
+    from momlevel_amd import _lib
+
+    nz, ny, nx = 75, 1080, 1440
+    g = synthetic.make_grid(ny, nx, nz)
+    vol0 = torch.from_numpy(g["volcello"]).cuda()
+    shape = (nt, nz, ny, nx)
+    n = int(np.prod(shape))
+    pz = torch.from_numpy(101325.0 + g["z_l"] * 1.0e4).cuda()
+    patm = torch.from_numpy(np.random.default_rng(1).normal(0.0, 500.0, (ny, nx))).cuda()
+    p3 = (pz.reshape(nz, 1, 1) + patm.reshape(1, ny, nx)).contiguous()
+    eta = torch.empty((nt, ny, nx), dtype=torch.float64, device="cuda")
+    drho = torch.empty(shape, dtype=torch.float64, device="cuda")
+    for dt, esz in ((torch.float64, 8), (torch.float32, 4)):
+        T = core.synth_field(shape, dt, seed=synthetic.SEED, field_id=1, lo=-2.0, scale=34.0, mask3d=vol0)
+        S = core.synth_field(shape, dt, seed=synthetic.SEED, field_id=2, lo=30.0, scale=10.0, mask3d=vol0)
+        rho0m = core.fold_mask(core.eos_map(T[0], S[0], pz), vol0)
+        for label, p in (("z profile", pz), ("(z,y,x) pressure field", p3)):
+            def report(name, ms, nbytes):
+                print(json.dumps({"case": f"{name}, {str(dt)[6:]}, {label}", "kernel": _lib.last_kernel(),
+                                  "ms": round(ms, 3), "Gcells_per_s": round(n / ms / 1e6, 1),
+                                  "algorithmic_GB_per_s": round(nbytes / ms / 1e6, 1),
+                                  "frac_of_8TBs": round(nbytes / ms / 1e6 / 8000.0, 4)}), flush=True)
+
+            report("K1 global steric (default arithmetic)",
+                   timed(lambda: core.steric_global_masso(T, S, vol0, p, skip_dry=False)), n * 2 * esz)
+            report("K1 global thermosteric (default arithmetic)",
+                   timed(lambda: core.steric_global_masso(T, S[0], vol0, p, skip_dry=False)), n * esz)
+            report("K2 local + delta_rho",
+                   timed(lambda: core.steric_local(T, S, rho0m, vol0[0], p, -1.0 / 1035.0, z_i=g["z_i"],
+                                                   deptho=g["deptho"], skip_dry=False, eta_out=eta,
+                                                   delta_rho_out=drho)), n * (2 * esz + 8))
+            report("K2 local thermosteric + delta_rho",
+                   timed(lambda: core.steric_local(T, S[0], rho0m, vol0[0], p, -1.0 / 1035.0,
+                                                   z_i=g["z_i"], deptho=g["deptho"], skip_dry=False,
+                                                   eta_out=eta, delta_rho_out=drho)), n * (esz + 8))
+            ms = timed(lambda: core.eos_map(T, S, p))
+            print(json.dumps({"case": f"K0 density map, {str(dt)[6:]}, {label}", "ms": round(ms, 3),
+                              "Gcells_per_s": round(n / ms / 1e6, 1),
+                              "algorithmic_GB_per_s": round(n * (2 * esz + 8) / ms / 1e6, 1),
+                              "frac_of_8TBs": round(n * (2 * esz + 8) / ms / 1e6 / 8000.0, 4)}), flush=True)
+        del T, S, rho0m
+
+
 if __name__ == "__main__":
+    if "--pressure-field" in sys.argv:
+        sys.argv.remove("--pressure-field")
+        ap = argparse.ArgumentParser()
+        ap.add_argument("--nt", type=int, default=16)
+        pressure_field_cases(ap.parse_args().nt)
+        sys.exit(0)
     main()

@@ -567,6 +567,90 @@ def test_time_dependent_pressure_in_the_fused_kernels(dtype):
                1e-12, "thermo 4-D pressure")
 
 
+@pytest.mark.parametrize("skip_dry", [False, True])
+@pytest.mark.parametrize("dtype,f32_mode", [(np.float64, "faithful"), (np.float32, "faithful"),
+                                            (np.float32, "upcast")])
+def test_pressure_field_takes_the_fast_kernels(dtype, f32_mode, skip_dry):
+    """MLX_P_FULL3D -- `patm` as a (yh,xh) DataArray makes the pressure a (z,y,x) FIELD
+    (steric.py:58-60,96) -- runs on the 16-byte-load kernels since round 4 (template argument P3D:
+    each thread keeps / reads its cells' own pressures), not on the scalar twins: K0, K1 and K2,
+    every single variant, exact and fused, against numpy; the scalar twin (forced by an unaligned
+    pressure view) must agree bit for bit pointwise and to 1e-12 in the sums; masso(t=0) == masso0."""
+    shape = (19, 5, 12, 40)  # nt=19: a ragged K2 time block for every blocking (6, 8, 12, 16)
+    nt, nz, ny, nx = shape
+    g, T, S = _case_fields(shape, dtype)
+    r = np.random.default_rng(21)
+    p3 = (g["z_l"] * 1.0e4)[:, None, None] + (101325.0 + r.normal(0.0, 700.0, (ny, nx)))[None]
+    dT, dS = torch.from_numpy(T).cuda(), torch.from_numpy(S).cuda()
+    vol0 = torch.from_numpy(g["volcello"]).cuda()
+    dp = torch.from_numpy(p3).cuda()
+    raw = torch.empty(p3.size + 1, dtype=torch.float64, device="cuda")
+    dp_odd = raw[1:].view(nz, ny, nx)  # 8 bytes off a 16-byte boundary: the scalar twin
+    dp_odd.copy_(dp)
+    kw = dict(f32_mode=f32_mode, skip_dry=skip_dry)
+    if f32_mode == "upcast":
+        T, S = T.astype(np.float64), S.astype(np.float64)
+    rho = o.wright_density(T, S, p3[None])
+    # K0
+    got = core.eos_map(dT, dS, dp, f32_mode=f32_mode)
+    assert_bit_equal(got.cpu().numpy(), rho, "K0, pressure field")
+    assert torch.equal(core.eos_map(dT, dS, dp_odd, f32_mode=f32_mode).nan_to_num(-1.0),
+                       got.nan_to_num(-1.0))
+    fused = core.eos_map(dT, dS, dp, f32_mode=f32_mode, arith="fused").cpu().numpy()
+    assert_rel(fused, rho, 1e-12, "K0 fused, pressure field")
+    # K1: every single variant, both policies
+    tin = "double" if dtype == np.float64 else "float"
+    for name, Tv, Sv, Tn, Sn in (("steric", dT, dS, T, S), ("thermo", dT, dS[0], T, S[0]),
+                                 ("halo", dT[0], dS, T[0], S)):
+        ref = np.nansum(o.wright_density(Tn, Sn, p3[None] if Tn.ndim == 4 or Sn.ndim == 4 else p3)
+                        * g["volcello"], axis=(1, 2, 3))
+        for arith, tol in (("exact", 1e-12), ("fused", 1e-10)):
+            m = core.steric_global_masso(Tv, Sv, vol0, dp, arith=arith, **kw)
+            kern = _lib.last_kernel()
+            args = kern[kern.index("<") + 1:-1].split(",")
+            # <type, cells per pack, packs, variant, mode, GENERIC, skip, fma, P3D>
+            assert kern.startswith(f"k_steric_global<{tin},") and len(args) == 9, kern
+            assert args[5] == "false" and args[8] == "true", kern  # the fast kernel, P3D form
+            assert_rel(m.cpu().numpy(), ref, tol, f"K1 {name} {arith}, pressure field")
+            m_odd = core.steric_global_masso(Tv, Sv, vol0, dp_odd, arith=arith, **kw)
+            assert len(_lib.last_kernel().split(",")) == 8  # the scalar twin has no P3D form
+            assert_rel(m_odd.cpu().numpy(), m.cpu().numpy(), 1e-12, "scalar twin vs fast kernel")
+            m0 = core.steric_global_masso(dT[:1], dS[:1], vol0, dp, arith=arith, **kw)
+            if name == "steric":
+                assert m0[0] == m[0]  # the reference state's masso0 through the same kernel
+    # K2: delta_rho and eta of every variant, bit for bit; eta-only launches agree
+    rho0 = o.wright_density(T[0], S[0], p3)
+    rho0m = core.fold_mask(core.eos_map(dT[0], dS[0], dp, f32_mode=f32_mode), vol0)
+    dz = o.calc_dz(g["z_l"], g["z_i"], g["deptho"])
+    for name, Tv, Sv, Tn, Sn in (("steric", dT, dS, T, S), ("thermo", dT, dS[0], T, S[:1]),
+                                 ("halo", dT[0], dS, T[:1], S)):
+        rv = o.wright_density(Tn, Sn, p3[None])
+        dref = np.where(~np.isnan(g["volcello"]), rv - rho0, np.nan)
+        eref = np.where(~np.isnan(g["volcello"][0]),
+                        (-1.0 / 1035.0) * np.nansum(dz * dref, axis=1), np.nan)
+        drho, eta = core.steric_local(Tv, Sv, rho0m, vol0[0], dp, -1.0 / 1035.0, z_i=g["z_i"],
+                                      deptho=g["deptho"], **kw)
+        kern = _lib.last_kernel()
+        args = kern[kern.index("<") + 1:-1].split(",")
+        assert kern.startswith(f"k_steric_local<{tin},") and len(args) == 9, kern
+        assert args[5] == "false" and args[8] == "true", kern
+        assert_bit_equal(drho.cpu().numpy(), dref, f"K2 {name} delta_rho, pressure field")
+        assert_bit_equal(eta.cpu().numpy(), eref, f"K2 {name} eta, pressure field")
+        _, eta_only = core.steric_local(Tv, Sv, rho0m, vol0[0], dp, -1.0 / 1035.0, z_i=g["z_i"],
+                                        deptho=g["deptho"], want_delta_rho=False, **kw)
+        assert torch.equal(eta_only.nan_to_num(-1.0), eta.nan_to_num(-1.0))
+        d_odd, e_odd = core.steric_local(Tv, Sv, rho0m, vol0[0], dp_odd, -1.0 / 1035.0,
+                                         z_i=g["z_i"], deptho=g["deptho"], **kw)
+        assert len(_lib.last_kernel().split(",")) == 8
+        assert torch.equal(d_odd.nan_to_num(-1.0), drho.nan_to_num(-1.0))
+        assert torch.equal(e_odd.nan_to_num(-1.0), eta.nan_to_num(-1.0))
+    # the all-variants kernels keep the scalar twin for a pressure field: rows equal the launches above
+    rows = core.steric_global_decomp(dT, dS, dT[0], dS[0], vol0, dp, arith="exact", **kw)
+    assert_rel(rows[0].cpu().numpy(),
+               core.steric_global_masso(dT, dS, vol0, dp, arith="exact", **kw).cpu().numpy(), 1e-12,
+               "one-pass (scalar twin) vs fast kernel")
+
+
 def test_stream_probe_adds():
     a = torch.rand(4096 * 6, dtype=torch.float64, device="cuda")
     b = torch.rand(4096 * 6, dtype=torch.float64, device="cuda")

@@ -71,3 +71,28 @@ def test_no_undefined_globals_in_script(rel):
     module = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(module)
     assert _undefined(module) == []
+
+
+def test_exec_masking_asm_declares_its_scalar_side_effects():
+    """s_and_saveexec_b64 writes SCC besides EXEC.  An inline-asm block that uses it must list
+    "scc" (and "vcc", which carries the lane mask) among its clobbers, or the compiler may keep a
+    scalar compare's result live across the block: round 4 found exactly that -- an `s_cmp ...
+    s_cselect` pair scheduled around the predicated accumulate of the float32 one-pass kernel, wrong
+    sums, no crash.  Checked on the source: every asm statement with `saveexec` names both."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = 0
+    for rel in ("momlevel_amd/csrc/eos_device.hpp", "momlevel_amd/csrc/momlevel_hip.hip",
+                "momlevel_amd/csrc/momlevel_promote.hip", "momlevel_amd/csrc/eos_promote.hpp"):
+        text = open(os.path.join(root, rel)).read()
+        for m in re.finditer(r"\basm\s*(?:volatile)?\s*\(", text):
+            depth, i = 1, m.end()
+            while depth and i < len(text):
+                depth += {"(": 1, ")": -1}.get(text[i], 0)
+                i += 1
+            stmt = text[m.start():i]
+            if "saveexec" in stmt:
+                found += 1
+                assert '"scc"' in stmt and '"vcc"' in stmt, f"{rel}: {stmt[:120]}"
+    assert found >= 2  # add_skipna and accumulate
