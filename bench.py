@@ -96,7 +96,7 @@ def measured_traffic(cells_per_launch):
     were taken on this workload AND on these kernel sources; bench.py itself cannot read
     hardware counters.  A stale profile (sources changed since) yields null, not an old number."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ("r03_summary.json", "r02_summary.json"):
+    for name in ("r04_summary.json", "r03_summary.json", "r02_summary.json"):
         try:
             with open(os.path.join(here, "profiles", name)) as f:
                 s = json.load(f)

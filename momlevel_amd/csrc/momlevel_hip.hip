@@ -750,7 +750,9 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
   typedef typename std::conditional<
       FMA, typename FusedFor<MODE>::type,
       typename std::conditional<GENERIC, ExactOps, typename ExactFastFor<MODE>::type>::type>::type Ops;
-  constexpr bool PRED = sizeof(TIn) == 4;  // add_skipna form: neutral at float64, +2-3 % at float32
+  // add_skipna form: +2-3 % at float32; at float64 neutral for the steric pass (round 3) and 0-2 %
+  // for the held-field passes (round 4, profiles/r04_tune_k2_pred_held64.log: inside the scatter)
+  constexpr bool PRED = sizeof(TIn) == 4;
   const int64_t col = (xcd_remap(blockIdx.x, gridDim.x) * kBlock + threadIdx.x) * VEC;
   if (col + VEC > plane) return;  // whole packs only; no barrier below
   const int t0 = blockIdx.y * NTI;
@@ -772,6 +774,7 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
   // rho0m of level z+1 is fetched while level z is processed, so that the dry test (SKIP) and the
   // theta/S loads of a level never wait for a dependent load
   Pack<double, VEC> r0n = load_pack<double, VEC>(rho0m + col);
+
   for (int z = 0; z < nz; ++z) {
     const int64_t off = (int64_t)z * plane + col;
     // The time strides pass through an empty asm in every iteration: the compiler then computes each

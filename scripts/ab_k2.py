@@ -63,6 +63,16 @@ def main():
         res[f"{tag}_eta_only_skip_dry"] = best(lambda: core.steric_local(
             T, S, rho0m, vol0[0], pz, -1.0 / 1035.0, want_delta_rho=False, eta_out=eta,
             z_i=zi, deptho=dep, skip_dry=True))
+        # fingerprints of the held-field outputs (equal across libraries: tuning never changes a bit)
+        for name, Tv, Sv in (("thermo", T, S[0]), ("halo", T[0], S)):
+            core.steric_local(Tv, Sv, rho0m, vol0[0], pz, -1.0 / 1035.0, eta_out=eta,
+                              delta_rho_out=drho, **kw)
+            res[f"{tag}_{name}_fingerprint"] = "%.17g/%.17g" % (
+                eta.nan_to_num(0.0).sum().item(), drho.nan_to_num(0.0).abs().sum().item())
+            core.steric_local(Tv, Sv, rho0m, vol0[0], pz, -1.0 / 1035.0, eta_out=eta,
+                              delta_rho_out=drho, z_i=zi, deptho=dep, skip_dry=True)
+            res[f"{tag}_{name}_fingerprint_skip_dry"] = "%.17g/%.17g" % (
+                eta.nan_to_num(0.0).sum().item(), drho.nan_to_num(0.0).abs().sum().item())
         del drho
         e3 = torch.empty((3, a.nt, ny, nx), dtype=torch.float64, device="cuda")
         res[f"{tag}_one_pass_eta_only"] = best(lambda: core.steric_local_decomp(

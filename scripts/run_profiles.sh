@@ -6,11 +6,13 @@
 # (run those in the build container afterwards, or here).
 set -e -o pipefail
 TAG=${1:-r04}
+PART=${2:-all}   # all | f64 | f32: the float32 passes can run in a call of their own
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 B=gpurun_out/prof_${TAG}
 V=gpurun_out/prof_${TAG}v
 mkdir -p $B $V
+if [ "$PART" != "f32" ]; then
 BENCH="python3 bench.py --steps 5 --warmup 1 --no-extras --cpu-seconds 0"
 echo "== bench: kernel trace + stats"; rocprofv3 --output-format csv --kernel-trace --stats -d $B/trace -o run -- $BENCH > $B/bench_trace.log 2>&1
 echo "== bench: FETCH_SIZE";           rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $B/pmc_fetch -o run -- $BENCH > $B/bench_pmc_fetch.log 2>&1
@@ -27,6 +29,8 @@ find $B $V -name "*_agent_info.csv" -delete
 python3 scripts/summarize_rocprof.py $B profiles/${TAG}
 python3 scripts/summarize_variants.py $V profiles/${TAG}
 echo "profiles done (f64)"
+fi
+if [ "$PART" = "f64" ]; then exit 0; fi
 # --- float32 theta/S (BASELINE.json configs[4]): the same variants, half the bytes per cell
 W=gpurun_out/prof_${TAG}v32
 mkdir -p $W
