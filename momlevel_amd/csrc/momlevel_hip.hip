@@ -409,8 +409,9 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
             const int k = g * W + w;
 #pragma unroll
             for (int o = 0; o < 3; ++o) accumulate<Ops, PRED>(c[o], r3[o][w], vol[u][k]);
-            // extension: heat content
-            accumulate<Ops, PRED>(c[3], (double)curT[u].v[k], vol[u][k]);
+            // extension: heat content -- product, then sum, whatever the density's policy (the row
+            // must not depend on how rho is evaluated)
+            accumulate<ExactOps, PRED>(c[3], (double)curT[u].v[k], vol[u][k]);
           }
         }
         continue;
@@ -440,8 +441,8 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
       for (int k = 0; k < VEC; ++k) {  // cells in ascending order: the order of summation is fixed
 #pragma unroll
         for (int o = 0; o < NR; ++o) accumulate<Ops, PRED>(c[o], rho[o][k], vol[u][k]);  // derived.py:435
-        if constexpr (VAR == kVarAll)  // extension: heat-content integrand theta*vol0
-          accumulate<Ops, PRED>(c[3], (double)curT[u].v[k], vol[u][k]);
+        if constexpr (VAR == kVarAll)  // extension: heat-content integrand theta*vol0 (see above)
+          accumulate<ExactOps, PRED>(c[3], (double)curT[u].v[k], vol[u][k]);
       }
     }
     const int row = (t - tb) % NTC;
