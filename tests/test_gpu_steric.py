@@ -334,6 +334,62 @@ def test_thetao_and_so_of_different_dtypes(variant, shape, dtypes):
     assert np.allclose(gres[variant].values / href, ogres["expansion_coeff"], rtol=0, atol=1e-12)
 
 
+def test_mixed_dtypes_refuse_the_fused_policy_in_every_kernel():
+    """theta and so of different dtypes have exact kernels only: an explicit arith="fused" raises the
+    same ValueError from K0 (eos_map, which routes them to the promote kernel) as from K1 and K2 --
+    it used to be ignored silently there"""
+    from momlevel_amd import core
+
+    d = _masked_dataset(3, 4, 6, 8)
+    T = torch.from_numpy(d["thetao"].values.astype(np.float32)).cuda()
+    S = torch.from_numpy(d["so"].values).cuda()
+    vol0 = torch.from_numpy(d["volcello"].values[0]).cuda()
+    pres = o.pressure_from_depth(d["z_l"].values)
+    with pytest.raises(ValueError, match="different dtypes"):
+        core.eos_map(T, S, pres, arith="fused")
+    with pytest.raises(ValueError, match="different dtypes"):
+        core.steric_global_masso(T, S, vol0, pres, arith="fused")
+    rho = core.eos_map(T, S, pres)  # the default policy falls back to exact: numpy's bits
+    assert_bit_equal(rho.cpu().numpy(),
+                     o.wright_density(d["thetao"].values.astype(np.float32), d["so"].values,
+                                      pres[:, None, None]), "mixed dtypes, default policy")
+
+
+def test_cpu_torch_tensors_are_staged_like_numpy_arrays():
+    """A CPU torch.Tensor field is host memory like any numpy array: engine.TimeChunks moves it
+    through hostio's page-locked staging on the copy stream, with an event, allocated under the
+    consumer's stream (it used to take a bare `.to(device)` in the worker thread) --
+    same bits as the numpy input, also under a caller's non-default stream"""
+    from momlevel_amd import engine
+
+    d = _masked_dataset(nt=7, nz=6, ny=32, nx=48)
+    T, S = d["thetao"].values, d["so"].values
+    vol0 = torch.from_numpy(d["volcello"].values[0]).cuda()
+    pres = o.pressure_from_depth(d["z_l"].values)
+    want = engine.global_masso(T, S, vol0, pres, steps=3).cpu().numpy()
+    seen = []
+    import momlevel_amd.hostio as hostio
+
+    real = hostio.upload
+
+    def spy(host, dev, stream=None, ring=None):
+        seen.append((host.numel() * host.element_size(), stream is not None))
+        return real(host, dev, stream=stream, ring=ring)
+
+    hostio.upload, saved = spy, hostio.upload
+    try:
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            got = engine.global_masso(torch.from_numpy(T.copy()), torch.from_numpy(S.copy()), vol0,
+                                      pres, steps=3)
+        side.synchronize()
+    finally:
+        hostio.upload = saved
+    assert np.array_equal(got.cpu().numpy(), want)
+    chunk = 3 * T[0].size * 8
+    assert sum(1 for n, on_stream in seen if n >= chunk // 2 and on_stream) >= 4  # theta and S chunks
+
+
 @pytest.mark.parametrize("domain", ["local", "global"])
 def test_reference_state_of_another_precision(domain):
     """steric(dset, reference=...) with a float64 reference state and float32 fields (a reference
