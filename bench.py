@@ -473,6 +473,8 @@ def main():
         # float32 one (outputs of the float64 run are host-side by now)
         del T, S
         extras["config5_f32"] = f32_timings(vol0, pres, g, dev, nt, kw)
+        if (nz, ny, nx) == GRID:
+            extras["reference_example_call"] = example_call()
 
     if rank == 0:
         layout = {1: "1x1", 2: "1x2", 4: "2x2", 8: "2x4"}.get(world, f"1x{world}")
@@ -576,6 +578,29 @@ def local_slab_check(o, Tn, Sn, rho0, g, pres, drho_gpu, eta_gpu):
     if drho_gpu is not None:
         ok = ok and bool(np.array_equal(drho_gpu, dref, equal_nan=True))
     return ok
+
+
+def example_call():
+    """Informative, PCIe-INCLUSIVE, never the bench value: the reference's one recorded real-size
+    call -- examples/example.ipynb cells 3-6, `thermosteric(ds)` on time 60 x z_l 35 x yh 1080 x xh
+    1440 float32 fields with the default domain="local" -- through the PRODUCT's public signature on
+    numpy-backed (host) inputs of that shape: upload through the staging ring, K2 (thermosteric,
+    float32, delta_rho), delta_rho and eta back into numpy arrays; one step checked bit for bit
+    against the oracle, whose one-thread time for that step is extrapolated to the call."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.spec_from_file_location(
+            "example_call", os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts",
+                                         "example_call.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        torch.cuda.empty_cache()
+        out = mod.run()
+        torch.cuda.empty_cache()
+        return out
+    except Exception as exc:  # reported, never fatal for the bench line
+        return {"error": f"{type(exc).__name__}: {exc}"}
 
 
 def _time(fn, reps=3):

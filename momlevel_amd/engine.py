@@ -290,9 +290,9 @@ def sum_dtype(x):
 # local variant (src/momlevel/steric.py:150-166)
 # ---------------------------------------------------------------------------------------
 def _host_output(shape):
-    """float64 host array for results copied back from the device: page-locked memory of our own
-    when it is not huge (the D2H copy is then one asynchronous DMA and the pages are already
-    resident); see hostio.pinned_array."""
+    """float64 host array for results copied back from the device: an ordinary numpy array filled
+    through the staging ring (the default), or page-locked memory of our own when the caller opted
+    in; see hostio.pinned_array."""
     return hostio.pinned_array(shape, np.float64)
 
 

@@ -11,8 +11,10 @@ section 7).  So this module never shows the GPU a byte of foreign memory:
 * uploads go through a small ring of page-locked staging buffers (torch's pinned allocator:
   hipHostMalloc'ed once, reused for the life of the process): the host copies piece k+1 into one
   buffer with all its cores while the DMA engine drains piece k from another;
-* downloads land in page-locked arrays of our own, handed to the caller as numpy arrays (or, for
-  results too large to keep pinned, come back through the same ring).
+* downloads come back through the same ring into ordinary numpy arrays (8 memcpy threads; 47 GB/s
+  end to end, first touch of the fresh pages included) or, opt-in, land in page-locked arrays of our
+  own handed to the caller as numpy arrays (one DMA at 57 GB/s -- after ~1 s per 16 GB to allocate
+  them: profiles/r04_d2h_probe.log).
 
 Nothing here computes: allocation, copies, stream ordering (torch as the device-array container).
 """
@@ -253,13 +255,20 @@ def to_device(x, device, dtype=None):
     return dev if dtype is None or dev.dtype == dtype else dev.to(dtype)
 
 
-PINNED_RESULT_LIMIT = 32 << 30
+# Results up to this size are returned in page-locked arrays of our own (one asynchronous DMA each);
+# larger ones in ordinary numpy arrays filled through the staging ring.  Default 0 = always the ring
+# (round 4): allocating page-locked memory costs ~1 s per 16 GB on the MI355X hosts, so a fresh
+# page-locked result array is 4x slower END TO END than the ring (alloc 15 GB/s + DMA 57 GB/s
+# against DMA + 8 memcpy threads = 47 GB/s, first touch of the pageable pages included --
+# profiles/r04_d2h_probe.log); it only pays for callers that free their results between calls, so
+# that torch's pinned allocator can hand the same block out again: MOMLEVEL_AMD_PINNED_RESULT_MIB.
+PINNED_RESULT_LIMIT = int(os.environ.get("MOMLEVEL_AMD_PINNED_RESULT_MIB", "0")) << 20
 
 
 def pinned_array(shape, dtype=np.float64):
-    """A page-locked numpy array of our own (the DMA target of result downloads); the array keeps
-    its pinned tensor alive.  Falls back to pageable memory (filled through the ring) when the
-    result is too large to keep page-locked or the pinned allocation fails."""
+    """The host array a result is downloaded into: a page-locked numpy array of our own (it keeps
+    its pinned tensor alive) up to PINNED_RESULT_LIMIT bytes, else -- the default -- an ordinary
+    numpy array, which download_into() fills through the staging ring."""
     tdt = {np.dtype(np.float64): torch.float64, np.dtype(np.float32): torch.float32}[np.dtype(dtype)]
     nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
     if 0 < nbytes <= PINNED_RESULT_LIMIT:
@@ -322,7 +331,7 @@ def download_into(out, dev, stream=None):
 
 
 def to_host(t):
-    """Device tensor -> numpy array (a page-locked array of ours when not small; synchronises)."""
+    """Device tensor -> numpy array (through the staging ring when not small; synchronises)."""
     if not (isinstance(t, torch.Tensor) and t.is_cuda):
         return t.detach().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
     t = t.detach()

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""The reference's one recorded real-size call, end to end: examples/example.ipynb cells 3-6 run
+`momlevel.thermosteric(ds)` on time 60 x z_l 35 x yh 1080 x xh 1440, float32, with the default
+domain="local" -- from HOST memory, delta_rho returned.  Here: the same call on momlevel_amd with
+numpy-backed inputs of that shape (synthetic fields), wall-clock including the PCIe transfers both
+ways, next to the numpy oracle's time for one time step of the same call.
+
+    python scripts/example_call.py [--nt 60] [--nz 35]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import momlevel_amd as m  # noqa: E402
+from momlevel_amd import core, hostio, synthetic  # noqa: E402
+from momlevel_amd.labeled import DataArray, Dataset  # noqa: E402
+
+
+def run(nt=60, nz=35, reps=2, ny=1080, nx=1440):
+    g = synthetic.make_grid(ny, nx, nz)
+    vol0 = hostio.to_device(g["volcello"], "cuda")
+    kw = dict(seed=synthetic.SEED, mask3d=vol0)
+    shape = (nt, nz, ny, nx)
+    # host-resident float32 fields (generated on the device, brought to pageable host memory)
+    host = {}
+    for name, fid, lo, sc in (("thetao", 1, -2.0, 34.0), ("so", 2, 30.0, 10.0)):
+        dev = core.synth_field(shape, torch.float32, field_id=fid, lo=lo, scale=sc, **kw)
+        host[name] = np.array(hostio.to_host(dev))  # a plain (pageable) numpy array, as a user has
+        del dev
+    torch.cuda.empty_cache()
+    d = Dataset()
+    d["time"] = DataArray(np.arange(nt, dtype=float), ("time",))
+    d["z_l"] = DataArray(g["z_l"], ("z_l",))
+    d["z_i"] = DataArray(g["z_i"], ("z_i",))
+    dims = ("time", "z_l", "yh", "xh")
+    d["thetao"] = DataArray(host["thetao"], dims)
+    d["so"] = DataArray(host["so"], dims)
+    d["volcello"] = DataArray(np.broadcast_to(g["volcello"].astype(np.float32), shape), dims)
+    d["areacello"] = DataArray(g["areacello"].astype(np.float32), ("yh", "xh"))
+    d["deptho"] = DataArray(g["deptho"], ("yh", "xh"))
+    cells = nt * nz * ny * nx
+    out = {"call": "thermosteric(ds)  # domain='local', float32 thetao/so from host memory, delta_rho returned",
+           "shape_t_z_y_x": list(shape), "cells": cells,
+           "host_bytes_in_GB": round(2 * cells * 4 / 1e9, 2),
+           "host_bytes_out_GB": round((cells + nt * ny * nx) * 8 / 1e9, 2)}
+    walls = []
+    res = ref = drho = eta = None
+    for _ in range(reps):
+        del res, ref, drho, eta  # (freeing 27 GB of earlier results is the caller's time, not the call's)
+        import gc
+
+        gc.collect()
+        t0 = time.perf_counter()
+        res, ref = m.thermosteric(d)
+        drho = res["delta_rho"].values  # host arrays: the call has synchronised
+        eta = res["thermosteric"].values
+        walls.append(time.perf_counter() - t0)
+        assert drho.shape == shape and eta.shape == (nt, ny, nx) and drho.dtype == np.float64
+    out["wall_s"] = [round(w, 3) for w in walls]
+    best = min(walls)
+    out["Mcells/s_end_to_end"] = round(cells / best / 1e6, 1)
+    # thermosteric streams theta only (S is held at the reference state: one slab)
+    out["host_bytes_streamed_in_GB"] = round(cells * 4 / 1e9, 2)
+    out["GB/s_host_link_in_plus_out"] = round((cells * 4 + (cells + nt * ny * nx) * 8) / best / 1e9, 1)
+    # the oracle (numpy, op for op) on ONE time step of the same call, one thread
+    from oracle import momlevel_numpy as o  # the checker / CPU baseline
+
+    pn = o.pressure_from_depth(g["z_l"])
+    T0, S0 = host["thetao"][0], host["so"][0]
+    rho0 = o.calc_rho(T0, S0, pn)
+    t = nt // 2
+    t0 = time.perf_counter()
+    rho = o.calc_rho(host["thetao"][t], S0, pn)
+    dref = np.where(~np.isnan(g["volcello"]), rho - rho0, np.nan)
+    dz = o.calc_dz(g["z_l"], g["z_i"], g["deptho"])
+    eref = np.where(~np.isnan(g["volcello"][0]), (-1.0 / 1035.0) * o.nansum(dz * dref, axis=0), np.nan)
+    cpu = time.perf_counter() - t0
+    out["oracle_one_step_s_1_thread"] = round(cpu, 3)
+    out["oracle_whole_call_extrapolated_s"] = round(cpu * nt, 1)
+    out["speedup_vs_oracle_1_thread"] = round(cpu * nt / best, 1)
+    out["step_bit_identical_to_oracle"] = bool(np.array_equal(drho[t], dref, equal_nan=True)
+                                               and np.array_equal(eta[t], eref, equal_nan=True))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nt", type=int, default=60)
+    ap.add_argument("--nz", type=int, default=35)
+    ap.add_argument("--reps", type=int, default=2)
+    a = ap.parse_args()
+    print(json.dumps(run(a.nt, a.nz, a.reps)), flush=True)
+
+
+if __name__ == "__main__":
+    main()

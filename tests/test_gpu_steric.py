@@ -603,10 +603,10 @@ def test_memory_mapped_inputs_stream_from_disk(tmp_path, monkeypatch):
 
 def test_uploads_and_downloads_go_through_owned_staging(monkeypatch):
     """Round 3: no GPU mapping of caller memory, ever (hostio.py) -- host chunks are copied into a
-    ring of page-locked staging buffers of our own and DMA'd from there, results land in
-    page-locked arrays of our own (or come back through the ring when too large to keep pinned).
-    Forced here through many small pieces (ring wrap-around, ragged last piece) and through the
-    pageable-result path; same bits as the plain path every time."""
+    ring of page-locked staging buffers of our own and DMA'd from there, results come back through
+    the ring into ordinary numpy arrays (round 4's default) or, opt-in, land in page-locked arrays
+    of our own.  Forced here through many small pieces (ring wrap-around, ragged last piece) and
+    through both result paths; same bits as the plain path every time."""
     from momlevel_amd import engine, hostio
 
     d = _masked_dataset(nt=6, nz=12, ny=64, nx=96)  # 590 KB per step and field
@@ -631,11 +631,15 @@ def test_uploads_and_downloads_go_through_owned_staging(monkeypatch):
     assert_bit_equal(res["delta_rho"].values, base["delta_rho"].values)
     gres, _ = steric(d, domain="global")
     assert_bit_equal(gres["steric"].values, gbase["steric"].values)
-    # results too large to keep page-locked: pageable arrays filled through the same ring
-    monkeypatch.setattr(hostio, "PINNED_RESULT_LIMIT", 0)
+    # the default: results come back through the same ring into ordinary numpy arrays ...
+    assert hostio.PINNED_RESULT_LIMIT == 0
+    assert not torch.from_numpy(res["delta_rho"].values).is_pinned()
+    # ... page-locked result arrays are opt-in (MOMLEVEL_AMD_PINNED_RESULT_MIB): one DMA each
+    monkeypatch.setattr(hostio, "PINNED_RESULT_LIMIT", 1 << 30)
     acquired.clear()
     big, _ = steric(d)
-    assert acquired
+    assert acquired  # (the uploads)
+    assert torch.from_numpy(big["delta_rho"].values).is_pinned()
     assert_bit_equal(big["steric"].values, base["steric"].values)
     assert_bit_equal(big["delta_rho"].values, base["delta_rho"].values)
     # the staging buffers are page-locked memory of torch's allocator, never the caller's array
@@ -742,7 +746,8 @@ def test_hostio_round_trip_ragged_sizes(monkeypatch):
             t = hostio.to_device(a, "cuda")
             assert t.dtype == (torch.float64 if dtype == np.float64 else torch.float32)
             assert np.array_equal(t.cpu().numpy(), a)
-            for out in (hostio.pinned_array((n,), dtype), np.empty(n, dtype)):
+            pinned = torch.empty(n, dtype=t.dtype, pin_memory=True).numpy()
+            for out in (pinned, hostio.pinned_array((n,), dtype), np.empty(n, dtype)):
                 hostio.download_into(out, t)
                 torch.cuda.synchronize()
                 assert np.array_equal(out, a)
