@@ -107,15 +107,15 @@ def launch_local_ranks(n, argv, environ=None, visible_gpus=None, out=None, grace
 
     pump = threading.Thread(target=relay, daemon=True)
     pump.start()
-    deadline = None
+    deadline, killing = None, False
     while any(p.poll() is None for p in procs):
         if deadline is None and any(p.poll() not in (None, 0) for p in procs):
             deadline = time.time() + grace  # a rank died: the others are stuck in a collective
         if deadline is not None and time.time() > deadline:
             for p in procs:
                 if p.poll() is None:
-                    p.terminate()
-            deadline = float("inf")
+                    (p.kill if killing else p.terminate)()  # SIGTERM first, SIGKILL 10 s later
+            deadline, killing = (float("inf") if killing else time.time() + 10.0), True
         time.sleep(0.05)
     pump.join(timeout=10)
     codes = [p.returncode for p in procs]
