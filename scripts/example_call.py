@@ -31,7 +31,8 @@ def run(nt=60, nz=35, reps=2, ny=1080, nx=1440):
     host = {}
     for name, fid, lo, sc in (("thetao", 1, -2.0, 34.0), ("so", 2, 30.0, 10.0)):
         dev = core.synth_field(shape, torch.float32, field_id=fid, lo=lo, scale=sc, **kw)
-        host[name] = np.array(hostio.to_host(dev))  # a plain (pageable) numpy array, as a user has
+        host[name] = hostio.to_host(dev)  # a plain (pageable) numpy array, as a user has
+        assert not torch.from_numpy(host[name]).is_pinned()
         del dev
     torch.cuda.empty_cache()
     d = Dataset()
