@@ -93,7 +93,8 @@ extern "C" {
                                never leave HBM.  0 = load every cell, wet or dry.               */
 #define MLX_FLAG_FMA 2      /* fused arithmetic for the Wright DENSITY: the reference's expression
                                tree with every "c + a*b" contracted into one fma and the quotient
-                               taken by a Newton reciprocal.  NOT bit-identical to numpy:
+                               taken from the hardware reciprocal seed and a cubic correction
+                               (<= 1 ulp).  NOT bit-identical to numpy:
                                - MLX_DTYPE_F64: rho differs by a few ulp (parity gate: 1e-10 relative
                                  on rho and masso, 1e-10*max|ref| on delta_rho and eta);
                                - MLX_DTYPE_F32 (numpy's mixed precision): the float32 polynomial is

@@ -40,7 +40,7 @@ def arith_default(kernel="k0", dtype=None):
     """Arithmetic of the Wright density when the caller does not choose (``arith=None``).
 
     "exact": numpy's operator-for-operator evaluation, bit-identical to the reference.
-    "fused": MLX_FLAG_FMA -- contracted multiply-adds and a Newton reciprocal: on float64 theta/S the
+    "fused": MLX_FLAG_FMA -- contracted multiply-adds and a refined hardware reciprocal: on float64 theta/S the
     whole expression (<= 2 ulp from numpy on rho, two thirds of the VALU work per cell); on float32
     theta/S in numpy's mixed precision (``f32_mode="faithful"``) the float32 polynomial is kept
     exactly as numpy rounds it and only the float64 tail is fused (a few float64 ulp from numpy's

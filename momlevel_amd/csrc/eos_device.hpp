@@ -97,8 +97,8 @@ struct Lanes<f2> {
 //   reference's operator order; results are bit-identical to eos/wright.py on the host.
 // FusedOps (MLX_FLAG_FMA; momlevel_amd's default for the global sums, opt-in elsewhere): the same
 //   expression tree with each "c + a*b" node contracted
-//   into one fma and the quotient taken by a Newton reciprocal (v_rcp_f64 + 1 refinement + exact
-//   residual correction; the Wright denominator lives near 2^19, far from over/underflow).  Not
+//   into one fma and the quotient num/den taken as num*r0*(1 + e + e^2) from the v_rcp_f64 seed r0
+//   (e = 1 - den*r0: <= 1 ulp; the Wright denominator lives near 2^19, far from over/underflow).  Not
 //   bit-identical to numpy: |rho_fused - rho_numpy| <= a few ulp (parity gate 1e-10 relative).
 //   float64 arithmetic; float32 theta/S in numpy's mixed precision keep their float32 polynomial
 //   and fuse the float64 tail only (FusedTailOps below).
@@ -166,6 +166,11 @@ __device__ __forceinline__ double rcp_scale_free(double den, double& seed) {
 // the others: profiles/r04_batched_reciprocal_negative.txt.)
 #ifndef MLX_TUNE_FMA_ACC
 #define MLX_TUNE_FMA_ACC 1
+#endif
+// MLX_TUNE_CUBIC_QUOTIENT (round 4, default on): FusedOps::quotient in five instructions instead
+// of six (see there); 3-5 % on the issue-bound kernels (profiles/r04_tune_cubic_quotient.log).
+#ifndef MLX_TUNE_CUBIC_QUOTIENT
+#define MLX_TUNE_CUBIC_QUOTIENT 1
 #endif
 
 struct ExactOps {
@@ -235,10 +240,22 @@ struct FusedOps {
   // +2 instructions per cell and -4.5 % on the thermosteric sums, profiles/r03_variants_summary.json
   // -- not worth it for inputs that are not sea water.)
   static __device__ __forceinline__ double quotient(double num, double den, lanemask_t&) {
-    double r = __builtin_amdgcn_rcp(den);           // ~2^-23 relative
-    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);  // ~2^-45
-    const double q = num * r;
-    return __builtin_fma(__builtin_fma(-den, q, num), r, q);  // exact residual: <= 1 ulp
+    const double r0 = __builtin_amdgcn_rcp(den);  // 1/den * (1 - e), |e| ~ 2^-23
+    if constexpr (MLX_TUNE_CUBIC_QUOTIENT) {
+      // num/den = num*r0 * (1 + e + e^2 + ...): the cubic truncation leaves e^3 ~ 2^-69, so
+      // q0*(1 + e + e^2) is num/den to <= 1 ulp (the roundings of q0 and of the last fma; checked
+      // in exact rational arithmetic over 2e4 Wright-sized operands with seeds as bad as 2^-22:
+      // max 0.993 ulp) -- five VALU instructions where Newton + the residual correction took six
+      // (round 4).  q0 does not wait for e: the two chains run side by side.
+      const double e = __builtin_fma(-den, r0, 1.0);
+      const double q0 = num * r0;
+      const double t = __builtin_fma(e, e, e);
+      return __builtin_fma(q0, t, q0);
+    } else {
+      const double r = __builtin_fma(__builtin_fma(-den, r0, 1.0), r0, r0);  // ~2^-45
+      const double q = num * r;
+      return __builtin_fma(__builtin_fma(-den, q, num), r, q);  // exact residual: <= 1/2 ulp
+    }
   }
   static __device__ __forceinline__ lanemask_t p_unsafe(double) { return 0; }
   static __device__ __forceinline__ lanemask_t p_unsafe_lanes(double) { return 0; }
@@ -247,7 +264,7 @@ struct FusedOps {
 // MLX_FLAG_FMA on float32 theta/S in numpy's mixed precision (MLX_DTYPE_F32): the POLYNOMIAL stays
 // what numpy computes on float32 arrays -- float32, every + and * rounded separately, because that
 // rounding (1e-7 relative) is what makes a float32 result a float32 result -- and only the float64
-// TAIL is fused: den = fma(al0, p + p0, lam) and FusedOps' Newton quotient.  rho is then within a
+// TAIL is fused: den = fma(al0, p + p0, lam) and FusedOps' quotient.  rho is then within a
 // few float64 ulp of numpy's own value on float32 input (FusedOps on upcast values is 1e-7 away),
 // for four instructions per cell less than the exact tail.
 struct FusedTailOps {
