@@ -139,15 +139,16 @@ def valu_profiles():
 
 def measure_valu_probe(dev):
     """This box's float64 VALU issue rate, lane-instructions per second: mlx_valu_probe (nothing but
-    independent v_fma_f64 chains), best of three launches of ~70 ms (128 fmas per chain: 2.1e12
-    lane-instructions)."""
-    core.valu_probe(16, dev)
+    independent v_fma_f64 chains), best of three launches of ~9 ms (16384 fmas per chain: 2.7e11
+    lane-instructions -- long enough that launch ramp and tail do not show: at 128 fmas per chain the
+    launch lasts 70 us and reads 15 % low)."""
+    core.valu_probe(256, dev)
     torch.cuda.synchronize(dev)
     best = 0.0
     for _ in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        n = core.valu_probe(128, dev)
+        n = core.valu_probe(16384, dev)
         e1.record()
         torch.cuda.synchronize(dev)
         best = max(best, n / (e0.elapsed_time(e1) * 1e-3))

@@ -422,7 +422,7 @@ def stream_probe_mix(a, b=None, out=None, write=True):
     return out
 
 
-def valu_probe(iters=128, device="cuda"):
+def valu_probe(iters=4096, device="cuda"):
     """Measurement aid: enqueue the float64 VALU issue-rate probe (mlx_valu_probe) on ``device``'s
     current stream; returns the number of v_fma_f64 lane-instructions the launch issues."""
     require_device()

@@ -680,7 +680,7 @@ def test_valu_probe_reports_its_instruction_count():
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    n = core.valu_probe(128)
+    n = core.valu_probe(4096)  # ~2 ms: long enough for the rate to mean something
     e1.record()
     torch.cuda.synchronize()
     rate = n / (e0.elapsed_time(e1) * 1e-3)
