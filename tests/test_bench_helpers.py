@@ -136,3 +136,32 @@ def test_bench_main_becomes_the_launcher_before_any_gpu_call(monkeypatch):
     assert exc.value.code == 0
     assert seen["n"] == 2 and seen["argv"][1].endswith("bench.py")
     assert seen["argv"][2:] == ["--gpus", "2", "--nt", "10", "--steps", "2"]
+
+
+def test_valu_roofline_fields_come_from_the_profile_of_these_sources():
+    """bench.add_valu_roofline: every timed kernel that the round's committed SQ_INSTS_VALU profile
+    covers gets valu_instr_per_cell / frac_of_valu_peak / frac_of_f64_fma_probe -- quoted, like
+    roofline.traffic, only while the profile's kernel-source sha is the current one"""
+    instr, sources = bench.valu_profiles()
+    with open(os.path.join(ROOT, "profiles", "r04_variants_summary.json")) as f:
+        summ = json.load(f)
+    line = {"value": 1.0,
+            "roofline": {"achieved": 6400.0, "algorithmic_bytes_per_cell": 16},
+            "thermosteric_global": {"Mcells/s": 800000.0},
+            "config5_f32": {"default": {"local_thermosteric_with_delta_rho": {"Mcells/s": 380000.0}},
+                            "faithful_fused": {"one_pass": {"Mcells/s": 400000.0}}}}
+    bench.add_valu_roofline(line, f64_probe=30.0e12)
+    assert line["valu_roofline"]["peak_lane_instr_per_s"] == 256 * 4 * 16 * 2.4e9
+    if summ["kernel_source_sha"] != bench.kernel_source_sha():
+        assert instr == {} and sources == [] and "valu_instr_per_cell" not in line["roofline"]
+        return
+    assert "profiles/r04_variants_summary.json" in sources
+    r = line["roofline"]  # 6400 GB/s at 16 B/cell = 400 Gcells/s
+    assert r["valu_instr_per_cell"] == instr["roofline"]
+    assert abs(r["frac_of_valu_peak"] - instr["roofline"] * 400e9 / (256 * 4 * 16 * 2.4e9)) < 1e-3
+    assert abs(r["frac_of_f64_fma_probe"] - instr["roofline"] * 400e9 / 30.0e12) < 1e-3
+    t = line["thermosteric_global"]
+    assert t["valu_instr_per_cell"] == instr["thermosteric_global"] < instr["thermosteric_global_exact"]
+    k2 = line["config5_f32"]["default"]["local_thermosteric_with_delta_rho"]
+    assert k2["valu_instr_per_cell"] == instr["config5_f32.default.local_thermosteric_with_delta_rho"]
+    assert "frac_of_f64_fma_probe" in line["config5_f32"]["faithful_fused"]["one_pass"]
