@@ -582,6 +582,28 @@ def local_slab_check(o, Tn, Sn, rho0, g, pres, drho_gpu, eta_gpu):
     return ok
 
 
+def _example_call_checker(host, g, drho, eta, wall_s):
+    """CPU leg of the example call: the oracle (numpy, op for op; one thread) on ONE time step of
+    thermosteric(ds) -- its time extrapolated to the call, its delta_rho / eta against the GPU's."""
+    from oracle import momlevel_numpy as o  # the checker / CPU baseline, never the product
+
+    nt = host["thetao"].shape[0]
+    pn = o.pressure_from_depth(g["z_l"])
+    rho0 = o.calc_rho(host["thetao"][0], host["so"][0], pn)
+    t = nt // 2
+    t0 = time.perf_counter()
+    rho = o.calc_rho(host["thetao"][t], host["so"][0], pn)
+    dref = np.where(~np.isnan(g["volcello"]), rho - rho0, np.nan)
+    dz = o.calc_dz(g["z_l"], g["z_i"], g["deptho"])
+    eref = np.where(~np.isnan(g["volcello"][0]), (-1.0 / 1035.0) * o.nansum(dz * dref, axis=0), np.nan)
+    cpu = time.perf_counter() - t0
+    return {"oracle_one_step_s_1_thread": round(cpu, 3),
+            "oracle_whole_call_extrapolated_s": round(cpu * nt, 1),
+            "speedup_vs_oracle_1_thread": round(cpu * nt / wall_s, 1),
+            "step_bit_identical_to_oracle": bool(np.array_equal(drho[t], dref, equal_nan=True)
+                                                 and np.array_equal(eta[t], eref, equal_nan=True))}
+
+
 def example_call():
     """Informative, PCIe-INCLUSIVE, never the bench value: the reference's one recorded real-size
     call -- examples/example.ipynb cells 3-6, `thermosteric(ds)` on time 60 x z_l 35 x yh 1080 x xh
@@ -598,7 +620,7 @@ def example_call():
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         torch.cuda.empty_cache()
-        out = mod.run()
+        out = mod.run(checker=_example_call_checker)
         torch.cuda.empty_cache()
         return out
     except Exception as exc:  # reported, never fatal for the bench line

@@ -3,7 +3,8 @@
 `momlevel.thermosteric(ds)` on time 60 x z_l 35 x yh 1080 x xh 1440, float32, with the default
 domain="local" -- from HOST memory, delta_rho returned.  Here: the same call on momlevel_amd with
 numpy-backed inputs of that shape (synthetic fields), wall-clock including the PCIe transfers both
-ways, next to the numpy oracle's time for one time step of the same call.
+ways.  (bench.py runs this with a checker that holds one time step against the numpy oracle and
+times the oracle on it; the script by itself only times the product.)
 
     python scripts/example_call.py [--nt 60] [--nz 35]
 """
@@ -22,7 +23,7 @@ from momlevel_amd import core, hostio, synthetic  # noqa: E402
 from momlevel_amd.labeled import DataArray, Dataset  # noqa: E402
 
 
-def run(nt=60, nz=35, reps=2, ny=1080, nx=1440):
+def run(nt=60, nz=35, reps=2, ny=1080, nx=1440, checker=None):
     g = synthetic.make_grid(ny, nx, nz)
     vol0 = hostio.to_device(g["volcello"], "cuda")
     kw = dict(seed=synthetic.SEED, mask3d=vol0)
@@ -69,24 +70,8 @@ def run(nt=60, nz=35, reps=2, ny=1080, nx=1440):
     # thermosteric streams theta only (S is held at the reference state: one slab)
     out["host_bytes_streamed_in_GB"] = round(cells * 4 / 1e9, 2)
     out["GB/s_host_link_in_plus_out"] = round((cells * 4 + (cells + nt * ny * nx) * 8) / best / 1e9, 1)
-    # the oracle (numpy, op for op) on ONE time step of the same call, one thread
-    from oracle import momlevel_numpy as o  # the checker / CPU baseline
-
-    pn = o.pressure_from_depth(g["z_l"])
-    T0, S0 = host["thetao"][0], host["so"][0]
-    rho0 = o.calc_rho(T0, S0, pn)
-    t = nt // 2
-    t0 = time.perf_counter()
-    rho = o.calc_rho(host["thetao"][t], S0, pn)
-    dref = np.where(~np.isnan(g["volcello"]), rho - rho0, np.nan)
-    dz = o.calc_dz(g["z_l"], g["z_i"], g["deptho"])
-    eref = np.where(~np.isnan(g["volcello"][0]), (-1.0 / 1035.0) * o.nansum(dz * dref, axis=0), np.nan)
-    cpu = time.perf_counter() - t0
-    out["oracle_one_step_s_1_thread"] = round(cpu, 3)
-    out["oracle_whole_call_extrapolated_s"] = round(cpu * nt, 1)
-    out["speedup_vs_oracle_1_thread"] = round(cpu * nt / best, 1)
-    out["step_bit_identical_to_oracle"] = bool(np.array_equal(drho[t], dref, equal_nan=True)
-                                               and np.array_equal(eta[t], eref, equal_nan=True))
+    if checker is not None:  # bench.py's CPU leg: the oracle on one step of the same call
+        out.update(checker(host, g, drho, eta, best))
     return out
 
 
