@@ -589,6 +589,21 @@ template <typename R>
 __device__ __forceinline__ SPart<double> widen_part(const SPart<R>& b) {
   return SPart<double>{(double)b.a2s, (double)b.b04, (double)b.b5s, (double)b.c04, (double)b.c5s};
 }
+// The same rule for the fast kernels, which evaluate the two parts separately (round 4: theta and
+// salinity of different dtypes on the 16-byte-load kernels): the float32 field's part in float32
+// with numpy's two roundings per multiply-add, widened exactly; the other field's part as the
+// kernel's policy evaluates it.  RV is double there (one cell per arithmetic group).
+template <int MODE, typename Ops, typename RV>
+__device__ __forceinline__ TPart<RV> t_part_m(RV T) {
+  if constexpr (MODE == kMixT32) return widen_part(t_part<ExactOps, float>((float)T));
+  else return t_part<Ops, RV>(T);
+}
+template <int MODE, typename Ops, typename RV>
+__device__ __forceinline__ SPart<RV> s_part_m(RV S, RV p_fold) {
+  if constexpr (MODE == kMixS32) return widen_part(s_part<ExactOps, float>((float)S, 0.0f));
+  else return s_part<Ops, RV>(S, p_fold);
+}
+
 template <int MODE>
 __device__ __forceinline__ double wright_density_mixed(double T, double S, double p) {
   static_assert(IsMixed<MODE>::value, "mixed-dtype modes only");

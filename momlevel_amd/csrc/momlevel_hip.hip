@@ -92,10 +92,18 @@ template <int MODE, bool IS_T, typename TIn, int VEC, bool STREAM = false>
 __device__ __forceinline__ Pack<TIn, VEC> load_field(const TIn* __restrict__ base, int64_t off) {
   constexpr bool F32_HERE = (MODE == kMixT32 && IS_T) || (MODE == kMixS32 && !IS_T);
   if constexpr (F32_HERE) {
-    static_assert(VEC == 1 && sizeof(TIn) == 8, "mixed dtypes run on the generic kernels");
+    static_assert((VEC == 1 || VEC == 2) && sizeof(TIn) == 8, "the other field is float64");
     Pack<TIn, VEC> r;
-    if constexpr (STREAM) r.v[0] = __builtin_nontemporal_load(reinterpret_cast<const float*>(base) + off);
-    else r.v[0] = reinterpret_cast<const float*>(base)[off];
+    const float* q = reinterpret_cast<const float*>(base) + off;
+    if constexpr (VEC == 2) {  // fast kernels: the two float32 cells of the pack in one 8-byte load
+      const Pack<float, 2> f = load_pack<float, 2, STREAM>(q);
+      r.v[0] = f.v[0];
+      r.v[1] = f.v[1];
+    } else if constexpr (STREAM) {
+      r.v[0] = __builtin_nontemporal_load(q);
+    } else {
+      r.v[0] = q[0];
+    }
     return r;
   } else {
     return load_pack<TIn, VEC, STREAM>(base + off);
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
       }
       if constexpr (!GENERIC) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) t0p[u][g] = t_part<Ops, RV>(Lanes<RV>::make(&h.v[g * W]));
+        for (int g = 0; g < G; ++g) t0p[u][g] = t_part_m<MODE, Ops, RV>(Lanes<RV>::make(&h.v[g * W]));
       }
     }
   }
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
       if constexpr (!GENERIC) {
 #pragma unroll
         for (int g = 0; g < G; ++g)
-          s0p[u][g] = s_part<Ops, RV>(Lanes<RV>::make(&h.v[g * W]), pfold_at(u, g));
+          s0p[u][g] = s_part_m<MODE, Ops, RV>(Lanes<RV>::make(&h.v[g * W]), pfold_at(u, g));
       }
     }
   }
@@ -312,7 +320,10 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
   // base + lane*16), so no barrier is involved: vmcnt(0) before the read-out, lgkmcnt(0) before the
   // buffer is overwritten by the next step's copies.
   constexpr bool PREFETCH = !(VAR == kVarAll && sizeof(TIn) == 8 && !GENERIC);
-  constexpr bool GLDS = !PREFETCH;
+  // (theta and salinity of different dtypes: the float32 field's pack is 8 bytes, not the 16 of an
+  //  LDS-DMA slot -- that rare all-variants kernel simply loads each step's packs when it needs them)
+  constexpr bool GLDS = !PREFETCH && !IsMixed<MODE>::value;
+  constexpr bool DIRECT = !PREFETCH && !GLDS;
   static_assert(!GLDS || sizeof(TIn) * VEC == 16, "one 16-byte LDS-DMA per pack");
   __shared__ f4_t stage[GLDS ? 2 * U : 1][kBlock];  // [field*U + u][thread]: 32 KiB
   Pack<TIn, VEC> curT[U], curS[U], nxtT[PREFETCH ? U : 1], nxtS[PREFETCH ? U : 1];
@@ -359,6 +370,17 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
       if (STREAM_T) curT[u] = nxtT[u];
       if (STREAM_S) curS[u] = nxtS[u];
     }
+    if constexpr (DIRECT) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        curT[u] = {};
+        curS[u] = {};
+        if (alive[u]) {
+          curT[u] = load_field<MODE, true, TIn, VEC, true>(T, (int64_t)t * t_stride_T + off[u]);
+          curS[u] = load_field<MODE, false, TIn, VEC, true>(S, (int64_t)t * t_stride_S + off[u]);
+        }
+      }
+    }
     if (PREFETCH && t + 1 < te) {  // issue the next step's loads before this step's arithmetic
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -397,8 +419,8 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
         // by group -- the same cell order as below, fewer densities live at a time
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-          const TPart<RV> a = t_part<Ops, RV>(Lanes<RV>::make(&curT[u].v[g * W]));
-          const SPart<RV> b = s_part<Ops, RV>(Lanes<RV>::make(&curS[u].v[g * W]), pfold_at(u, g));
+          const TPart<RV> a = t_part_m<MODE, Ops, RV>(Lanes<RV>::make(&curT[u].v[g * W]));
+          const SPart<RV> b = s_part_m<MODE, Ops, RV>(Lanes<RV>::make(&curS[u].v[g * W]), pfold_at(u, g));
           double r3[3][W];
           static_assert(!(P3D && VAR == kVarAll), "the all-variants kernel has no register to spare");
           wright_combine_lanes<Ops, RV>(a, b, pz, r3[0]);
@@ -422,9 +444,9 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
         for (int g = 0; g < G; ++g) {
           TPart<RV> a;
           SPart<RV> b;
-          if constexpr (STREAM_T) a = t_part<Ops, RV>(Lanes<RV>::make(&curT[u].v[g * W]));
+          if constexpr (STREAM_T) a = t_part_m<MODE, Ops, RV>(Lanes<RV>::make(&curT[u].v[g * W]));
           if constexpr (STREAM_S)
-            b = s_part<Ops, RV>(Lanes<RV>::make(&curS[u].v[g * W]), pfold_at(u, g));
+            b = s_part_m<MODE, Ops, RV>(Lanes<RV>::make(&curS[u].v[g * W]), pfold_at(u, g));
           double pg[W];
 #pragma unroll
           for (int w = 0; w < W; ++w) pg[w] = p_at(u, g * W + w);
@@ -676,8 +698,8 @@ __global__ __launch_bounds__(kBlock) void k_eos_map(const TIn* __restrict__ T,
         }
         RV pfold = RV{};
         if constexpr (Ops::fused) pfold = (R)pg[0];
-        wright_numden_lanes<Ops, RV>(t_part<Ops, RV>(Lanes<RV>::make(&a[u].v[k])),
-                                     s_part<Ops, RV>(Lanes<RV>::make(&b[u].v[k]), pfold), pg,
+        wright_numden_lanes<Ops, RV>(t_part_m<MODE, Ops, RV>(Lanes<RV>::make(&a[u].v[k])),
+                                     s_part_m<MODE, Ops, RV>(Lanes<RV>::make(&b[u].v[k]), pfold), pg,
                                      &num[k], &den[k]);
       }
       quotients<Ops, VEC>(num, den, r.v, pbad);
@@ -839,12 +861,12 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
     SPart<RV> hSp[G];
     if constexpr (!GENERIC && HELD_T) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) hTp[g] = t_part<Ops, RV>(Lanes<RV>::make(&hT.v[g * W]));
+      for (int g = 0; g < G; ++g) hTp[g] = t_part_m<MODE, Ops, RV>(Lanes<RV>::make(&hT.v[g * W]));
     }
     if constexpr (!GENERIC && HELD_S) {
 #pragma unroll
       for (int g = 0; g < G; ++g)
-        hSp[g] = s_part<Ops, RV>(Lanes<RV>::make(&hS.v[g * W]), pfold[g]);
+        hSp[g] = s_part_m<MODE, Ops, RV>(Lanes<RV>::make(&hS.v[g * W]), pfold[g]);
     }
 
     Pack<TIn, VEC> a[NTI], b[NTI];
@@ -888,9 +910,9 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
           for (int g = 0; g < G; ++g) {
             TPart<RV> tp;
             SPart<RV> sp;
-            if constexpr (STREAM_T) tp = t_part<Ops, RV>(Lanes<RV>::make(&a[j].v[g * W]));
+            if constexpr (STREAM_T) tp = t_part_m<MODE, Ops, RV>(Lanes<RV>::make(&a[j].v[g * W]));
             if constexpr (STREAM_S)
-              sp = s_part<Ops, RV>(Lanes<RV>::make(&b[j].v[g * W]), pfold[g]);
+              sp = s_part_m<MODE, Ops, RV>(Lanes<RV>::make(&b[j].v[g * W]), pfold[g]);
             double* const n0 = &num[0][g * W];
             double* const d0 = &den[0][g * W];
             const double* const pl = pg[g];
@@ -1175,7 +1197,9 @@ int check_common(const void* T, const void* S, int dtype, const double* p, int p
   return 0;
 }
 
-inline int vec_of(int dtype) { return (dtype == MLX_DTYPE_F64) ? kVec64 : kVec32; }
+// cells per pack of the fast kernels: 2 when a float64 field takes part (also theta and salinity of
+// different dtypes: the float32 field then comes as 8-byte loads), 4 for float32 fields
+inline int vec_of(int dtype) { return (dtype == MLX_DTYPE_F64 || mixed_dtype(dtype)) ? kVec64 : kVec32; }
 
 // the dwordx4 kernels need: Wright EOS, z-profile pressure, whole packs per plane and per time
 // stride, 16-byte aligned operands; everything else takes the generic (scalar) twin
@@ -1185,7 +1209,6 @@ inline int vec_of(int dtype) { return (dtype == MLX_DTYPE_F64) ? kVec64 : kVec32
 bool fast_layout(int dtype, int p_mode, int eos, int64_t plane, int64_t sT, int64_t sS,
                  std::initializer_list<const void*> ptrs, const void* p3d = nullptr) {
   const int vec = vec_of(dtype);
-  if (mixed_dtype(dtype)) return false;  // scalar loads of two element sizes: the generic twin
   if (eos != MLX_EOS_WRIGHT) return false;
   if (p_mode != MLX_P_ZPROF && !(p3d && p_mode == MLX_P_FULL3D && aligned(p3d, 16))) return false;
   if (plane % vec || sT % vec || sS % vec) return false;
@@ -1234,7 +1257,8 @@ void k1_flags(const K1Args& a, bool skip, bool fma) {
   constexpr int FM = MODE;   // (faithful float32 keeps its float32 polynomial under MLX_FLAG_FMA)
   constexpr bool S1 = !GEN;  // the generic twin has no skipping instantiation
   if constexpr (IsMixed<MODE>::value) {  // exact arithmetic only (the entry points refuse the flag)
-    k1_go<TIn, VEC, U, VAR, MODE, GEN, false, false>(a);
+    if (skip && S1) k1_go<TIn, VEC, U, VAR, MODE, GEN, S1, false>(a);
+    else k1_go<TIn, VEC, U, VAR, MODE, GEN, false, false>(a);
   } else if (fma) {
     if (skip && S1) k1_go<TIn, VEC, U, VAR, FM, GEN, S1, true>(a);
     else k1_go<TIn, VEC, U, VAR, FM, GEN, false, true>(a);
@@ -1263,6 +1287,8 @@ void k1_dispatch(const K1Args& a, int dtype, bool fast, int var, bool skip, bool
   if (fast) {
     if (dtype == MLX_DTYPE_F64) k1_var<double, kVec64, kU64, kF64, false>(a, var, skip, fma);
     else if (dtype == MLX_DTYPE_F32) k1_var<float, kVec32, kU32, kF32Faithful, false>(a, var, skip, fma);
+    else if (dtype == MLX_DTYPE_T32_S64) k1_var<double, kVec64, kU64, kMixT32, false>(a, var, skip, fma);
+    else if (dtype == MLX_DTYPE_T64_S32) k1_var<double, kVec64, kU64, kMixS32, false>(a, var, skip, fma);
     else k1_var<float, kVec32, kU32, kF32Upcast, false>(a, var, skip, fma);
   } else {
     if (dtype == MLX_DTYPE_F64) k1_var<double, 1, kUGen, kF64, true>(a, var, skip, fma);
@@ -1379,7 +1405,8 @@ void k2_flags(const K2Args& a, bool skip, bool fma) {
   constexpr int FM = MODE;
   constexpr bool S1 = !GEN;
   if constexpr (IsMixed<MODE>::value) {  // exact arithmetic only
-    k2_go<TIn, VEC, NTI, VAR, MODE, GEN, false, false>(a);
+    if (skip && S1) k2_go<TIn, VEC, NTI, VAR, MODE, GEN, S1, false>(a);
+    else k2_go<TIn, VEC, NTI, VAR, MODE, GEN, false, false>(a);
   } else if (fma) {
     if (skip && S1) k2_go<TIn, VEC, NTI, VAR, FM, GEN, S1, true>(a);
     else k2_go<TIn, VEC, NTI, VAR, FM, GEN, false, true>(a);
@@ -1447,7 +1474,7 @@ int steric_local_impl(const void* T, const void* S, const void* T0, const void* 
     if (eta_vstride < nt * plane || (delta_rho_out && drho_vstride < n4))
       return fail(MLX_E_SHAPE, "variant strides must be >= the size of one variant's field");
   }
-  const bool f64 = (dtype == MLX_DTYPE_F64);
+  const bool f64 = (dtype == MLX_DTYPE_F64) || mixed_dtype(dtype);  // the float64 kernel SHAPE
   // both strides must be whole packs too in the all-variants kernel (three fields, one base)
   bool fast = fast_layout(dtype, p_mode, eos, plane, sT, sS,
                           {T, S, T0, S0, rho0m, vol0_surface, eta_out, dz, dz ? nullptr : deptho,
@@ -1480,12 +1507,16 @@ int steric_local_impl(const void* T, const void* S, const void* T0, const void* 
   a.drho = delta_rho_out; a.eta = eta_out; a.drho_vstride = drho_vstride; a.eta_vstride = eta_vstride;
   a.p3d = fast && p_mode == MLX_P_FULL3D;
   if (fast) {
-    if (f64) k2_var<double, kVec64, 0, kVec64, kNTI64All, kF64, false>(a, var, skip, fma);
+    if (dtype == MLX_DTYPE_T32_S64)
+      k2_var<double, kVec64, 0, kVec64, kNTI64All, kMixT32, false>(a, var, skip, fma);
+    else if (dtype == MLX_DTYPE_T64_S32)
+      k2_var<double, kVec64, 0, kVec64, kNTI64All, kMixS32, false>(a, var, skip, fma);
+    else if (f64) k2_var<double, kVec64, 0, kVec64, kNTI64All, kF64, false>(a, var, skip, fma);
     else if (dtype == MLX_DTYPE_F32)
       k2_var<float, kVec32, 0, kVec32All, kNTI32All, kF32Faithful, false>(a, var, skip, fma);
     else k2_var<float, kVec32, 0, kVec32All, kNTI32All, kF32Upcast, false>(a, var, skip, fma);
   } else {
-    if (f64) k2_var<double, 1, kNTIGen, 1, kNTIGenAll, kF64, true>(a, var, skip, fma);
+    if (dtype == MLX_DTYPE_F64) k2_var<double, 1, kNTIGen, 1, kNTIGenAll, kF64, true>(a, var, skip, fma);
     else if (dtype == MLX_DTYPE_F32)
       k2_var<float, 1, kNTIGen, 1, kNTIGenAll, kF32Faithful, true>(a, var, skip, fma);
     else if (dtype == MLX_DTYPE_T32_S64)

@@ -326,7 +326,13 @@ def test_thetao_and_so_of_different_dtypes(variant, shape, dtypes):
     assert_bit_equal(ref["rho"].values, oref["rho"], "rho0, mixed dtypes")
     assert_bit_equal(res["delta_rho"].values, ores["delta_rho"], "delta_rho, mixed dtypes")
     assert_bit_equal(res[variant].values, ores[variant], "eta, mixed dtypes")
+    from momlevel_amd import _lib
+
     gres, gref = steric(d, variant=variant, domain="global")
+    # even planes run on the 16-byte-load kernels since round 4 (the float32 field in 8-byte loads),
+    # odd ones on the scalar twins: <type, cells per pack, packs, variant, mode, GENERIC, ...>
+    args = _lib.last_kernel().split("<")[1].split(",")
+    assert args[4] in ("3", "4") and args[5] == ("false" if (shape[2] * shape[3]) % 2 == 0 else "true")
     ogres, ogref = _oracle(d, variant=variant, domain="global")
     assert float(gres[variant][0]) == 0.0
     assert_rel(gref["masso"].values, ogref["masso"], RTOL_SUM, "masso0, mixed dtypes")
