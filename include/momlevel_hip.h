@@ -38,12 +38,13 @@
 extern "C" {
 #endif
 
-#define MLX_ABI_VERSION 5 /* 2: mlx_eos_map takes flags; mlx_steric_global_decomp, mlx_steric_local_decomp,
+#define MLX_ABI_VERSION 6 /* 2: mlx_eos_map takes flags; mlx_steric_global_decomp, mlx_steric_local_decomp,
                              mlx_stream_probe;
                              MLX_FLAG_FMA, MLX_FLAG_TCHUNK; MLX_P_FULL4D in K1/K2
                              3: mlx_build_kind; a NULL p (linear EOS) requires p_mode MLX_P_SCALAR
                              4: mlx_eos_map_promote (MLX_KIND_*); MLX_DTYPE_T32_S64 / _T64_S32 in K1/K2
-                             5: mlx_stream_probe_mix, mlx_valu_probe, mlx_last_kernel */
+                             5: mlx_stream_probe_mix, mlx_valu_probe, mlx_last_kernel
+                             6: mlx_host_copy */
 
 /* argument-error codes (negative) */
 #define MLX_E_NULL     (-1) /* a required pointer is NULL                      */
@@ -352,6 +353,19 @@ int mlx_synth_field(void *out, int dtype, int64_t nt, int64_t nz, int64_t ny, in
                     int64_t t0, int64_t NY, int64_t NX, int64_t y0, int64_t x0,
                     uint64_t seed, int field_id, double lo, double scale,
                     const double *mask3d, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * Host side of the staged transfers (momlevel_amd/hostio.py; no reference counterpart: the
+ * reference passes numpy arrays to numpy).  Copies nbytes of HOST memory from src to dst, split
+ * into page-aligned slices over `threads` (1..64) threads: the caller's and threads-1 workers of a
+ * team the library keeps (created on first use, shared by concurrent callers, re-created in a
+ * forked child).  Returns when dst is complete.  streaming != 0 writes dst with non-temporal stores
+ * (no read-for-ownership of the destination lines -- for data that is touched once: a result
+ * array, a staging buffer the DMA engine reads next).  The ranges must not overlap (MLX_E_SHAPE).
+ * Touches no device; callable concurrently on disjoint ranges.  One call per staging piece from
+ * Python: a foreign call, so the GIL is released for its whole duration.
+ * ------------------------------------------------------------------------------- */
+int mlx_host_copy(void *dst, const void *src, size_t nbytes, int threads, int streaming);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("MOMLEVEL_AMD_LIB") or os.path.join(HERE, "libmomlevel
 _ORACLE_DIR = os.path.join(os.path.dirname(HERE), "oracle")
 
 # ---- constants mirrored from include/momlevel_hip.h --------------------------------
-ABI_VERSION = 5
+ABI_VERSION = 6
 EOS_WRIGHT, EOS_LINEAR = 0, 1
 FUNC_DENSITY, FUNC_DRHO_DTEMP, FUNC_DRHO_DSAL, FUNC_ALPHA, FUNC_BETA, FUNC_IBH = 0, 1, 2, 3, 4, 5
 P_SCALAR, P_ZPROF, P_FULL3D, P_FULL4D = 0, 1, 2, 3
@@ -101,6 +101,7 @@ SIGNATURES = {
     "mlx_stream_probe_mix": (_int, [_vp, _vp, _int, _i64, _vp, _int, _vp]),
     "mlx_valu_probe": (_int, [_i64, _vp, ctypes.POINTER(ctypes.c_int64), _vp]),
     "mlx_calc_dz": (_int, [_vp, _vp, _i64, _i64, _dbl, _dbl, _int, _int, _vp, _vp]),
+    "mlx_host_copy": (_int, [_vp, _vp, _sz, _int, _int]),
     "mlx_synth_field": (
         _int,
         [_vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _u64, _int,

@@ -333,29 +333,26 @@ def local_steric(T, S, rho0, vol0, pres, rhozero, z_i=None, deptho=None, dz=None
             torch.empty((nt, nz, ny, nx), dtype=torch.float64, device=dev)
             if want_delta_rho else None
         )
-    # results go back on their own stream: the D2H of chunk k then overlaps the H2D of chunk
-    # k+1 (PCIe is full duplex, the copies use different DMA engines)
-    d2h = torch.cuda.Stream(device=dev) if out_host else None
-    main = torch.cuda.current_stream(dev)
-    for t0, t1, Tc, Sc in chunks:
-        pc = pressure_chunk(pres, t0, t1, dev)
-        if out_host:
-            d, e = core.steric_local(Tc, Sc, rho0m, surface, pc, neg_inv, dz=dz, z_i=z_i,
-                                     deptho=deptho, eos=eos, f32_mode=f32_mode,
-                                     want_delta_rho=want_delta_rho)
-            d2h.wait_stream(main)
-            # straight into the caller-visible arrays (one D2H pass, no intermediate copy)
-            hostio.download_into(eta[t0:t1], e, d2h)
-            if want_delta_rho:
-                hostio.download_into(drho[t0:t1], d, d2h)
-        else:
-            core.steric_local(Tc, Sc, rho0m, surface, pc, neg_inv, dz=dz, z_i=z_i,
-                              deptho=deptho, eos=eos, f32_mode=f32_mode,
+    # results go back on a stream and a worker thread of their own (hostio.Downloader): the D2H of
+    # chunk k overlaps the H2D of chunk k+1 (PCIe is full duplex, the copies use different DMA
+    # engines) and this loop goes straight on to chunk k+1's kernels
+    if not out_host:
+        for t0, t1, Tc, Sc in chunks:
+            core.steric_local(Tc, Sc, rho0m, surface, pressure_chunk(pres, t0, t1, dev), neg_inv,
+                              dz=dz, z_i=z_i, deptho=deptho, eos=eos, f32_mode=f32_mode,
                               want_delta_rho=want_delta_rho,
                               delta_rho_out=drho[t0:t1] if want_delta_rho else None,
                               eta_out=eta[t0:t1])
-    if d2h is not None:
-        d2h.synchronize()  # the host arrays are complete when we return
+        return drho, eta
+    with hostio.Downloader(dev) as results:
+        for t0, t1, Tc, Sc in chunks:
+            pc = pressure_chunk(pres, t0, t1, dev)
+            d, e = core.steric_local(Tc, Sc, rho0m, surface, pc, neg_inv, dz=dz, z_i=z_i,
+                                     deptho=deptho, eos=eos, f32_mode=f32_mode,
+                                     want_delta_rho=want_delta_rho)
+            # straight into the caller-visible arrays (one D2H pass, no intermediate array)
+            results.submit([(eta[t0:t1], e)] + ([(drho[t0:t1], d)] if want_delta_rho else []))
+    # (the host arrays are complete: the with-block waits for the last piece)
     return drho, eta
 
 
@@ -491,47 +488,49 @@ def local_steric_variants(T, S, T0, S0, rho0, vol0, pres, rhozero, variants, z_i
     else:
         eta = {v: alloc((nt_out, ny, nx)) for v in variants}
         drho = {v: (alloc((nt_out, nz, ny, nx)) if want_delta_rho else None) for v in variants}
-    d2h = torch.cuda.Stream(device=dev) if out_host else None
-    main = torch.cuda.current_stream(dev)
     kw = dict(dz=dz, z_i=z_i, deptho=deptho, eos=eos, f32_mode=f32_mode,
               want_delta_rho=want_delta_rho)
-    for t0, t1, Tc, Sc in chunks:
-        o0, o1 = (t0 // 12, t1 // 12) if annual else (t0, t1)
-        pc = pressure_chunk(pres, t0, t1, dev)
-        if direct:
-            core.steric_local_decomp(
-                Tc, Sc, T0, S0, rho0m, surface, pc, neg_inv,
-                delta_rho_out=drho_all[:, t0:t1] if want_delta_rho else None,
-                eta_out=eta_all[:, t0:t1], **kw)
-            continue
-        if one_pass:
-            d3, e3 = core.steric_local_decomp(Tc, Sc, T0, S0, rho0m, surface, pc, neg_inv, **kw)
-            chunk_fields = {v: (d3[i] if want_delta_rho else None, e3[i])
-                            for i, v in enumerate(rows)}
-        for v in variants:
-            Tv, Sv = _variant_operands(v, Tc, Sc, T0, S0)
-            if annual:  # K2 on the chunk, then the fused annual-mean epilogue on the device
-                d, e = (chunk_fields[v] if one_pass else
-                        core.steric_local(Tv, Sv, rho0m, surface, pc, neg_inv, **kw))
-                e = core.group_weighted_mean(e, w_dev[t0:t1], 12,
-                                             out=None if out_host else eta[v][o0:o1])
-                if want_delta_rho:
-                    d = core.group_weighted_mean(d, w_dev[t0:t1], 12,
-                                                 out=None if out_host else drho[v][o0:o1])
-                if not out_host:
-                    continue
-            if out_host:
-                if not annual:
+    import contextlib
+
+    # host results leave on a stream and a worker thread of their own (hostio.Downloader)
+    with (hostio.Downloader(dev) if out_host else contextlib.nullcontext()) as results:
+        for t0, t1, Tc, Sc in chunks:
+            o0, o1 = (t0 // 12, t1 // 12) if annual else (t0, t1)
+            pc = pressure_chunk(pres, t0, t1, dev)
+            if direct:
+                core.steric_local_decomp(
+                    Tc, Sc, T0, S0, rho0m, surface, pc, neg_inv,
+                    delta_rho_out=drho_all[:, t0:t1] if want_delta_rho else None,
+                    eta_out=eta_all[:, t0:t1], **kw)
+                continue
+            if one_pass:
+                d3, e3 = core.steric_local_decomp(Tc, Sc, T0, S0, rho0m, surface, pc, neg_inv, **kw)
+                chunk_fields = {v: (d3[i] if want_delta_rho else None, e3[i])
+                                for i, v in enumerate(rows)}
+            going_out = []
+            for v in variants:
+                Tv, Sv = _variant_operands(v, Tc, Sc, T0, S0)
+                if annual:  # K2 on the chunk, then the fused annual-mean epilogue on the device
                     d, e = (chunk_fields[v] if one_pass else
                             core.steric_local(Tv, Sv, rho0m, surface, pc, neg_inv, **kw))
-                d2h.wait_stream(main)
-                hostio.download_into(eta[v][o0:o1], e, d2h)
-                if want_delta_rho:
-                    hostio.download_into(drho[v][o0:o1], d, d2h)
-            else:
-                core.steric_local(Tv, Sv, rho0m, surface, pc, neg_inv,
-                                  delta_rho_out=drho[v][t0:t1] if want_delta_rho else None,
-                                  eta_out=eta[v][t0:t1], **kw)
-    if d2h is not None:
-        d2h.synchronize()
+                    e = core.group_weighted_mean(e, w_dev[t0:t1], 12,
+                                                 out=None if out_host else eta[v][o0:o1])
+                    if want_delta_rho:
+                        d = core.group_weighted_mean(d, w_dev[t0:t1], 12,
+                                                     out=None if out_host else drho[v][o0:o1])
+                    if not out_host:
+                        continue
+                if out_host:
+                    if not annual:
+                        d, e = (chunk_fields[v] if one_pass else
+                                core.steric_local(Tv, Sv, rho0m, surface, pc, neg_inv, **kw))
+                    going_out.append((eta[v][o0:o1], e))
+                    if want_delta_rho:
+                        going_out.append((drho[v][o0:o1], d))
+                else:
+                    core.steric_local(Tv, Sv, rho0m, surface, pc, neg_inv,
+                                      delta_rho_out=drho[v][t0:t1] if want_delta_rho else None,
+                                      eta_out=eta[v][t0:t1], **kw)
+            if going_out:
+                results.submit(going_out)
     return {v: (drho[v], eta[v]) for v in variants}

@@ -11,10 +11,13 @@ section 7).  So this module never shows the GPU a byte of foreign memory:
 * uploads go through a small ring of page-locked staging buffers (torch's pinned allocator:
   hipHostMalloc'ed once, reused for the life of the process): the host copies piece k+1 into one
   buffer with all its cores while the DMA engine drains piece k from another;
-* downloads come back through the same ring into ordinary numpy arrays (8 memcpy threads; 47 GB/s
-  end to end, first touch of the fresh pages included) or, opt-in, land in page-locked arrays of our
-  own handed to the caller as numpy arrays (one DMA at 57 GB/s -- after ~1 s per 16 GB to allocate
-  them: profiles/r04_d2h_probe.log).
+* downloads come back through such a ring into ordinary numpy arrays -- the bulk results of the
+  local variants on a worker thread of their own (Downloader: one pipeline of pieces across arrays
+  and time chunks, 52 GB/s of the link's 57 on the reference's recorded call) -- or, opt-in, land in
+  page-locked arrays of our own handed to the caller as numpy arrays (one DMA at 57 GB/s -- after
+  ~1 s per 16 GB to allocate them: profiles/r04_d2h_probe.log);
+* the host side of every piece is ONE call into our library (mlx_host_copy: a team of native
+  threads, streaming stores, the GIL released throughout).
 
 Nothing here computes: allocation, copies, stream ordering (torch as the device-array container).
 """
@@ -61,14 +64,15 @@ class _Ring:
     """RING_DEPTH page-locked buffers of PIECE_BYTES (+ slack) and the event that marks each
     buffer's last transfer as finished."""
 
-    def __init__(self):
-        self.bufs = [None] * RING_DEPTH
-        self.events = [None] * RING_DEPTH
+    def __init__(self, depth=RING_DEPTH):
+        self.depth = depth
+        self.bufs = [None] * depth
+        self.events = [None] * depth
         self.next = 0
 
     def acquire(self):
         i = self.next
-        self.next = (i + 1) % RING_DEPTH
+        self.next = (i + 1) % self.depth
         if self.events[i] is not None:
             self.events[i].synchronize()  # the DMA that last used this buffer is done
             self.events[i] = None
@@ -123,37 +127,37 @@ def _count_host_threads():
             n = min(n, max(1, int(quota) // int(period)))
     except (OSError, ValueError):
         pass
-    return max(1, min(n, 8))  # 8 threads fill a staging buffer at ~100 GB/s (profiles/r03_host_copy_probe.log)
+    # 8 threads copy a staging piece at 75-120 GB/s, twice the link's rate; 12 and 16 measured no
+    # faster end to end (profiles/r04_hostio_breakdown.log)
+    return max(1, min(n, 8))
 
 
-_pool = None
+_copy_fn = None
 
 
-def _copy_pool():
-    global _pool
-    if _pool is None:
-        from concurrent.futures import ThreadPoolExecutor
+def _native_copy():
+    """mlx_host_copy of our own library: ONE foreign call per staging piece -- the GIL is released
+    for its whole duration -- split over host_threads() native threads inside the library.  (The
+    split used to be a Python thread pool calling libc's memcpy: 8-16 futures per piece, each
+    completion taking the GIL the upload thread, the download thread and the caller contend for;
+    np.copyto and torch's sliced copy_ serialise on it outright, 11 and 6 GB/s from eight threads.)
+    It writes the destination with streaming stores; MOMLEVEL_AMD_HOST_COPY=libc keeps memcpy's
+    cached stores (for A/B measurements)."""
+    global _copy_fn
+    if _copy_fn is None:
+        from . import _lib
 
-        _pool = ThreadPoolExecutor(max_workers=host_threads(), thread_name_prefix="mlx-stage")
-    return _pool
+        fn = _lib.load().mlx_host_copy
+        streaming = 0 if os.environ.get("MOMLEVEL_AMD_HOST_COPY", "stream") == "libc" else 1
+        threads = host_threads()
 
+        def copy(d, s, n):
+            rc = fn(d, s, n, threads, streaming)
+            if rc != 0:
+                raise RuntimeError(f"mlx_host_copy failed ({rc}): {_lib.last_error()}")
 
-_memcpy = None
-
-
-def _libc_memcpy():
-    """libc's memcpy through ctypes: a foreign call, so it runs WITHOUT the GIL -- np.copyto and
-    torch's sliced copy_ measured 11 and 6 GB/s from eight Python threads (they serialise), this
-    35 GB/s on the same eight cores."""
-    global _memcpy
-    if _memcpy is None:
-        import ctypes
-
-        fn = ctypes.CDLL(None).memcpy
-        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
-        fn.restype = ctypes.c_void_p
-        _memcpy = fn
-    return _memcpy
+        _copy_fn = copy
+    return _copy_fn
 
 
 def _host_copy(dst, src):
@@ -162,18 +166,7 @@ def _host_copy(dst, src):
     not from the cgroup quota -- 5.7 GB/s end to end on the quota-limited GPU boxes.)"""
     n = dst.numel()
     assert src.numel() == n
-    memcpy = _libc_memcpy()
-    d, s_ = dst.data_ptr(), src.data_ptr()
-    threads = host_threads()
-    if n < (4 << 20) or threads == 1:
-        memcpy(d, s_, n)
-        return
-    step = -(-n // threads)
-    step = -(-step // 4096) * 4096
-    futures = [_copy_pool().submit(memcpy, d + o, s_ + o, min(step, n - o))
-               for o in range(0, n, step)]
-    for f in futures:
-        f.result()
+    _native_copy()(dst.data_ptr(), src.data_ptr(), n)
 
 
 class roctx_range:
@@ -193,10 +186,10 @@ class roctx_range:
         return False
 
 
-def new_ring():
+def new_ring(depth=RING_DEPTH):
     """A private staging ring (engine.TimeChunks stages its uploads from a worker thread and must
     not share buffers with transfers issued by the main thread)."""
-    return _Ring()
+    return _Ring(depth)
 
 
 def upload(host, dev, stream=None, ring=None):
@@ -281,14 +274,24 @@ def pinned_array(shape, dtype=np.float64):
     return np.empty(shape, dtype=dtype)
 
 
-def download_into(out, dev, stream=None):
-    """Copy the device tensor ``dev`` into the numpy array ``out`` (same shape / dtype, contiguous).
-    Page-locked ``out`` (pinned_array): one asynchronous DMA on ``stream`` -- the caller
-    synchronises the stream before reading.  Pageable ``out``: piecewise through the ring,
-    complete on return."""
-    device = dev.device
-    stream = stream if stream is not None else torch.cuda.current_stream(device)
+def _drain_one(ring, pending):
+    """Oldest enqueued piece: wait for its DMA, copy it out of the staging buffer."""
+    dst, n, i = pending.pop(0)
+    ring.events[i].synchronize()
+    ring.events[i] = None
+    _host_copy(dst, ring.bufs[i][:n])
+
+
+def _enqueue_download(out, dev, stream, ring, pending):
+    """Start copying the device tensor ``dev`` into the numpy array ``out`` on ``stream``.  Pageable
+    ``out``: piece by piece through ``ring``; on return every piece's DMA is enqueued and all but
+    the last ring.depth-1 pieces are in ``out`` -- those wait in ``pending`` (a list the caller
+    owns, shared by consecutive calls so that the pipeline does not run dry between arrays).
+    Page-locked or small ``out``: one copy on ``stream``, nothing pending."""
     host = torch.from_numpy(out)
+    if host.dtype != dev.dtype or host.numel() != dev.numel():
+        raise ValueError(f"download of a {dev.dtype} tensor of {dev.numel()} elements into a "
+                         f"{host.dtype} array of {host.numel()}")
     if host.numel() == 0:
         return
     nbytes = host.numel() * host.element_size()
@@ -302,32 +305,110 @@ def download_into(out, dev, stream=None):
     with torch.cuda.stream(stream):
         src = dev.contiguous()
     hb, db = _bytes_view(host), _bytes_view(src)
-    ring = _ring(device)
     _log_range("download destination (pageable: written by host memcpy only)", host.data_ptr(),
                nbytes)
     step = PIECE_BYTES // 8 * 8
-    pending = []  # (offset, n, buffer index): DMA enqueued, host copy-out still to do
-
-    def drain(k):
-        off, n, i = pending.pop(k)
-        ring.events[i].synchronize()
-        ring.events[i] = None
-        _host_copy(hb[off:off + n], ring.bufs[i][:n])
-
     for off in range(0, nbytes, step):
         n = min(step, nbytes - off)
-        if len(pending) == RING_DEPTH - 1:
-            drain(0)
+        if len(pending) == ring.depth - 1:
+            _drain_one(ring, pending)
         i, buf = ring.acquire()
         with torch.cuda.stream(stream):
             buf[:n].copy_(db[off:off + n], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(stream)
         ring.events[i] = ev
-        pending.append((off, n, i))
-    while pending:
-        drain(0)
+        pending.append((hb[off:off + n], n, i))
     src.record_stream(stream)
+
+
+def download_into(out, dev, stream=None):
+    """Copy the device tensor ``dev`` into the numpy array ``out`` (same shape / dtype, contiguous).
+    Page-locked ``out`` (pinned_array): one asynchronous DMA on ``stream`` -- the caller
+    synchronises the stream before reading.  Pageable ``out``: piecewise through the ring,
+    complete on return."""
+    device = dev.device
+    stream = stream if stream is not None else torch.cuda.current_stream(device)
+    ring, pending = _ring(device), []
+    _enqueue_download(out, dev, stream, ring, pending)
+    while pending:
+        _drain_one(ring, pending)
+
+
+class Downloader:
+    """Results -> host arrays on a worker thread with a stream and a staging ring of its own.
+
+    The caller's loop ``submit()``s each time chunk's (host array, device tensor) pairs right
+    after enqueuing the kernels that produce them and goes on to the next chunk; the worker keeps
+    ONE pipeline of staging pieces running across arrays and chunks (DMA of piece k+1 and k+2
+    while piece k is copied out), so the link does not idle between chunks -- draining after
+    every array, as download_into() does, left it idle 15 % of the time on the reference's recorded
+    call (profiles/r04_hostio_breakdown.log).  At most ``depth`` chunks are outstanding: submit()
+    blocks beyond that, which bounds the device memory held by results still on their way out.
+
+        with hostio.Downloader(device) as results:
+            for chunk: ...; results.submit([(eta[t0:t1], e), (drho[t0:t1], d)])
+        # here every array is complete
+    """
+
+    def __init__(self, device, depth=2):
+        import collections
+        from concurrent.futures import ThreadPoolExecutor
+
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.depth = int(depth)
+        # one buffer more than the shared rings: two DMAs stay queued while a piece is copied out,
+        # so a slow copy-out of one piece does not idle the link
+        self._ring = new_ring(int(os.environ.get("MOMLEVEL_AMD_DOWNLOAD_RING", "4")))
+        self._pending = []  # touched by the worker thread only
+        self._jobs = collections.deque()
+        self._pool = ThreadPoolExecutor(1, thread_name_prefix="mlx-download")
+
+    def submit(self, pairs):
+        """``pairs``: [(numpy array, device tensor)]; the tensors are results of work enqueued on
+        the device's CURRENT stream (of the calling thread)."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        while len(self._jobs) >= self.depth:
+            self._jobs.popleft().result()  # (re-raises what the worker raised)
+        self._jobs.append(self._pool.submit(self._run, list(pairs), ev))
+
+    def _run(self, pairs, ev):
+        with torch.cuda.device(self.device):
+            self.stream.wait_event(ev)
+            for out, dev in pairs:
+                _enqueue_download(out, dev, self.stream, self._ring, self._pending)
+
+    def _flush(self):
+        while self._pending:
+            _drain_one(self._ring, self._pending)
+
+    def finish(self):
+        """Block until every submitted array is complete."""
+        while self._jobs:
+            self._jobs.popleft().result()
+        self._pool.submit(self._flush).result()
+        self.stream.synchronize()  # (page-locked / small arrays: plain asynchronous copies)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        try:
+            if exc_type is None:
+                self.finish()
+            else:  # the caller failed: let what is in flight land, report the caller's error
+                for j in self._jobs:
+                    j.cancel()
+                try:
+                    self._pool.submit(self._flush).result()
+                    self.stream.synchronize()
+                except Exception:
+                    pass
+        finally:
+            self._pool.shutdown(wait=True)
+        return False
 
 
 def to_host(t):

@@ -562,6 +562,18 @@ int mlx_valu_probe(int64_t iters, double *out, int64_t *lane_instructions, void 
   return 0;
 }
 
+int mlx_host_copy(void *dst, const void *src, size_t nbytes, int threads, int streaming) {
+  (void)streaming; /* the checker's build has no tuned copy: one plain memcpy, same contract */
+  if (nbytes == 0) return 0;
+  if (!dst || !src) return fail(MLX_E_NULL, "dst and src must not be NULL");
+  if (threads < 1 || threads > 64) return fail(MLX_E_SHAPE, "threads must be in 1..64");
+  const unsigned char *s = (const unsigned char *)src;
+  unsigned char *d = (unsigned char *)dst;
+  if (d < s + nbytes && s < d + nbytes) return fail(MLX_E_SHAPE, "dst and src overlap");
+  memcpy(d, s, nbytes);
+  return 0;
+}
+
 static inline uint64_t splitmix64(uint64_t x) {
   uint64_t z = x + 0x9E3779B97F4A7C15ULL;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;

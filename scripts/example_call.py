@@ -23,7 +23,7 @@ from momlevel_amd import core, hostio, synthetic  # noqa: E402
 from momlevel_amd.labeled import DataArray, Dataset  # noqa: E402
 
 
-def run(nt=60, nz=35, reps=2, ny=1080, nx=1440, checker=None):
+def run(nt=60, nz=35, reps=2, ny=1080, nx=1440, checker=None, before_call=None):
     g = synthetic.make_grid(ny, nx, nz)
     vol0 = hostio.to_device(g["volcello"], "cuda")
     kw = dict(seed=synthetic.SEED, mask3d=vol0)
@@ -58,6 +58,8 @@ def run(nt=60, nz=35, reps=2, ny=1080, nx=1440, checker=None):
         import gc
 
         gc.collect()
+        if before_call is not None:
+            before_call()
         t0 = time.perf_counter()
         res, ref = m.thermosteric(d)
         drho = res["delta_rho"].values  # host arrays: the call has synchronised

@@ -3,7 +3,7 @@
 
     python scripts/sanitize_host.py [--iters N] [--keep]
 
-1. compiles momlevel_amd/csrc/momlevel_hip.hip and momlevel_promote.hip with the HOST pass instrumented by
+1. compiles momlevel_amd/csrc/momlevel_hip.hip, momlevel_promote.hip and host_copy.cpp with the HOST pass instrumented by
    AddressSanitizer + UndefinedBehaviorSanitizer (``-fsanitize=address,undefined
    -fno-gpu-sanitize``: the gfx950 device code is built as always and never instrumented -- GPU
    ASan is not available on this pool and is not used) into build/sanitize/libmomlevel_hip.so;
@@ -42,7 +42,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     lib = os.path.join(OUT, "libmomlevel_hip.so")
     csrc = os.path.join(ROOT, "momlevel_amd", "csrc")
-    srcs = [os.path.join(csrc, "momlevel_hip.hip"), os.path.join(csrc, "momlevel_promote.hip")]
+    srcs = [os.path.join(csrc, "momlevel_hip.hip"), os.path.join(csrc, "momlevel_promote.hip"),
+            os.path.join(csrc, "host_copy.cpp")]
     deps = srcs + [os.path.join(csrc, "eos_device.hpp"), os.path.join(csrc, "eos_promote.hpp"),
                    os.path.join(csrc, "mlx_internal.hpp"),
                    os.path.join(ROOT, "include", "momlevel_hip.h"), os.path.abspath(__file__)]

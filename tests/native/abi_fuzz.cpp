@@ -123,6 +123,48 @@ int main(int argc, char** argv) {
       }
     }
   }
+  {  // mlx_host_copy works on REAL host memory: heap buffers with ASan's red zones either side,
+     // alignments of source and destination, lengths around the 128-byte inner block, and sizes
+     // that are split over the thread team (slices of >= 1 MiB)
+    const size_t cap = (size_t)9 << 20;
+    unsigned char* src = (unsigned char*)malloc(cap + 64);
+    unsigned char* dst = (unsigned char*)malloc(cap + 64);
+    for (size_t i = 0; i < cap + 64; ++i) src[i] = (unsigned char)(i * 131 + (i >> 12) + 7);
+    static const size_t lens[] = {0, 1, 31, 32, 33, 127, 128, 129, 4095, 4096, 4097, 4223, 8192,
+                                  65535, 69999, ((size_t)1 << 20) + 1, ((size_t)3 << 20) - 5,
+                                  (size_t)9 << 20};
+    static const int teams[] = {1, 2, 3, 8, 64};
+    for (int streaming = 0; streaming < 2; ++streaming)
+      for (int threads : teams)
+        for (size_t so = 0; so < 40; so += 13)
+          for (size_t dof = 0; dof < 40; dof += 11)
+            for (size_t n : lens) {
+              if (n < 4096 && threads > 2) continue;  // (one slice anyway)
+              dst[dof + n] = 0xEE;
+              if (dof) dst[dof - 1] = 0xEE;
+              if (n) memset(dst + dof, 0, n < 4096 ? n : 4096);
+              if (mlx_host_copy(dst + dof, src + so, n, threads, streaming) != 0 ||
+                  memcmp(dst + dof, src + so, n) != 0 || dst[dof + n] != 0xEE ||
+                  (dof && dst[dof - 1] != 0xEE)) {
+                fprintf(stderr, "FAIL: mlx_host_copy(streaming=%d, threads=%d, src+%zu, dst+%zu, %zu)\n",
+                        streaming, threads, so, dof, n);
+                return 1;
+              }
+            }
+    if (mlx_host_copy(nullptr, src, 8, 1, 1) != MLX_E_NULL ||
+        mlx_host_copy(dst, nullptr, 8, 1, 1) != MLX_E_NULL ||
+        mlx_host_copy(src + 8, src, 64, 1, 1) != MLX_E_SHAPE ||
+        mlx_host_copy(src, src + 8, 64, 2, 0) != MLX_E_SHAPE ||
+        mlx_host_copy(dst, src, 64, 0, 0) != MLX_E_SHAPE ||
+        mlx_host_copy(dst, src, 64, 65, 0) != MLX_E_SHAPE ||
+        mlx_host_copy(dst, (void*)(~(uintptr_t)0 - 15), 64, 1, 0) != MLX_E_SHAPE ||
+        mlx_host_copy(nullptr, nullptr, 0, 1, 1) != 0) {
+      fprintf(stderr, "FAIL: mlx_host_copy argument checks\n");
+      return 1;
+    }
+    free(src);
+    free(dst);
+  }
   char tiny[4];
   mlx_last_error(tiny, sizeof tiny);  // truncation path
   mlx_last_error(nullptr, 0);

@@ -6,6 +6,8 @@ import ctypes
 import os
 import re
 
+import numpy as np
+
 from momlevel_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -82,3 +84,35 @@ def test_null_pressure_requires_scalar_mode():
 
 def test_build_kind():
     assert _lib.load().mlx_build_kind() == _lib.BUILD_HIP
+
+
+def test_host_copy_needs_no_gpu():
+    """mlx_host_copy (v6): host memory only -- every byte, any alignment, one thread or a team,
+    concurrent callers on disjoint ranges; overlapping ranges and bad team sizes are refused"""
+    import threading
+
+    lib = _lib.load()
+    r = np.random.default_rng(3)
+    n = (5 << 20) + 77
+    src = r.integers(0, 255, n, dtype=np.uint8)
+    for streaming in (0, 1):
+        for threads in (1, 3, 8):
+            for off_s, off_d, m in ((0, 0, n), (1, 5, n - 9), (3, 0, 4097), (0, 7, 0), (64, 64, 100)):
+                dst = np.full(n, 0xEE, dtype=np.uint8)
+                rc = lib.mlx_host_copy(dst.ctypes.data + off_d, src.ctypes.data + off_s, m, threads,
+                                       streaming)
+                assert rc == 0
+                assert np.array_equal(dst[off_d:off_d + m], src[off_s:off_s + m])
+                assert (dst[:off_d] == 0xEE).all() and (dst[off_d + m:] == 0xEE).all()
+    outs = [np.zeros(n, dtype=np.uint8) for _ in range(3)]
+    jobs = [threading.Thread(target=lambda o=o: [lib.mlx_host_copy(o.ctypes.data, src.ctypes.data,
+                                                                   n, 4, 1) for _ in range(4)])
+            for o in outs]
+    [j.start() for j in jobs]
+    [j.join() for j in jobs]
+    assert all(np.array_equal(o, src) for o in outs)
+    a = src.ctypes.data
+    assert lib.mlx_host_copy(a + 8, a, 64, 1, 1) == -2 and "overlap" in _lib.last_error()
+    assert lib.mlx_host_copy(outs[0].ctypes.data, a, 64, 0, 1) == -2
+    assert lib.mlx_host_copy(outs[0].ctypes.data, a, 64, 65, 1) == -2
+    assert lib.mlx_host_copy(None, a, 64, 1, 1) == -1
