@@ -67,29 +67,55 @@ def _tuned_kernel_covers(kT, kS, kp, eos):
     return eos != "linear" and kT == "f32" and kS == "f32" and kp == "f64"
 
 
-_HOST_CHUNK_ELEMS = 1 << 28  # 2 GiB of float64 per operand and chunk
+# host arrays above this size are evaluated in pieces along their leading axis, the pieces'
+# uploads, kernels and result downloads overlapping (the link is full duplex)
+_HOST_PIPELINE_ELEMS = 1 << 26
+_HOST_CHUNK_ELEMS = 1 << 25  # 256 MiB of float64 per operand and piece
 
 
 def _evaluate_host_chunked(eos, func, T, S, p, gravity):
-    """Large host arrays: walk the leading axis of the broadcast shape in chunks so that the
-    device never holds more than a few GiB (the result is a host array anyway)."""
+    """Large host arrays: walk the leading axis of the broadcast shape in pieces.  Piece k+1 is
+    staged and uploaded by a worker thread (hostio.Uploader) while piece k's kernel runs and piece
+    k-1's result leaves on another (hostio.Downloader): both directions of the host link are busy
+    at once, and the device never holds more than a few pieces (the result is a host array
+    anyway)."""
     arrs = [x if _is_weak(x) else np.asarray(x) for x in (T, S, p if p is not None else 0.0)]
     shape = np.broadcast_shapes(*(np.shape(a) for a in arrs))
     rows = max(1, _HOST_CHUNK_ELEMS // max(1, int(np.prod(shape[1:]))))
-    out = None
+    bounds = [(i0, min(i0 + rows, shape[0])) for i0 in range(0, shape[0], rows)]
+    device = torch.device("cuda", torch.cuda.current_device())
+    main = torch.cuda.current_stream(device)
 
     def part(a, i0, i1):  # slice the leading axis unless the operand broadcasts along it
         if np.ndim(a) == len(shape) and a.shape[0] == shape[0] and shape[0] > 1:
             return a[i0:i1]
         return a
 
-    for i0 in range(0, shape[0], rows):
-        i1 = min(i0 + rows, shape[0])
-        res = evaluate(eos, func, part(arrs[0], i0, i1), part(arrs[1], i0, i1),
-                       None if p is None else part(arrs[2], i0, i1), gravity=gravity)
-        if out is None:
-            out = np.empty(shape, dtype=res.dtype)
-        out[i0:i1] = res
+    def pieces(i0, i1):  # (operands of the piece, which of them travel)
+        ops = [part(arrs[0], i0, i1), part(arrs[1], i0, i1), None if p is None else part(arrs[2], i0, i1)]
+        return ops, [k for k, x in enumerate(ops) if x is not None and not _is_weak(x)]
+
+    out = None
+    up = hostio.Uploader(device)
+    try:
+        with hostio.Downloader(device) as results:
+            ops, travel = pieces(*bounds[0])
+            nxt = up.submit([ops[k] for k in travel])
+            for n, (i0, i1) in enumerate(bounds):
+                tensors, ready = nxt.result()  # (re-raises what the worker raised)
+                cur, cur_travel = ops, travel
+                if n + 1 < len(bounds):
+                    ops, travel = pieces(*bounds[n + 1])
+                    nxt = up.submit([ops[k] for k in travel])
+                main.wait_event(ready)
+                for k, t in zip(cur_travel, tensors):
+                    cur[k] = t
+                res = evaluate(eos, func, cur[0], cur[1], cur[2], gravity=gravity)  # device tensor
+                if out is None:
+                    out = np.empty(shape, dtype=np.float32 if res.dtype == torch.float32 else np.float64)
+                results.submit([(out[i0:i1], res.reshape(out[i0:i1].shape))])
+    finally:
+        up.close()
     return out
 
 
@@ -126,7 +152,7 @@ def evaluate(eos, func, T, S, p, gravity=None):
     core.require_device()
     if not any(isinstance(x, torch.Tensor) for x in (T, S, p)):
         shape = np.broadcast_shapes(*(np.shape(x) for x in (T, S, p) if x is not None))
-        if len(shape) >= 1 and int(np.prod(shape)) > _HOST_CHUNK_ELEMS and shape[0] > 1:
+        if len(shape) >= 1 and int(np.prod(shape)) > _HOST_PIPELINE_ELEMS and shape[0] > 1:
             return _evaluate_host_chunked(eos, func, T, S, p, gravity)
     on_device = any(isinstance(x, torch.Tensor) and x.is_cuda for x in (T, S, p))
     scalar_in = all(np.ndim(x) == 0 and not isinstance(x, torch.Tensor) for x in (T, S, p))

@@ -411,6 +411,61 @@ class Downloader:
         return False
 
 
+class Uploader:
+    """Host arrays -> fresh device tensors on a worker thread with a stream and a staging ring of
+    its own (what engine.TimeChunks does for theta/S, for callers that chunk something else):
+
+        up = hostio.Uploader(device)
+        nxt = up.submit([a0, b0])
+        for k ...:
+            tensors, ready = nxt.result(); nxt = up.submit([a_k+1, b_k+1])
+            torch.cuda.current_stream().wait_event(ready); ...kernels on tensors...
+        up.close()
+
+    The tensors belong to the stream that was current when the Uploader was made (the caching
+    allocator ties a block to a stream), the copies run on the Uploader's own."""
+
+    def __init__(self, device):
+        from concurrent.futures import ThreadPoolExecutor
+
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._main = torch.cuda.current_stream(self.device)
+        self._ring = new_ring()
+        self._pool = ThreadPoolExecutor(1, thread_name_prefix="mlx-upload")
+
+    def submit(self, arrays):
+        """Future of ([device tensor per array], event that completes the copies)."""
+        return self._pool.submit(self._run, list(arrays))
+
+    def _run(self, arrays):
+        import warnings
+
+        out = []
+        with torch.cuda.device(self.device):
+            for a in arrays:
+                a = np.ascontiguousarray(a)
+                if a.dtype not in (np.float32, np.float64):
+                    a = a.astype(np.float64)
+                with warnings.catch_warnings():  # read-only views are only read
+                    warnings.simplefilter("ignore", UserWarning)
+                    host = torch.from_numpy(a)
+                with torch.cuda.stream(self._main):
+                    dev = torch.empty(host.shape, dtype=host.dtype, device=self.device)
+                # `dev` may reuse memory the consumer's stream is done with: what is enqueued
+                # there so far goes first
+                self.stream.wait_stream(self._main)
+                upload(host, dev, stream=self.stream, ring=self._ring)
+                dev.record_stream(self.stream)
+                out.append(dev)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return out, ev
+
+    def close(self):
+        self._pool.shutdown(wait=True)
+
+
 def to_host(t):
     """Device tensor -> numpy array (through the staging ring when not small; synchronises)."""
     if not (isinstance(t, torch.Tensor) and t.is_cuda):

@@ -113,9 +113,15 @@ def test_linear_eos():
 
 
 def test_large_host_arrays_are_chunked(monkeypatch):
-    """calc_rho-style calls on host arrays larger than the chunk limit walk the leading axis."""
+    """calc_rho-style calls on host arrays above the pipeline limit walk the leading axis in
+    pieces: upload of piece k+1, kernel of piece k and result download of piece k-1 overlap
+    (hostio.Uploader / Downloader).  Same bits as numpy whatever the piece size; operands that
+    broadcast along the leading axis, python-float pressures and float32-throughout results
+    (numpy's promotion) included."""
+    from momlevel_amd import hostio
     from momlevel_amd.eos import _dispatch
 
+    monkeypatch.setattr(_dispatch, "_HOST_PIPELINE_ELEMS", 1000)
     monkeypatch.setattr(_dispatch, "_HOST_CHUNK_ELEMS", 1000)
     r = np.random.default_rng(5)
     T = r.uniform(-2, 32, (7, 5, 6, 10))
@@ -125,6 +131,24 @@ def test_large_host_arrays_are_chunked(monkeypatch):
     p4 = r.uniform(1e5, 5e7, (7, 5, 6, 10))
     assert_bit_equal(alpha(T, S, p4), o.wright_alpha(T, S, p4))
     assert_bit_equal(density(T, S[0], 2.0e5), o.wright_density(T, S[0], 2.0e5))
+    # pieces large enough for the staging ring (0.96 MB each), float64 and float32 fields
+    used = []
+    real = hostio._enqueue_download
+    monkeypatch.setattr(hostio, "_enqueue_download",
+                        lambda out, dev, *a: used.append(out.nbytes) or real(out, dev, *a))
+    monkeypatch.setattr(_dispatch, "_HOST_CHUNK_ELEMS", 200_000)
+    T = r.uniform(-2, 32, (6, 40, 50, 60))
+    S = r.uniform(30, 40, (6, 40, 50, 60))
+    pz = np.linspace(1e5, 5e7, 40)[:, None, None]
+    assert_bit_equal(density(T, S, pz), o.wright_density(T, S, pz))
+    assert len(used) == 6 and all(n == 40 * 50 * 60 * 8 for n in used)
+    T32, S32 = T.astype(np.float32), S.astype(np.float32)
+    got = density(T32, S32, pz)  # float32 fields, float64 pressure: float64 out
+    assert got.dtype == np.float64
+    assert_bit_equal(got, o.wright_density(T32, S32, pz))
+    got = density(T32, S32, 2.0e5)  # python-float pressure: float32 throughout, as numpy
+    assert got.dtype == np.float32
+    assert_bit_equal(got, o.wright_density(T32, S32, 2.0e5))
 
 
 # ---- held-field (thermosteric / halosteric) kernels vs the reference module's vectors ---------
