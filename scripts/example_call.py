@@ -61,9 +61,10 @@ def run(nt=60, nz=35, reps=2, ny=1080, nx=1440, checker=None, before_call=None):
         if before_call is not None:
             before_call()
         t0 = time.perf_counter()
-        res, ref = m.thermosteric(d)
-        drho = res["delta_rho"].values  # host arrays: the call has synchronised
-        eta = res["thermosteric"].values
+        with hostio.roctx_range("thermosteric(ds) on host float32 inputs"):  # (MOMLEVEL_AMD_ROCTX=1)
+            res, ref = m.thermosteric(d)
+            drho = res["delta_rho"].values  # host arrays: the call has synchronised
+            eta = res["thermosteric"].values
         walls.append(time.perf_counter() - t0)
         assert drho.shape == shape and eta.shape == (nt, ny, nx) and drho.dtype == np.float64
     out["wall_s"] = [round(w, 3) for w in walls]

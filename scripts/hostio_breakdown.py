@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--nt", type=int, default=60)
     ap.add_argument("--nz", type=int, default=35)
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--case", default="example", choices=["example", "ingest32", "ingest64"],
+                    help="example: the recorded thermosteric(ds) call; ingest*: scripts/ingest_check.py's "
+                         "steric(d, domain='local') on 48 x 75 x 576 x 360 host fields")
     a = ap.parse_args()
     hostio._host_copy = timed("memcpy", hostio._host_copy, lambda d, s: d.numel())
     hostio.upload = timed("upload", hostio.upload,
@@ -61,10 +64,28 @@ def main():
         with lock:
             acc.clear()
 
-    out2 = example_call.run(a.nt, a.nz, reps=a.reps, before_call=reset)  # counters: the last call only
+    if a.case == "example":
+        out2 = example_call.run(a.nt, a.nz, reps=a.reps, before_call=reset)  # counters: the last call only
+    else:
+        import numpy as np
+        import torch
+
+        import momlevel_amd as m
+        from ingest_check import dataset
+
+        d = dataset(48, 75, 576, 360, np.float32 if a.case == "ingest32" else np.float64)
+        walls = []
+        for _ in range(a.reps):
+            reset()
+            t0 = time.perf_counter()
+            res, ref = m.steric(d, domain="local")
+            torch.cuda.synchronize()
+            walls.append(round(time.perf_counter() - t0, 3))
+            del res, ref
+        out2 = {"wall_s": walls}
     with lock:
         second = {k: list(v) for k, v in acc.items()}
-    rep = {"threads": hostio.host_threads(), "piece_MiB": hostio.PIECE_BYTES >> 20,
+    rep = {"case": a.case, "threads": hostio.host_threads(), "piece_MiB": hostio.PIECE_BYTES >> 20,
            "download_ring": os.environ.get("MOMLEVEL_AMD_DOWNLOAD_RING", "default"),
            "wall_s": out2["wall_s"]}
     for k, (s, b, c) in sorted(second.items()):

@@ -60,7 +60,7 @@ def main(src, out_path):
     out = {"source": src, "ranges": []}
     for r in markers:
         name = r.get("Function", "") or r.get("Name", "")
-        if not name.startswith("steric(domain="):
+        if not name.startswith(("steric(domain=", "thermosteric(ds)")):
             continue
         lo, hi = ts(r)
         uh, th = union(clip(h2d, lo, hi))
