@@ -44,7 +44,8 @@ extern "C" {
                              3: mlx_build_kind; a NULL p (linear EOS) requires p_mode MLX_P_SCALAR
                              4: mlx_eos_map_promote (MLX_KIND_*); MLX_DTYPE_T32_S64 / _T64_S32 in K1/K2
                              5: mlx_stream_probe_mix, mlx_valu_probe, mlx_last_kernel
-                             6: mlx_host_copy */
+                             6: mlx_host_copy; mlx_stratification, mlx_adjust_negative_n2,
+                                mlx_wave_speed_where_time0 */
 
 /* argument-error codes (negative) */
 #define MLX_E_NULL     (-1) /* a required pointer is NULL                      */
@@ -353,6 +354,50 @@ int mlx_synth_field(void *out, int dtype, int64_t nt, int64_t nz, int64_t ny, in
                     int64_t t0, int64_t NY, int64_t NX, int64_t y0, int64_t x0,
                     uint64_t seed, int field_id, double lo, double scale,
                     const double *mask3d, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * Stratification diagnostics: the consumers of alpha / beta.
+ *
+ * mlx_stratification -- derived.calc_n2 (derived.py:328-411, interfaces=None) and
+ * derived.calc_stability_angle (derived.py:714-766) in one pass over theta / S:
+ *   MLX_STRAT_N2      gravity * ((alpha * dT/dz) - (beta * dS/dz))
+ *   MLX_STRAT_TURNER  degrees(arctan((1 + R) / (1 - R))),  R = (beta * dS/dz) / (alpha * dT/dz)
+ * with alpha, beta of the chosen EOS at (T, S, p) and d/dz = numpy.gradient(f, z, edge_order=2)
+ * along z (xarray's differentiate).  T, S, out: (nt, nz, plane); dtype MLX_DTYPE_F64, _F32
+ * (numpy's mixed precision: the derivative of a float32 field is float32, alpha / beta float64;
+ * Wright only) or _F32_UPCAST.  p[t*p_stride_t + z*p_stride_z + cell*p_stride_cell] in elements
+ * (a z profile: 0, 1, 0; a scalar: 0, 0, 0; a full field: nz*plane, plane, 1); NULL for the linear
+ * EOS.  coef: (nz, 3) device doubles, numpy.gradient's a, b, c of every level computed by the
+ * caller from the coordinate exactly as numpy does (rows 0 and nz-1: the one-sided formulas on
+ * levels (0,1,2) / (nz-3,nz-2,nz-1)); uniform != 0 (numpy: all spacings equal): interior levels are
+ * (f[k+1] - f[k-1]) / two_dx instead.  nz >= 3.  Values identical to numpy's except the arctan.
+ *
+ * mlx_adjust_negative_n2 -- derived.adjust_negative_n2 (derived.py:30-71) and the column sum of
+ * derived.calc_wave_speed (derived.py:798-831) in one walk down each column.  n2, adjusted:
+ * (nt, nz, plane), nt = the product of the dimensions before z.  The reference's
+ * `adjusted[0].fillna(1e-8)` indexes the array's LEADING dimension: lead0_rows > 0 = that is not z,
+ * and the first lead0_rows of the nt rows (index 0 of the leading dimension: 1 for a
+ * (time, z, y, x) field) are filled at every level; lead0_rows == 0 (nt == 1) = z leads and the
+ * surface level is filled.  speed (nt, plane) = sum_z sqrt(adjusted) * dz / pi (skipna), dz
+ * (nz, plane); with lead0_rows == 0 also NaN where the surface n2 is NaN.  adjusted or speed may
+ * be NULL.
+ *
+ * mlx_wave_speed_where_time0 -- what derived.py:823 returns for a (time, z, y, x) n2: xarray
+ * broadcasts the condition n2[time=0] (z, y, x) against the speeds (time, y, x) into
+ * out (nz, plane, nt).
+ * ------------------------------------------------------------------------------- */
+#define MLX_STRAT_N2     0
+#define MLX_STRAT_TURNER 1
+int mlx_stratification(const void *T, const void *S, int dtype, const double *p,
+                       int64_t p_stride_t, int64_t p_stride_z, int64_t p_stride_cell,
+                       int eos, int func, const double *coef, int uniform, double two_dx,
+                       double gravity, int64_t nt, int64_t nz, int64_t plane, double *out,
+                       void *stream);
+int mlx_adjust_negative_n2(const double *n2, int64_t nt, int64_t nz, int64_t plane,
+                           int64_t lead0_rows, const double *dz, double *adjusted, double *speed,
+                           void *stream);
+int mlx_wave_speed_where_time0(const double *n2_t0, const double *speed, int64_t nt, int64_t nz,
+                               int64_t plane, double *out, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * Host side of the staged transfers (momlevel_amd/hostio.py; no reference counterpart: the

@@ -28,6 +28,7 @@ FLAG_SKIP_DRY = 1
 FLAG_FMA = 2
 BUILD_HIP, BUILD_HOST = 1, 2
 KIND_F64, KIND_F32, KIND_WEAK = 0, 1, 2  # operand kinds of mlx_eos_map_promote
+STRAT_N2, STRAT_TURNER = 0, 1  # mlx_stratification's func
 
 
 def flag_tchunk(steps):
@@ -102,6 +103,10 @@ SIGNATURES = {
     "mlx_valu_probe": (_int, [_i64, _vp, ctypes.POINTER(ctypes.c_int64), _vp]),
     "mlx_calc_dz": (_int, [_vp, _vp, _i64, _i64, _dbl, _dbl, _int, _int, _vp, _vp]),
     "mlx_host_copy": (_int, [_vp, _vp, _sz, _int, _int]),
+    "mlx_stratification": (_int, [_vp, _vp, _int, _vp, _i64, _i64, _i64, _int, _int, _vp, _int,
+                                  _dbl, _dbl, _i64, _i64, _i64, _vp, _vp]),
+    "mlx_adjust_negative_n2": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "mlx_wave_speed_where_time0": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "mlx_synth_field": (
         _int,
         [_vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _u64, _int,

@@ -297,6 +297,133 @@ def eos_map_promote(T, S, p, eos="wright", func="density", gravity=9.8):
     return out
 
 
+def gradient_coefficients(z):
+    """numpy.gradient's per-level coefficients for ``edge_order=2`` along a coordinate ``z`` (what
+    xarray's ``differentiate(zcoord, edge_order=2)`` evaluates; derived.py:399-400, :752-753),
+    computed on the host from the coordinate with numpy's own expressions, operator for operator.
+    Returns (coef (nz,3) float64, uniform, two_dx): level k's derivative is
+    ``a*f[k-1] + b*f[k] + c*f[k+1]`` (level 0: on levels 0,1,2; level nz-1: on the last three);
+    for evenly spaced levels -- numpy's test: every np.diff equals the first -- the interior is
+    ``(f[k+1] - f[k-1]) / two_dx`` instead and only the edge rows of ``coef`` are used."""
+    z = np.asarray(z)
+    if z.ndim != 1:
+        raise ValueError("distances must be either scalars or 1d")
+    n = z.shape[0]
+    if n < 3:
+        raise ValueError("Shape of array too small to calculate a numerical gradient, "
+                         "at least (edge_order + 1) elements are required.")
+    if np.issubdtype(z.dtype, np.integer):
+        z = z.astype(np.float64)
+    diffx = np.diff(z)
+    coef = np.zeros((n, 3), dtype=np.float64)
+    if (diffx == diffx[0]).all():
+        dx = diffx[0]
+        coef[0] = (-1.5 / dx, 2.0 / dx, -0.5 / dx)
+        coef[-1] = (0.5 / dx, -2.0 / dx, 1.5 / dx)
+        return coef, True, float(2.0 * dx)
+    dx1, dx2 = diffx[0:-1], diffx[1:]
+    coef[1:-1, 0] = -(dx2) / (dx1 * (dx1 + dx2))
+    coef[1:-1, 1] = (dx2 - dx1) / (dx1 * dx2)
+    coef[1:-1, 2] = dx1 / (dx2 * (dx1 + dx2))
+    dx1, dx2 = diffx[0], diffx[1]
+    coef[0] = (-(2.0 * dx1 + dx2) / (dx1 * (dx1 + dx2)), (dx1 + dx2) / (dx1 * dx2),
+               -dx1 / (dx2 * (dx1 + dx2)))
+    dx1, dx2 = diffx[-2], diffx[-1]
+    coef[-1] = ((dx2) / (dx1 * (dx1 + dx2)), -(dx2 + dx1) / (dx1 * dx2),
+                (2.0 * dx2 + dx1) / (dx2 * (dx1 + dx2)))
+    return coef, False, 0.0
+
+
+def stratification(T, S, p, z, func="n2", eos="wright", gravity=-9.8, f32_mode="faithful"):
+    """mlx_stratification: N^2 (``func="n2"``, derived.py:328-411) or the stability angle
+    (``"turner"``, derived.py:714-766) in one pass over device fields laid out (nt, nz, plane)
+    -- z the middle axis, nt / plane the products of the dimensions before / after it.  ``z`` the
+    level coordinate (nz,); ``p`` None (linear EOS), one value, (nz,) or a (nt, nz, plane) /
+    (nz, plane) float64 device tensor.  Returns (nt, nz, plane) float64."""
+    require_device()
+    if not (isinstance(T, torch.Tensor) and isinstance(S, torch.Tensor) and T.is_cuda and S.is_cuda):
+        raise TypeError("thetao and so must be CUDA/HIP torch tensors")
+    if T.dim() != 3 or T.shape != S.shape:
+        raise ValueError(f"thetao {tuple(T.shape)} and so {tuple(S.shape)} must both be (nt, nz, plane)")
+    if T.dtype != S.dtype:
+        raise TypeError("thetao and so of different dtypes: convert one of them")
+    dt = _dtype_code(T, f32_mode)
+    T, S = T.contiguous(), S.contiguous()
+    nt, nz, plane = (int(v) for v in T.shape)
+    if nt == 0 or plane == 0:
+        raise ValueError(f"empty field: shape {(nt, nz, plane)} has no cells")
+    coef, uniform, two_dx = gradient_coefficients(z)
+    if coef.shape[0] != nz:
+        raise ValueError("when 1d, distances must match the length of the corresponding dimension")
+    if eos.lower() == "linear":
+        pt, strides = None, (0, 0, 0)
+    else:
+        if p is None:
+            raise TypeError("p must not be None for the Wright EOS")
+        pt = _f64(p, T.device)
+        shape = tuple(pt.shape)
+        if pt.numel() == 1:
+            pt, strides = pt.reshape(1), (0, 0, 0)
+        elif shape == (nz,):
+            strides = (0, 1, 0)
+        elif shape == (nz, plane):
+            strides = (0, plane, 1)
+        elif shape == (nt, nz, plane):
+            strides = (nz * plane, plane, 1)
+        else:
+            raise ValueError(f"pressure of shape {shape} is none of (), ({nz},), ({nz},{plane}), "
+                             f"({nt},{nz},{plane})")
+    coef_dev = _f64(coef, T.device)
+    out = torch.empty((nt, nz, plane), dtype=torch.float64, device=T.device)
+    with _on(T.device):
+        rc = _lib.load().mlx_stratification(
+            _ptr(T), _ptr(S), dt, _ptr(pt), *strides, EOS_IDS[eos.lower()],
+            {"n2": _lib.STRAT_N2, "turner": _lib.STRAT_TURNER}[func], _ptr(coef_dev),
+            int(uniform), float(two_dx), float(gravity), nt, nz, plane, _ptr(out),
+            _stream(T.device))
+    _lib.check(rc, "mlx_stratification")
+    return out
+
+
+def adjust_negative_n2(n2, lead0_rows, dz=None, want_adjusted=True):
+    """mlx_adjust_negative_n2 on a (nt, nz, plane) float64 device field (see the header for
+    ``lead0_rows``).  Returns (adjusted or None, speed or None): ``speed`` (nt, plane), the column
+    sum of derived.py:822, when ``dz`` (nz, plane) is given."""
+    require_device()
+    if n2.dim() != 3:
+        raise ValueError("n2 must be (nt, nz, plane)")
+    n2 = n2.to(torch.float64).contiguous()
+    nt, nz, plane = (int(v) for v in n2.shape)
+    adjusted = torch.empty_like(n2) if want_adjusted else None
+    speed = dzt = None
+    if dz is not None:
+        dzt = _f64(dz, n2.device)
+        if tuple(dzt.shape) != (nz, plane):
+            raise ValueError(f"dz has shape {tuple(dzt.shape)}, expected {(nz, plane)}")
+        speed = torch.empty((nt, plane), dtype=torch.float64, device=n2.device)
+    with _on(n2.device):
+        rc = _lib.load().mlx_adjust_negative_n2(_ptr(n2), nt, nz, plane, int(lead0_rows),
+                                                _ptr(dzt), _ptr(adjusted), _ptr(speed),
+                                                _stream(n2.device))
+    _lib.check(rc, "mlx_adjust_negative_n2")
+    return adjusted, speed
+
+
+def wave_speed_where_time0(n2_t0, speed):
+    """mlx_wave_speed_where_time0: (nz, plane) condition field x (nt, plane) speeds ->
+    (nz, plane, nt)."""
+    require_device()
+    nz, plane = (int(v) for v in n2_t0.shape)
+    nt = int(speed.shape[0])
+    out = torch.empty((nz, plane, nt), dtype=torch.float64, device=speed.device)
+    n2_t0, speed = n2_t0.contiguous(), speed.contiguous()
+    with _on(speed.device):
+        rc = _lib.load().mlx_wave_speed_where_time0(_ptr(n2_t0), _ptr(speed), nt, nz, plane,
+                                                    _ptr(out), _stream(speed.device))
+    _lib.check(rc, "mlx_wave_speed_where_time0")
+    return out
+
+
 def skip_dry_default():
     """Land / sub-bottom skipping is exact, so it is on unless MOMLEVEL_AMD_SKIP_DRY=0."""
     import os

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 SOURCES = [os.path.join(HERE, "momlevel_hip.hip"), os.path.join(HERE, "momlevel_promote.hip"),
-           os.path.join(HERE, "host_copy.cpp")]
+           os.path.join(HERE, "momlevel_strat.hip"), os.path.join(HERE, "host_copy.cpp")]
 DEPENDS = SOURCES + [
     os.path.join(HERE, "eos_device.hpp"),
     os.path.join(HERE, "eos_promote.hpp"),

@@ -3,7 +3,10 @@
 Same signatures as src/momlevel/derived.py: ``calc_rho`` (:597-639), ``calc_masso``
 (:414-444), ``calc_volo`` (:769-795), ``calc_rhoga`` (:642-666), ``calc_dz``
 (:249-325), plus ``calc_alpha`` / ``calc_beta`` (:74-159) which reuse the EOS
-kernel.  Inputs and outputs are labelled arrays (momlevel_amd.labeled, or xarray
+kernel, and their consumers: ``calc_n2`` (:328-411),
+``calc_stability_angle`` (:714-766), ``adjust_negative_n2`` (:30-71) and
+``calc_wave_speed`` (:798-831), each ONE pass of a HIP kernel of its own
+(csrc/momlevel_strat.hip) over what the reference evaluates as dozens of numpy passes.  Inputs and outputs are labelled arrays (momlevel_amd.labeled, or xarray
 objects when xarray is installed -- see adapters.py); every number comes from a
 HIP kernel.
 """
@@ -16,14 +19,18 @@ from .adapters import accepts_xarray
 from .labeled import DataArray
 
 __all__ = [
+    "adjust_negative_n2",
     "calc_alpha",
     "calc_beta",
     "calc_dz",
     "calc_masso",
+    "calc_n2",
     "calc_pdens",
     "calc_rho",
     "calc_rhoga",
+    "calc_stability_angle",
     "calc_volo",
+    "calc_wave_speed",
 ]
 
 
@@ -214,3 +221,166 @@ def calc_dz(levels, interfaces, depth, top=0.0, bottom=None, fraction=False):
     coords = dict(depth.coords)
     coords[zdim] = levels.coords.get(zdim, levels)
     return DataArray(out if depth.is_device else hostio.to_host(out), (zdim,) + depth.dims, coords)
+
+
+# ---------------------------------------------------------------------------------------
+# stratification: the consumers of alpha / beta (csrc/momlevel_strat.hip)
+# ---------------------------------------------------------------------------------------
+def _z_layout(da, zcoord):
+    """(index of zcoord, nt, nz, plane): the field seen as (nt, nz, plane), z the middle axis."""
+    if zcoord not in da.dims:
+        raise ValueError(f"{zcoord!r} is not a dimension of the field (dims {da.dims})")
+    zi = da.dims.index(zcoord)
+    shape = tuple(int(v) for v in da.shape)
+    return zi, int(np.prod(shape[:zi], dtype=np.int64)), shape[zi], int(np.prod(shape[zi + 1:], dtype=np.int64))
+
+
+def _level_values(da, zcoord):
+    if zcoord not in da.coords:
+        raise ValueError(f"the field has no coordinate values for {zcoord!r}")
+    return np.asarray(da.coords[zcoord].values)
+
+
+def _strat_pressure(pres, like, zcoord, dev, f32_fields):
+    """The pressure operand of alpha / beta as core.stratification takes it.  float32 fields need
+    a float64 pressure ARRAY: with a python float or a float32 array numpy evaluates alpha in
+    float32 (eos/_dispatch.py), which this kernel does not restate."""
+    if isinstance(pres, DataArray):
+        if f32_fields and str(pres.dtype) != "float64":
+            raise TypeError("float32 thetao/so need a float64 pressure (numpy evaluates alpha and "
+                            f"beta in float32 against a {pres.dtype} one): convert it")
+        if not set(pres.dims) <= set(like.dims):
+            raise ValueError(f"pressure dims {pres.dims} are not dims of the field {like.dims}")
+        zi, nt, nz, plane = _z_layout(like, zcoord)
+        if pres.dims == (zcoord,):
+            return engine.to_device(pres.data, dev, torch.float64).reshape(nz)
+        if pres.dims == ():
+            return engine.to_device(pres.data, dev, torch.float64).reshape(1)
+        sizes = dict(like.sizes)
+        raw = engine.to_device(_expand_to(pres, like.dims, sizes), dev, torch.float64)
+        if zi > 0 and all(d not in pres.dims for d in like.dims[:zi]):  # no leading (time) dims
+            return raw.reshape(raw.shape[zi:]).expand(tuple(like.shape[zi:])).contiguous().reshape(nz, plane)
+        return raw.expand(tuple(like.shape)).contiguous().reshape(nt, nz, plane)
+    if f32_fields:
+        raise TypeError("float32 thetao/so need a float64 pressure array (numpy evaluates alpha and "
+                        "beta in float32 against a python float): pass a DataArray")
+    return float(pres)
+
+
+def _stratification(func, thetao, so, pres, eos, zcoord, gravity=-9.8):
+    if tuple(so.dims) != tuple(thetao.dims) or tuple(so.shape) != tuple(thetao.shape):
+        raise ValueError(f"thetao {thetao.dims}{tuple(thetao.shape)} and so {so.dims}{tuple(so.shape)} "
+                         "must share dims and shape")
+    if str(thetao.dtype) != str(so.dtype):
+        raise TypeError("thetao and so of different dtypes: convert one of them")
+    if str(thetao.dtype) not in ("float32", "float64"):
+        raise TypeError(f"thetao/so must be float32 or float64, not {thetao.dtype}")
+    f32 = str(thetao.dtype) == "float32"
+    if f32 and eos.lower() == "linear":
+        raise TypeError("the linear EOS on float32 fields is float32 throughout in numpy: "
+                        "convert the fields to float64")
+    util.eos_func_from_str(eos, func_name="alpha")  # unknown EOS: the reference's ValueError
+    zi, nt, nz, plane = _z_layout(thetao, zcoord)
+    z = _level_values(thetao, zcoord)
+    dev = engine.device_of(thetao.data, so.data)
+    dt = torch.float32 if f32 else torch.float64
+    T = engine.to_device(thetao.data, dev, dt).reshape(nt, nz, plane)
+    S = engine.to_device(so.data, dev, dt).reshape(nt, nz, plane)
+    p = None if eos.lower() == "linear" else _strat_pressure(pres, thetao, zcoord, dev, f32)
+    out = core.stratification(T, S, p, z, func=func, eos=eos.lower(), gravity=gravity)
+    out = out.reshape(tuple(thetao.shape))
+    on_device = thetao.is_device or so.is_device
+    return DataArray(out if on_device else hostio.to_host(out), thetao.dims, dict(thetao.coords))
+
+
+@accepts_xarray
+def calc_n2(thetao, so, eos="Wright", gravity=-9.8, patm=101325.0, zcoord="z_l", interfaces=None,
+            adjust_negative=False):
+    """Buoyancy frequency N^2 at the cell centres (derived.py:328-411):
+    ``gravity * ((alpha * dT/dz) - (beta * dS/dz))`` with alpha, beta at
+    ``p = thetao[zcoord] * 1e4 + patm`` and d/dz = ``differentiate(zcoord, edge_order=2)``.
+    ``interfaces`` (the cell-edge variant) interpolates with xgcm's ``Grid.transform`` in the
+    reference: not built."""
+    if interfaces is not None:
+        raise NotImplementedError("calc_n2(interfaces=...) needs xgcm's linear vertical transform "
+                                  "(derived.py:389-394): not built; pass interfaces=None")
+    z = DataArray(_level_values(thetao, zcoord).astype(np.float64), (zcoord,))
+    pres = (z * 1.0e4) + patm  # derived.py:396
+    n2 = _stratification("n2", thetao, so, pres, eos, zcoord, gravity=gravity)
+    n2.attrs = {
+        "standard_name": "square_of_brunt_vaisala_frequency_in_sea_water",
+        "long_name": "Square of seawater buoyancy frequency",
+        "units": "s-2",
+    }
+    return adjust_negative_n2(n2, zcoord=zcoord) if adjust_negative else n2
+
+
+@accepts_xarray
+def calc_stability_angle(thetao, so, pres, eos="Wright", zcoord="z_l"):
+    """Stability (Turner) angle in degrees (derived.py:714-766)."""
+    result = _stratification("turner", thetao, so, pres, eos, zcoord)
+    result.name = "tu_angle"
+    result.attrs = {
+        "long_name": "Stability angle",
+        "units": "degrees",
+    }
+    return result
+
+
+def _adjust(n2, zcoord, dz=None, want_adjusted=True):
+    zi, nt, nz, plane = _z_layout(n2, zcoord)
+    # `adjusted[0]` (derived.py:62) indexes the LEADING dimension: the rows of the (nt, nz, plane)
+    # view whose index along it is 0 -- all nt // size0 of them -- unless z leads
+    lead0_rows = 0 if zi == 0 else nt // int(n2.shape[0])
+    dev = engine.device_of(n2.data)
+    x = engine.to_device(n2.data, dev, torch.float64).reshape(nt, nz, plane)
+    dzt = None
+    if dz is not None:
+        if tuple(dz.dims) != tuple(n2.dims[zi:]) or tuple(dz.shape) != tuple(n2.shape[zi:]):
+            raise ValueError(f"dz {dz.dims}{tuple(dz.shape)} must cover the field's "
+                             f"{n2.dims[zi:]}{tuple(n2.shape[zi:])}")
+        dzt = engine.to_device(dz.data, dev, torch.float64).reshape(nz, plane)
+    adjusted, speed = core.adjust_negative_n2(x, lead0_rows, dz=dzt, want_adjusted=want_adjusted)
+    return adjusted, speed, (zi, nt, nz, plane), x
+
+
+@accepts_xarray
+def adjust_negative_n2(n2, zcoord="z_l"):
+    """Remove negative N^2 after Chelton et al. 1998 (derived.py:30-71): non-positive values
+    become NaN, NaN at index 0 OF THE LEADING DIMENSION becomes 1e-8 (the reference writes
+    ``adjusted[0]``: the first time step of a (time, z, y, x) field, the surface of a (z, y, x)
+    one), the rest is forward-filled down the column, the original NaN mask is put back."""
+    adjusted, _, _, _ = _adjust(n2, zcoord)
+    adjusted = adjusted.reshape(tuple(n2.shape))
+    out = DataArray(adjusted if n2.is_device else hostio.to_host(adjusted), n2.dims, dict(n2.coords))
+    out.attrs = {**n2.attrs, "comment": "adjustment applied for negative values"}
+    return out
+
+
+@accepts_xarray
+def calc_wave_speed(n2, dz, zcoord="z_l"):
+    """Gravity wave speed of the first baroclinic mode (derived.py:798-831):
+    ``(sqrt(adjust_negative_n2(n2)) * dz).sum(zcoord) / pi``, NaN where ``n2[0]`` is null.  As in
+    the reference ``n2[0]`` indexes the leading dimension: for a (z, y, x) field it is the surface
+    and the result has dims (y, x); for a (time, z, y, x) field it is the first TIME STEP, dims
+    (z, y, x), which xarray broadcasts against the (time, y, x) speeds into (z, y, x, time) -- the
+    array whose sum the reference's own test holds (tests/test_derived.py:147-151)."""
+    _, speed, (zi, nt, nz, plane), x = _adjust(n2, zcoord, dz=dz, want_adjusted=False)
+    trail_dims, trail_shape = tuple(n2.dims[zi + 1:]), tuple(n2.shape[zi + 1:])
+    host = not n2.is_device
+    if zi == 0:
+        data = speed.reshape(trail_shape)
+        result = DataArray(hostio.to_host(data) if host else data, trail_dims,
+                           {k: v for k, v in n2.coords.items() if set(v.dims) <= set(trail_dims)})
+    elif zi == 1:
+        data = core.wave_speed_where_time0(x[0], speed).reshape((nz,) + trail_shape + (nt,))
+        dims = (zcoord,) + trail_dims + (n2.dims[0],)
+        result = DataArray(hostio.to_host(data) if host else data, dims, dict(n2.coords))
+    else:
+        raise NotImplementedError("calc_wave_speed: more than one dimension before "
+                                  f"{zcoord!r} (dims {n2.dims})")
+    result.attrs = {
+        "long name": "Ocean gravity wave speed of the first baroclinic mode",
+        "units": "m s-1",
+    }
+    return result

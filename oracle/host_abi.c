@@ -562,6 +562,119 @@ int mlx_valu_probe(int64_t iters, double *out, int64_t *lane_instructions, void 
   return 0;
 }
 
+/* ---- stratification diagnostics (derived.py:328-411, :714-766, :30-71, :798-831) ---------- */
+static inline double gradient_at(const void *f, int dtype, int64_t i0, int64_t stride, double a,
+                                 double b, double c, int central, double two_dx) {
+  /* numpy.gradient, one value: levels i0, i0+stride, i0+2*stride */
+  if (dtype == MLX_DTYPE_F32) { /* float32 array: float64 products, float32 result */
+    const float *x = (const float *)f;
+    const float f0 = x[i0], f1 = x[i0 + stride], f2 = x[i0 + 2 * stride];
+    if (central) return (double)(float)((double)(f2 - f0) / two_dx);
+    return (double)(float)((a * (double)f0 + b * (double)f1) + c * (double)f2);
+  }
+  double d0, d1, d2;
+  if (dtype == MLX_DTYPE_F64) {
+    const double *x = (const double *)f;
+    d0 = x[i0], d1 = x[i0 + stride], d2 = x[i0 + 2 * stride];
+  } else {
+    const float *x = (const float *)f;
+    d0 = (double)x[i0], d1 = (double)x[i0 + stride], d2 = (double)x[i0 + 2 * stride];
+  }
+  if (central) return (d2 - d0) / two_dx;
+  return (a * d0 + b * d1) + c * d2;
+}
+
+int mlx_stratification(const void *T, const void *S, int dtype, const double *p,
+                       int64_t p_stride_t, int64_t p_stride_z, int64_t p_stride_cell, int eos,
+                       int func, const double *coef, int uniform, double two_dx, double gravity,
+                       int64_t nt, int64_t nz, int64_t plane, double *out, void *stream) {
+  (void)stream;
+  if (!T || !S || !coef || !out) return fail(MLX_E_NULL, "T, S, coef and out must not be NULL");
+  if (eos != MLX_EOS_WRIGHT && eos != MLX_EOS_LINEAR) return fail(MLX_E_ENUM, "unknown eos");
+  if (func != MLX_STRAT_N2 && func != MLX_STRAT_TURNER) return fail(MLX_E_ENUM, "unknown func");
+  if (dtype != MLX_DTYPE_F64 && dtype != MLX_DTYPE_F32 && dtype != MLX_DTYPE_F32_UPCAST)
+    return fail(MLX_E_ENUM, "dtype must be MLX_DTYPE_F64, _F32 or _F32_UPCAST");
+  if (eos == MLX_EOS_LINEAR && dtype == MLX_DTYPE_F32)
+    return fail(MLX_E_ENUM, "linear EOS on float32 fields is float32 throughout in numpy: not built");
+  if (!p && eos == MLX_EOS_WRIGHT) return fail(MLX_E_NULL, "p must not be NULL for the Wright EOS");
+  if (nt <= 0 || plane <= 0) return fail(MLX_E_SHAPE, "nt and plane must be > 0");
+  if (nz < 3) return fail(MLX_E_SHAPE, "nz must be >= 3 (second-order edges)");
+  if (p_stride_t < 0 || p_stride_z < 0 || p_stride_cell < 0 || p_stride_cell > 1)
+    return fail(MLX_E_SHAPE, "pressure strides must be >= 0 (cell stride 0 or 1)");
+  if (uniform && !(two_dx == two_dx && two_dx != 0.0))
+    return fail(MLX_E_SHAPE, "uniform spacing needs a non-zero two_dx");
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int64_t t = 0; t < nt; ++t)
+    for (int64_t k = 0; k < nz; ++k) {
+      const int64_t k0 = (k == 0) ? 0 : (k == nz - 1) ? nz - 3 : k - 1; /* first level of the stencil */
+      const int central = uniform && k > 0 && k < nz - 1;
+      const double a = coef[3 * k], b = coef[3 * k + 1], c = coef[3 * k + 2];
+      for (int64_t i = 0; i < plane; ++i) {
+        const int64_t at = (t * nz + k) * plane + i, at0 = (t * nz + k0) * plane + i;
+        const double pk = p ? p[t * p_stride_t + k * p_stride_z + i * p_stride_cell] : 0.0;
+        const Val Tv = load(T, at, dtype), Sv = load(S, at, dtype);
+        const double alpha = eos_eval(eos, MLX_FUNC_ALPHA, Tv, Sv, pk, 0.0);
+        const double beta = eos_eval(eos, MLX_FUNC_BETA, Tv, Sv, pk, 0.0);
+        const double dtdz = gradient_at(T, dtype, at0, plane, a, b, c, central, two_dx);
+        const double dsdz = gradient_at(S, dtype, at0, plane, a, b, c, central, two_dx);
+        if (func == MLX_STRAT_N2) {
+          out[at] = gravity * ((alpha * dtdz) - (beta * dsdz));
+        } else {
+          const double r = (beta * dsdz) / (alpha * dtdz);
+          out[at] = atan((1.0 + r) / (1.0 - r)) * (180.0 / 3.14159265358979323846);
+        }
+      }
+    }
+  return 0;
+}
+
+int mlx_adjust_negative_n2(const double *n2, int64_t nt, int64_t nz, int64_t plane,
+                           int64_t lead0_rows, const double *dz, double *adjusted, double *speed,
+                           void *stream) {
+  (void)stream;
+  if (!n2) return fail(MLX_E_NULL, "n2 must not be NULL");
+  if (!adjusted && !speed) return fail(MLX_E_NULL, "one of adjusted / speed is required");
+  if (speed && !dz) return fail(MLX_E_NULL, "speed needs dz");
+  if (nt <= 0 || nz <= 0 || plane <= 0) return fail(MLX_E_SHAPE, "nt, nz, plane must be > 0");
+  if (lead0_rows < 0 || lead0_rows > nt || (lead0_rows == 0 && nt != 1))
+    return fail(MLX_E_SHAPE, "lead0_rows must be in 1..nt, or 0 with nt == 1");
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int64_t t = 0; t < nt; ++t)
+    for (int64_t i = 0; i < plane; ++i) {
+      double carried = NAN, sum = 0.0;
+      for (int64_t k = 0; k < nz; ++k) {
+        const double x = n2[(t * nz + k) * plane + i];
+        double a = (x <= 0.0) ? NAN : x;
+        const int lead0 = lead0_rows ? (t < lead0_rows) : (k == 0);
+        if (lead0 && a != a) a = 1.0e-8;
+        if (a != a) a = carried;
+        carried = a;
+        const double masked = (x != x) ? NAN : a;
+        if (adjusted) adjusted[(t * nz + k) * plane + i] = masked;
+        if (speed) {
+          const double term = sqrt(masked) * dz[k * plane + i];
+          if (term == term) sum += term;
+        }
+      }
+      if (speed) {
+        const double surface = n2[t * nz * plane + i];
+        speed[t * plane + i] = (!lead0_rows && surface != surface) ? NAN : sum / 3.14159265358979323846;
+      }
+    }
+  return 0;
+}
+
+int mlx_wave_speed_where_time0(const double *n2_t0, const double *speed, int64_t nt, int64_t nz,
+                               int64_t plane, double *out, void *stream) {
+  (void)stream;
+  if (!n2_t0 || !speed || !out) return fail(MLX_E_NULL, "n2_t0, speed and out must not be NULL");
+  if (nt <= 0 || nz <= 0 || plane <= 0) return fail(MLX_E_SHAPE, "nt, nz, plane must be > 0");
+  for (int64_t kc = 0; kc < nz * plane; ++kc)
+    for (int64_t t = 0; t < nt; ++t)
+      out[kc * nt + t] = (n2_t0[kc] != n2_t0[kc]) ? NAN : speed[t * plane + kc % plane];
+  return 0;
+}
+
 int mlx_host_copy(void *dst, const void *src, size_t nbytes, int threads, int streaming) {
   (void)streaming; /* the checker's build has no tuned copy: one plain memcpy, same contract */
   if (nbytes == 0) return 0;

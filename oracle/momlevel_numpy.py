@@ -186,6 +186,81 @@ def inverse_barometer(tos, sos, pso, gravity=9.8, equation_of_state="Wright"):
     return pso * (-1.0 / (rho_conv * gravity))
 
 
+# ----------------------------------------------------------------------------
+# Stratification diagnostics: the consumers of alpha / beta
+# ----------------------------------------------------------------------------
+def differentiate_z(f, z, axis):
+    """``DataArray.differentiate(zcoord, edge_order=2)`` (src/momlevel/derived.py:399-400,
+    :752-753): xarray hands the data and the coordinate values to ``numpy.gradient`` -- the
+    third-party routine itself, called here as the reference calls it (second-order one-sided
+    differences at the two ends; a float32 field gives a float32 derivative)."""
+    return np.gradient(f, np.asarray(z), axis=axis, edge_order=2)
+
+
+def calc_n2(thetao, so, z_l, eos="Wright", gravity=-9.8, patm=101325.0, zaxis=-3):
+    """src/momlevel/derived.py:328-411 with ``interfaces=None`` (cell centres; the
+    ``interfaces`` branch needs xgcm).  thetao / so: (..., z, y, x); z_l: (nz,)."""
+    z_l = np.asarray(z_l, dtype=np.float64)
+    pres = ((z_l * 1.0e4) + patm)[:, None, None]  # derived.py:396: thetao[zcoord] * 1e4 + patm
+    alpha = eos_func_from_str(eos, func_name="alpha")(thetao, so, pres)
+    beta = eos_func_from_str(eos, func_name="beta")(thetao, so, pres)
+    dtdz = differentiate_z(thetao, z_l, zaxis)
+    dsdz = differentiate_z(so, z_l, zaxis)
+    return gravity * ((alpha * dtdz) - (beta * dsdz))  # derived.py:401
+
+
+def adjust_negative_n2(n2):
+    """src/momlevel/derived.py:30-71, quirk included: ``adjusted[0]`` indexes the LEADING
+    dimension of the array, whatever it is -- the time axis for a (time, z, y, x) field, the
+    surface only for a (z, y, x) one.  The forward fill runs along z (axis -3)."""
+    n2 = np.asarray(n2)
+    mask = np.where(np.isnan(n2), np.nan, 1.0)
+    with np.errstate(invalid="ignore"):
+        adjusted = np.where(n2 <= 0.0, np.nan, n2)
+    adjusted[0] = np.where(np.isnan(adjusted[0]), 1.0e-8, adjusted[0])
+    zaxis = adjusted.ndim - 3
+    a = np.moveaxis(adjusted, zaxis, 0).copy()
+    for k in range(1, a.shape[0]):  # ffill(zcoord)
+        a[k] = np.where(np.isnan(a[k]), a[k - 1], a[k])
+    adjusted = np.moveaxis(a, 0, zaxis)
+    return adjusted * mask
+
+
+def calc_stability_angle(thetao, so, pres, z_l, eos="Wright", zaxis=-3):
+    """src/momlevel/derived.py:714-766 (the Turner angle, degrees).  ``pres`` broadcasts against
+    the fields (the reference's test passes the z profile z_l * 1e4)."""
+    pres = np.asarray(pres)
+    if pres.ndim == 1:
+        pres = pres[:, None, None]
+    alpha = eos_func_from_str(eos, func_name="alpha")(thetao, so, pres)
+    beta = eos_func_from_str(eos, func_name="beta")(thetao, so, pres)
+    dtdz = differentiate_z(thetao, z_l, zaxis)
+    dsdz = differentiate_z(so, z_l, zaxis)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        R_rho = (beta * dsdz) / (alpha * dtdz)
+        return np.degrees(np.arctan((1 + R_rho) / (1 - R_rho)))
+
+
+def calc_wave_speed(n2, dz):
+    """src/momlevel/derived.py:798-831 for a (z, y, x) n2 (one time level: there ``n2[0]`` IS the
+    surface, as the function's text intends; with a leading time axis the reference's
+    ``xr.where(n2[0].isnull(), ...)`` broadcasts (z,y,x) against (time,y,x) into a 4-D array --
+    the golden tests/test_derived.py:147-151 is the sum of that array and is reproduced by
+    calc_wave_speed_4d_quirk below)."""
+    with np.errstate(invalid="ignore"):
+        result = nansum(np.sqrt(adjust_negative_n2(n2)) * dz, axis=-3) / np.pi
+    return np.where(np.isnan(n2[0]), np.nan, result)
+
+
+def calc_wave_speed_4d_quirk(n2, dz):
+    """The reference's result for a (time, z, y, x) n2, as xarray broadcasts it: dims
+    (z, y, x, time) -- condition n2[time=0] (z,y,x) against the (time,y,x) speeds."""
+    with np.errstate(invalid="ignore"):
+        result = nansum(np.sqrt(adjust_negative_n2(n2)) * dz, axis=-3) / np.pi  # (time, y, x)
+    cond = np.isnan(n2[0])  # (z, y, x)
+    return np.where(cond[..., None], np.nan, np.moveaxis(result, 0, -1)[None])
+
+
 def calc_volo(volcello):
     """src/momlevel/derived.py:769-795 -- asserts 3-D, skipna sum."""
     assert volcello.ndim == 3, "Expecting only 3 dimensions for volcello"

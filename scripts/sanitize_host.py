@@ -43,7 +43,7 @@ def main():
     lib = os.path.join(OUT, "libmomlevel_hip.so")
     csrc = os.path.join(ROOT, "momlevel_amd", "csrc")
     srcs = [os.path.join(csrc, "momlevel_hip.hip"), os.path.join(csrc, "momlevel_promote.hip"),
-            os.path.join(csrc, "host_copy.cpp")]
+            os.path.join(csrc, "momlevel_strat.hip"), os.path.join(csrc, "host_copy.cpp")]
     deps = srcs + [os.path.join(csrc, "eos_device.hpp"), os.path.join(csrc, "eos_promote.hpp"),
                    os.path.join(csrc, "mlx_internal.hpp"),
                    os.path.join(ROOT, "include", "momlevel_hip.h"), os.path.abspath(__file__)]
