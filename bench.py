@@ -567,6 +567,50 @@ def main():
         dist.destroy_process_group()
 
 
+def stratification_timings(T, S, g, steps, B1):
+    """derived.calc_n2's kernel (csrc/momlevel_strat.hip: alpha, beta and both vertical derivatives
+    in one pass; 2 x B1 B read + 8 B written per cell) on `steps` time steps of the resident record,
+    against the no-math probe of that mix, with a band of columns of one step checked against the
+    numpy oracle (numpy.gradient + the EOS module, as the reference evaluates it)."""
+    from oracle import momlevel_numpy as o  # the checker, never the product
+
+    nt, nz, ny, nx = T.shape
+    plane = ny * nx
+    free, _ = torch.cuda.mem_get_info(T.device)
+    steps = int(min(steps, max(0, free - (4 << 30)) // (nz * plane * 8)))  # the float64 result
+    if steps < 2:
+        return {"skipped": "no room for the result beside the resident record"}
+    z = np.asarray(g["z_l"], dtype=np.float64)
+    pz = torch.from_numpy(z * 1.0e4 + 101325.0).to(T.device)
+    Tc, Sc = T[:steps].reshape(steps, nz, plane), S[:steps].reshape(steps, nz, plane)
+    cells = steps * nz * plane
+    res = {}
+
+    def run():
+        res["n2"] = core.stratification(Tc, Sc, pz, z)
+
+    ms = _time(run, reps=2)
+    bpc = 2 * B1 + 8
+    r = {"Mcells/s": round(cells / ms / 1e3, 1), "ms": round(ms, 3),
+         "algorithmic_bytes_per_cell": bpc, "GB/s": round(bpc * cells / ms / 1e6, 1),
+         "frac_of_8TBs": round(bpc * cells / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    r["steps"] = steps
+    r["kernel"] = ("k_stratification<double, 2, kF64, kWright, MLX_STRAT_N2>" if B1 == 8 else
+                   "k_stratification<float, 4, kF32Faithful, kWright, MLX_STRAT_N2>")
+    band = min(ny, 96)  # whole columns (the derivative runs along z) of `band` rows of one step
+    t = steps // 2
+    got = res["n2"][t].reshape(nz, ny, nx)[:, :band].cpu().numpy()
+    ref = o.calc_n2(T[t, :, :band].cpu().numpy(), S[t, :, :band].cpu().numpy(), z)
+    r["band_bit_identical_to_numpy"] = bool(np.array_equal(got, ref, equal_nan=True))
+    # (the probe writes into the result buffer: only after the check)
+    pms = _time(lambda: core.stream_probe_mix(Tc, Sc, out=res["n2"]), reps=2)
+    r["probe_GB/s"] = round((2 * B1 + 8) * cells / pms / 1e6, 1)
+    r["frac_of_matching_probe"] = round(pms / ms, 4)
+    r["probe"] = "mlx_stream_probe_mix: 2 fields in, float64 out, no arithmetic"
+    del res["n2"]
+    return r
+
+
 def local_slab_check(o, Tn, Sn, rho0, g, pres, drho_gpu, eta_gpu):
     """steric.py:151-166 on ONE time slab in numpy (the oracle's functions): delta_rho =
     where(volcello_ref notnull, rho - rho0, NaN), eta = -1/rhozero * nansum(dz * delta_rho) masked by
@@ -789,6 +833,11 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
             out["calc_rho_map"]["frac_of_read_write_probe"] = round(pms / kms, 4)
         ms_skip = _time(lambda: run(True), reps=2)
         out["land_skipping"]["local_with_delta_rho_Mcells/s"] = round(done / ms_skip / 1e3, 1)
+        del drho
+        torch.cuda.empty_cache()
+        # the consumers of alpha / beta: derived.calc_n2 in one pass
+        out["calc_n2"] = stratification_timings(T, S, g, min(nt, 2 * chunk), B1)
+        drho = torch.empty((chunk, nz, ny, nx), dtype=torch.float64, device=dev)
 
         # all three local variants: three launches (24 + 16 + 16 B/cell) vs ONE pass of the
         # all-variants K2 (16 B read + 3 x 8 B written per cell)
@@ -979,6 +1028,7 @@ def f32_timings(vol0, pres, g, dev, nt, synth_kw):
             steps_d, g, 4, with_steric=True))
         del dbuf
         torch.cuda.empty_cache()
+    out["default"]["calc_n2"] = stratification_timings(T, S, g, min(nt, 48), 4)
     # derived.calc_pdens on float32 fields (derived.py:477: a python-float pressure, so numpy keeps
     # the whole expression float32): the any-dtype map, 8 B read + 4 B written per cell
     np_steps = min(nt, 40)

@@ -86,7 +86,9 @@ __device__ __forceinline__ double gradient(TIn f0, TIn f1, TIn f2, double a, dou
   }
 }
 
-template <typename TIn, int V, int MODE>
+// EOS and FUNC are template arguments: as run-time (wave-uniform) switches they left the hot loop a
+// maze of branches around four copies of the arithmetic.
+template <typename TIn, int V, int MODE, int EOS, int FUNC>
 __global__ __launch_bounds__(kStratBlock) void k_stratification(StratArgs g) {
   const int64_t cell0 = ((int64_t)blockIdx.x * kStratBlock + threadIdx.x) * V;
   if (cell0 >= g.plane) return;
@@ -114,13 +116,13 @@ __global__ __launch_bounds__(kStratBlock) void k_stratification(StratArgs g) {
     for (int v = 0; v < V; ++v) {
       const TIn Tc = tw[centre].v[v], Sc = sw[centre].v[v];
       const double pk = p ? p[k * g.p_stride_z + v * g.p_stride_cell] : 0.0;
-      const double alpha = eos_eval<MODE, TIn>(g.eos, kAlpha, Tc, Sc, pk);
-      const double beta = eos_eval<MODE, TIn>(g.eos, kBeta, Tc, Sc, pk);
+      const double alpha = eos_eval<MODE, TIn>(EOS, kAlpha, Tc, Sc, pk);
+      const double beta = eos_eval<MODE, TIn>(EOS, kBeta, Tc, Sc, pk);
       const double dtdz =
           gradient<MODE, TIn>(tw[0].v[v], tw[1].v[v], tw[2].v[v], a, b, c, central, g.two_dx);
       const double dsdz =
           gradient<MODE, TIn>(sw[0].v[v], sw[1].v[v], sw[2].v[v], a, b, c, central, g.two_dx);
-      if (g.func == MLX_STRAT_N2) {
+      if constexpr (FUNC == MLX_STRAT_N2) {
         res[v] = g.gravity * ((alpha * dtdz) - (beta * dsdz));  // derived.py:401
       } else {
         const double r = (beta * dsdz) / (alpha * dtdz);  // derived.py:756
@@ -155,11 +157,26 @@ __global__ __launch_bounds__(kStratBlock) void k_stratification(StratArgs g) {
   emit(nz - 1, integral_constant<int, 2>{}, false);  // out[-1] = a f[-3] + b f[-2] + c f[-1]
 }
 
+template <typename TIn, int V, int MODE, int EOS>
+void launch_eos(const StratArgs& g, dim3 grid, hipStream_t st) {
+  if (g.func == MLX_STRAT_N2)
+    hipLaunchKernelGGL((k_stratification<TIn, V, MODE, EOS, MLX_STRAT_N2>), grid,
+                       dim3(kStratBlock), 0, st, g);
+  else
+    hipLaunchKernelGGL((k_stratification<TIn, V, MODE, EOS, MLX_STRAT_TURNER>), grid,
+                       dim3(kStratBlock), 0, st, g);
+}
+
 template <typename TIn, int V, int MODE>
 void launch(const StratArgs& g, int64_t nt, hipStream_t st) {
   const int64_t per_block = (int64_t)kStratBlock * V;
   dim3 grid((unsigned)((g.plane + per_block - 1) / per_block), (unsigned)nt);
-  hipLaunchKernelGGL((k_stratification<TIn, V, MODE>), grid, dim3(kStratBlock), 0, st, g);
+  if (g.eos == MLX_EOS_LINEAR) {
+    // (numpy's float32-throughout linear EOS is refused by the entry point)
+    if constexpr (MODE != kF32Faithful) launch_eos<TIn, V, MODE, kLinear>(g, grid, st);
+  } else {
+    launch_eos<TIn, V, MODE, kWright>(g, grid, st);
+  }
 }
 
 // adjust_negative_n2 (derived.py:30-71) and calc_wave_speed's column sum (derived.py:822) in one

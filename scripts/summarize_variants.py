@@ -18,7 +18,8 @@ import os
 import shutil
 import sys
 
-MAIN = ("k_steric_global", "k_steric_local")
+# the kernels whose dispatches the plan lists (MLX_SUMMARY_MAIN overrides: run_profiles_strat.sh)
+MAIN = tuple(os.environ.get("MLX_SUMMARY_MAIN", "k_steric_global,k_steric_local").split(","))
 
 
 def kernel_source_sha():
