@@ -608,6 +608,7 @@ def stratification_timings(T, S, g, steps, B1):
     r["frac_of_matching_probe"] = round(pms / ms, 4)
     r["probe"] = "mlx_stream_probe_mix: 2 fields in, float64 out, no arithmetic"
     del res["n2"]
+    torch.cuda.empty_cache()  # (the callers size their next buffers from the driver's free memory)
     return r
 
 
