@@ -51,3 +51,47 @@ def test_hip_library_matches_the_host_build(shape, dtype, f32_mode):
     assert_bit_equal(core.calc_dz(g["z_i"], torch.from_numpy(g["deptho"]).cuda()).cpu().numpy(),
                      h.calc_dz(g["z_i"], g["deptho"]), "calc_dz")
     assert core.nansum(dvol).item() == pytest.approx(h.nansum(vol), rel=1e-13)
+
+
+@pytest.mark.parametrize("dtype,f32_mode", [(np.float64, "faithful"), (np.float32, "faithful"),
+                                            (np.float32, "upcast")])
+@pytest.mark.parametrize("levels", ["uneven", "even"])
+def test_stratification_matches_the_host_build(dtype, f32_mode, levels):
+    """mlx_stratification / mlx_adjust_negative_n2 / mlx_wave_speed_where_time0: the HIP kernels
+    against the host build's plain C loops (separately written: oracle/host_abi.c) on the same
+    inputs -- N^2, the adjustment and the wave speed bit for bit, the stability angle to the last
+    bits of the two arctans.  (What pins them to the REFERENCE: tests/test_gpu_stratification.py.)"""
+    nt, nz, ny, nx = 3, 9, 6, 20
+    plane = ny * nx
+    r = np.random.default_rng(23)
+    T = r.uniform(-2, 32, (nt, nz, plane)).astype(dtype)
+    S = r.uniform(30, 40, (nt, nz, plane)).astype(dtype)
+    land = r.random(plane) < 0.2
+    T[..., land] = np.nan
+    S[..., land] = np.nan
+    z = np.cumsum(2.0 * 1.3 ** np.arange(nz)) if levels == "uneven" else 4.0 * np.arange(nz) + 2.0
+    p = z * 1.0e4 + 101325.0
+    coef, uniform, two_dx = core.gradient_coefficients(z)
+    dT, dS = torch.from_numpy(T).cuda(), torch.from_numpy(S).cuda()
+    kw = dict(f32_mode=f32_mode)
+    n2 = core.stratification(dT, dS, torch.from_numpy(p).cuda(), z, **kw)
+    hn2 = h.stratification(T, S, p, coef, uniform, two_dx, **kw)
+    assert_bit_equal(n2.cpu().numpy(), hn2, "n2")
+    tu = core.stratification(dT, dS, torch.from_numpy(p).cuda(), z, func="turner", **kw).cpu().numpy()
+    htu = h.stratification(T, S, p, coef, uniform, two_dx, func="turner", **kw)
+    assert np.array_equal(np.isnan(tu), np.isnan(htu))
+    assert np.nanmax(np.abs(tu - htu)) <= 90.0 * 1e-12
+    dz = np.abs(r.normal(10.0, 3.0, (nz, plane)))
+    adj, speed = core.adjust_negative_n2(n2, 1, dz=torch.from_numpy(dz).cuda())
+    hadj, hspeed = h.adjust_negative_n2(hn2, 1, dz=dz)
+    assert_bit_equal(adj.cpu().numpy(), hadj, "adjusted")
+    assert_bit_equal(speed.cpu().numpy(), hspeed, "speed")
+    assert_bit_equal(core.wave_speed_where_time0(n2[0], speed).cpu().numpy(),
+                     h.wave_speed_where_time0(hn2[0], hspeed), "speed broadcast")
+    one, sp1 = core.adjust_negative_n2(n2[:1], 0, dz=torch.from_numpy(dz).cuda())
+    hone, hsp1 = h.adjust_negative_n2(hn2[:1], 0, dz=dz)
+    assert_bit_equal(one.cpu().numpy(), hone, "adjusted, z leading")
+    assert_bit_equal(sp1.cpu().numpy(), hsp1, "speed, z leading")
+    if dtype == np.float64:
+        lin = core.stratification(dT, dS, None, z, eos="linear")
+        assert_bit_equal(lin.cpu().numpy(), h.stratification(T, S, None, coef, uniform, two_dx, eos="linear"))
