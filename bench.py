@@ -600,8 +600,12 @@ def stratification_timings(T, S, g, steps, B1):
     band = min(ny, 96)  # whole columns (the derivative runs along z) of `band` rows of one step
     t = steps // 2
     got = res["n2"][t].reshape(nz, ny, nx)[:, :band].cpu().numpy()
-    ref = o.calc_n2(T[t, :, :band].cpu().numpy(), S[t, :, :band].cpu().numpy(), z)
+    Tn, Sn = T[t, :, :band].cpu().numpy(), S[t, :, :band].cpu().numpy()
+    t0 = time.perf_counter()
+    ref = o.calc_n2(Tn, Sn, z)
+    cpu_s = time.perf_counter() - t0
     r["band_bit_identical_to_numpy"] = bool(np.array_equal(got, ref, equal_nan=True))
+    r["numpy_oracle_1_thread_Mcells/s"] = round(ref.size / cpu_s / 1e6, 2)  # (on that band)
     # (the probe writes into the result buffer: only after the check)
     pms = _time(lambda: core.stream_probe_mix(Tc, Sc, out=res["n2"]), reps=2)
     r["probe_GB/s"] = round((2 * B1 + 8) * cells / pms / 1e6, 1)

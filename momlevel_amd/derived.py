@@ -284,13 +284,51 @@ def _stratification(func, thetao, so, pres, eos, zcoord, gravity=-9.8):
     z = _level_values(thetao, zcoord)
     dev = engine.device_of(thetao.data, so.data)
     dt = torch.float32 if f32 else torch.float64
+    p = None if eos.lower() == "linear" else _strat_pressure(pres, thetao, zcoord, dev, f32)
+    kw = dict(func=func, eos=eos.lower(), gravity=gravity)
+    on_device = thetao.is_device or so.is_device
+    if not on_device and nt > 1 and nt * nz * plane > _HOST_PIPELINE_ELEMS:
+        out = _stratification_host_rows(thetao.data, so.data, p, z, nt, nz, plane, dev, **kw)
+        return DataArray(out.reshape(tuple(thetao.shape)), thetao.dims, dict(thetao.coords))
     T = engine.to_device(thetao.data, dev, dt).reshape(nt, nz, plane)
     S = engine.to_device(so.data, dev, dt).reshape(nt, nz, plane)
-    p = None if eos.lower() == "linear" else _strat_pressure(pres, thetao, zcoord, dev, f32)
-    out = core.stratification(T, S, p, z, func=func, eos=eos.lower(), gravity=gravity)
-    out = out.reshape(tuple(thetao.shape))
-    on_device = thetao.is_device or so.is_device
+    out = core.stratification(T, S, p, z, **kw).reshape(tuple(thetao.shape))
     return DataArray(out if on_device else hostio.to_host(out), thetao.dims, dict(thetao.coords))
+
+
+# host fields above this size are evaluated in groups of rows (the dimensions before z: time
+# steps), the groups' uploads, kernels and result downloads overlapping -- as the pointwise EOS
+# functions do (eos/_dispatch.py) -- and the device never holds more than a few groups
+_HOST_PIPELINE_ELEMS = 1 << 26
+_HOST_GROUP_ELEMS = 1 << 25
+
+
+def _stratification_host_rows(T, S, p, z, nt, nz, plane, dev, **kw):
+    """core.stratification on host fields seen as (nt, nz, plane), group of rows by group: rows
+    are independent (the derivative runs along z), so group k+1 uploads (hostio.Uploader) while
+    group k's kernel runs and group k-1's result leaves (hostio.Downloader)."""
+    Tn = np.asarray(T).reshape(nt, nz, plane)
+    Sn = np.asarray(S).reshape(nt, nz, plane)
+    rows = max(1, _HOST_GROUP_ELEMS // (nz * plane))
+    bounds = [(i0, min(i0 + rows, nt)) for i0 in range(0, nt, rows)]
+    p_rows = isinstance(p, torch.Tensor) and p.dim() == 3  # a pressure that varies from row to row
+    out = np.empty((nt, nz, plane), dtype=np.float64)
+    main = torch.cuda.current_stream(dev)
+    up = hostio.Uploader(dev)
+    try:
+        with hostio.Downloader(dev) as results:
+            nxt = up.submit([Tn[bounds[0][0]:bounds[0][1]], Sn[bounds[0][0]:bounds[0][1]]])
+            for n, (i0, i1) in enumerate(bounds):
+                (Td, Sd), ready = nxt.result()  # (re-raises what the worker raised)
+                if n + 1 < len(bounds):
+                    j0, j1 = bounds[n + 1]
+                    nxt = up.submit([Tn[j0:j1], Sn[j0:j1]])
+                main.wait_event(ready)
+                res = core.stratification(Td, Sd, p[i0:i1] if p_rows else p, z, **kw)
+                results.submit([(out[i0:i1], res)])
+    finally:
+        up.close()
+    return out
 
 
 @accepts_xarray

@@ -69,6 +69,24 @@ def main():
         else:
             rep["same_bits"] = bool(np.array_equal(got, res, equal_nan=True))
     print(json.dumps(rep), flush=True)
+    # derived.calc_n2 on the same host fields: groups of time steps pipelined the same way
+    from momlevel_amd import derived
+    from momlevel_amd.labeled import DataArray
+
+    z = np.cumsum(2.0 * 1.075 ** np.arange(a.nz)) - 1.0
+    dims = ("time", "z_l", "yh", "xh")
+    coords = {"z_l": DataArray(z, ("z_l",))}
+    Td, Sd = DataArray(host[0], dims, coords), DataArray(host[1], dims, coords)
+    walls = []
+    for _ in range(3):
+        n2 = None
+        t0 = time.perf_counter()
+        n2 = derived.calc_n2(Td, Sd)
+        walls.append(round(time.perf_counter() - t0, 3))
+    print(json.dumps({"call": "derived.calc_n2(thetao, so) on host fields", "shape": list(shape),
+                      "dtype": a.dtype, "wall_s": walls,
+                      "GB/s_in_plus_out": round((2 * cells * itemsize + cells * 8) / min(walls) / 1e9, 1),
+                      "Gcells/s_end_to_end": round(cells / min(walls) / 1e9, 2)}), flush=True)
 
 
 if __name__ == "__main__":

@@ -140,6 +140,36 @@ def test_pressure_operands_and_device_inputs():
     assert_bit_equal(alt.values, o.calc_n2(T, S, z, gravity=-9.81, patm=0.0))
 
 
+def test_large_host_fields_are_pipelined(monkeypatch):
+    """Host fields above the pipeline limit go through groups of time steps whose uploads, kernels
+    and result downloads overlap (hostio.Uploader / Downloader): same bits, whatever the group
+    size; a pressure that varies with time is sliced with its rows."""
+    from momlevel_amd import hostio
+
+    monkeypatch.setattr(derived, "_HOST_PIPELINE_ELEMS", 1000)
+    monkeypatch.setattr(derived, "_HOST_GROUP_ELEMS", 2 * 6 * 40 * 50)  # two time steps a group
+    used = []
+    real = hostio._enqueue_download
+    monkeypatch.setattr(hostio, "_enqueue_download",
+                        lambda out, dev, *a: used.append(out.shape) or real(out, dev, *a))
+    shape = (5, 6, 40, 50)
+    z = LEVELS["mom6_like"](6)
+    dims = ("time", "z_l", "yh", "xh")
+    coords = {"z_l": DataArray(z, ("z_l",))}
+    for dtype in (np.float64, np.float32):
+        T, S = _fields(shape, dtype, 21)
+        used.clear()
+        n2 = derived.calc_n2(DataArray(T, dims, coords), DataArray(S, dims, coords))
+        assert [u[0] for u in used] == [2, 2, 1] and isinstance(n2.data, np.ndarray)
+        assert_bit_equal(n2.values, o.calc_n2(T, S, z))
+    T, S = _fields(shape, np.float64, 22)
+    p4 = np.random.default_rng(4).uniform(1e5, 5e7, shape)
+    tu = derived.calc_stability_angle(DataArray(T, dims, coords), DataArray(S, dims, coords),
+                                      DataArray(p4, dims))
+    ref = o.calc_stability_angle(T, S, p4, z)
+    assert np.nanmax(np.abs(tu.values - ref)) <= 90.0 * 1e-12
+
+
 def test_float32_upcast_mode_matches_float64_arithmetic():
     T, S = _fields((2, 5, 4, 8), np.float32, 9)
     z = LEVELS["mom6_like"](5)
