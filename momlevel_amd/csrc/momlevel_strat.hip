@@ -187,33 +187,82 @@ void launch(const StratArgs& g, int64_t nt, hipStream_t st) {
 // null, = sum_z sqrt(adjusted) * dz (skipna) / pi, dz (nz, plane); for a (z, y, x) field
 // (lead0_rows == 0) the reference's final `xr.where(n2[0].isnull(), nan, result)` -- n2[0] is then
 // the surface -- is applied here; for a (time, z, y, x) field it is k_speed_where_time0's.
+// V adjacent columns per thread (2: one 16-byte access per level), kAdjustDepth levels requested
+// before the first is used: the walk down a column is a serial chain only through `carried`, the
+// loads are independent of it.
+#ifndef MLX_TUNE_ADJUST_DEPTH
+#define MLX_TUNE_ADJUST_DEPTH 8
+#endif
+#ifndef MLX_TUNE_ADJUST_NT_STORE
+#define MLX_TUNE_ADJUST_NT_STORE 1
+#endif
+#ifndef MLX_TUNE_ADJUST_V
+#define MLX_TUNE_ADJUST_V 2
+#endif
+constexpr int kAdjustDepth = MLX_TUNE_ADJUST_DEPTH;
+
+template <int V>
 __global__ __launch_bounds__(kStratBlock) void k_adjust_n2(const double* n2, int64_t nz,
                                                            int64_t plane, int64_t lead0_rows,
                                                            const double* dz, double* adjusted,
                                                            double* speed) {
-  const int64_t cell = (int64_t)blockIdx.x * kStratBlock + threadIdx.x;
+  const int64_t cell = ((int64_t)blockIdx.x * kStratBlock + threadIdx.x) * V;
   if (cell >= plane) return;
   const int64_t t = blockIdx.y;
   const double* col = n2 + t * nz * plane + cell;
   const double nan = __builtin_nan("");
-  double carried = nan, sum = 0.0;
-  for (int64_t k = 0; k < nz; ++k) {
-    const double x = col[k * plane];
-    double a = (x <= 0.0) ? nan : x;  // xr.where(n2 <= 0.0, nan, n2): NaN compares false, stays
-    const bool lead0 = lead0_rows ? (t < lead0_rows) : (k == 0);
-    if (lead0 && a != a) a = 1.0e-8;
-    if (a != a) a = carried;  // ffill(zcoord)
-    carried = a;
-    const double masked = (x != x) ? nan : a;  // adjusted * mask
-    if (adjusted) adjusted[(t * nz + k) * plane + cell] = masked;
-    if (speed) {
-      const double term = sqrt(masked) * dz[k * plane + cell];
-      if (term == term) sum += term;  // skipna sum, ascending z as numpy's axis reduce
+  double carried[V], sum[V], surface[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) carried[v] = nan, sum[v] = 0.0, surface[v] = 0.0;
+  for (int64_t k0 = 0; k0 < nz; k0 += kAdjustDepth) {
+    Pack<double, V> x[kAdjustDepth], w[kAdjustDepth];
+#pragma unroll
+    for (int j = 0; j < kAdjustDepth; ++j)
+      if (k0 + j < nz) {
+        x[j] = load_pack<double, V>(col + (k0 + j) * plane);
+        if (speed) w[j] = load_pack<double, V>(dz + (k0 + j) * plane + cell);
+      }
+#pragma unroll
+    for (int j = 0; j < kAdjustDepth; ++j) {
+      const int64_t k = k0 + j;
+      if (k >= nz) break;
+      const bool lead0 = lead0_rows ? (t < lead0_rows) : (k == 0);
+      double m[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const double xv = x[j].v[v];
+        if (k == 0) surface[v] = xv;
+        double a = (xv <= 0.0) ? nan : xv;  // xr.where(n2 <= 0.0, nan, n2): NaN compares false, stays
+        if (lead0 && a != a) a = 1.0e-8;
+        if (a != a) a = carried[v];  // ffill(zcoord)
+        carried[v] = a;
+        m[v] = (xv != xv) ? nan : a;  // adjusted * mask
+        if (speed) {
+          const double term = sqrt(m[v]) * w[j].v[v];
+          if (term == term) sum[v] += term;  // skipna sum, ascending z as numpy's axis reduce
+        }
+      }
+      if (adjusted) {
+        double* o = adjusted + (t * nz + k) * plane + cell;
+        if constexpr (V == 2) {
+          typedef __attribute__((ext_vector_type(2))) double d2;
+#if MLX_TUNE_ADJUST_NT_STORE
+          __builtin_nontemporal_store(d2{m[0], m[1]}, reinterpret_cast<d2*>(o));
+#else
+          *reinterpret_cast<d2*>(o) = d2{m[0], m[1]};
+#endif
+        } else {
+          o[0] = m[0];
+        }
+      }
     }
   }
   if (speed) {
-    const double c1 = sum / 3.14159265358979323846;
-    speed[t * plane + cell] = (!lead0_rows && col[0] != col[0]) ? nan : c1;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const double c1 = sum[v] / 3.14159265358979323846;
+      speed[t * plane + cell + v] = (!lead0_rows && surface[v] != surface[v]) ? nan : c1;
+    }
   }
 }
 
@@ -307,9 +356,19 @@ extern "C" int mlx_adjust_negative_n2(const double* n2, int64_t nt, int64_t nz, 
     return detail::fail(MLX_E_SHAPE, "nt*nz*plane too large");
   for (const void* q : {(const void*)n2, (const void*)dz, (const void*)adjusted, (const void*)speed})
     if (q && reinterpret_cast<uintptr_t>(q) % 8) return detail::fail(MLX_E_ALIGN, "pointer not 8-byte aligned");
-  dim3 grid((unsigned)((plane + kStratBlock - 1) / kStratBlock), (unsigned)nt);
-  hipLaunchKernelGGL(k_adjust_n2, grid, dim3(kStratBlock), 0, static_cast<hipStream_t>(stream), n2,
-                     nz, plane, lead0_rows, dz, adjusted, speed);
+  bool wide = plane % 2 == 0 && MLX_TUNE_ADJUST_V == 2;
+  for (const void* q : {(const void*)n2, (const void*)dz, (const void*)adjusted})
+    if (q && reinterpret_cast<uintptr_t>(q) % 16) wide = false;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (wide) {
+    dim3 grid((unsigned)((plane / 2 + kStratBlock - 1) / kStratBlock), (unsigned)nt);
+    hipLaunchKernelGGL(k_adjust_n2<2>, grid, dim3(kStratBlock), 0, st, n2, nz, plane, lead0_rows, dz,
+                       adjusted, speed);
+  } else {
+    dim3 grid((unsigned)((plane + kStratBlock - 1) / kStratBlock), (unsigned)nt);
+    hipLaunchKernelGGL(k_adjust_n2<1>, grid, dim3(kStratBlock), 0, st, n2, nz, plane, lead0_rows, dz,
+                       adjusted, speed);
+  }
   return detail::hip_status(hipGetLastError(), "mlx_adjust_negative_n2 launch");
 }
 
