@@ -349,7 +349,7 @@ extern "C" int mlx_adjust_negative_n2(const double* n2, int64_t nt, int64_t nz, 
   if (!adjusted && !speed) return detail::fail(MLX_E_NULL, "one of adjusted / speed is required");
   if (speed && !dz) return detail::fail(MLX_E_NULL, "speed needs dz");
   if (nt <= 0 || nz <= 0 || plane <= 0) return detail::fail(MLX_E_SHAPE, "nt, nz, plane must be > 0");
-  if (nt > 65535) return detail::fail(MLX_E_SHAPE, "nt must be <= 65535");
+  if (nt > 65535 || nz > 65535) return detail::fail(MLX_E_SHAPE, "nt and nz must be <= 65535");
   if (lead0_rows < 0 || lead0_rows > nt || (lead0_rows == 0 && nt != 1))
     return detail::fail(MLX_E_SHAPE, "lead0_rows must be in 1..nt, or 0 with nt == 1");
   if (plane > ((int64_t)1 << 36) || (__int128)nt * nz * plane > ((__int128)1 << 40))
@@ -377,7 +377,10 @@ extern "C" int mlx_wave_speed_where_time0(const double* n2_t0, const double* spe
   using namespace mlx;
   if (!n2_t0 || !speed || !out) return detail::fail(MLX_E_NULL, "n2_t0, speed and out must not be NULL");
   if (nt <= 0 || nz <= 0 || plane <= 0) return detail::fail(MLX_E_SHAPE, "nt, nz, plane must be > 0");
-  if ((__int128)nt * nz * plane > ((__int128)1 << 38)) return detail::fail(MLX_E_SHAPE, "nt*nz*plane too large");
+  // (each factor bounded first: the product of three arbitrary int64 overflows even __int128)
+  if (nt > 65535 || nz > 65535 || plane > ((int64_t)1 << 36) ||
+      (__int128)nt * nz * plane > ((__int128)1 << 38))
+    return detail::fail(MLX_E_SHAPE, "nt*nz*plane too large");
   for (const void* q : {(const void*)n2_t0, (const void*)speed, (const void*)out})
     if (reinterpret_cast<uintptr_t>(q) % 8) return detail::fail(MLX_E_ALIGN, "pointer not 8-byte aligned");
   const int64_t n = nt * nz * plane;

@@ -174,7 +174,7 @@ int main(int argc, char** argv) {
     // the products may overflow int64 for the extreme draws: computed unsigned, only as a hint
     const int64_t n3 = (int64_t)((uint64_t)nz * (uint64_t)plane);
     const int dtype = small_enum(), p_mode = small_enum(), eos = small_enum(), func = small_enum();
-    switch (rnd() % 13) {
+    switch (rnd() % 15) {
       case 0:
         check(mlx_eos_map(ptr(), ptr(), dtype, (const double*)ptr(), p_mode, eos, func, nt, nz,
                           plane, stride(n3), stride(n3), flagbits(), (double*)ptr(), nullptr),
@@ -226,6 +226,24 @@ int main(int argc, char** argv) {
                                       (rnd() % 2) ? (int64_t)((uint64_t)nt * (uint64_t)plane) : dim(),
                                       nullptr),
               "mlx_steric_local_decomp");
+        break;
+      case 13:
+        check(mlx_stratification(ptr(), ptr(), dtype, (const double*)ptr(), stride(n3), stride(plane),
+                                 corrupt() ? (int64_t)(rnd() % 5) - 1 : (int64_t)(rnd() % 2), eos,
+                                 small_enum(), (const double*)ptr(), (int)(rnd() % 2),
+                                 corrupt() ? 0.0 : 20.0, -9.8, nt, nz, plane, (double*)ptr(), nullptr),
+              "mlx_stratification");
+        break;
+      case 14:
+        if (rnd() % 2)
+          check(mlx_adjust_negative_n2((const double*)ptr(), nt, nz, plane,
+                                       corrupt() ? dim() : (int64_t)(rnd() % 2),
+                                       (const double*)ptr(), (double*)ptr(), (double*)ptr(), nullptr),
+                "mlx_adjust_negative_n2");
+        else
+          check(mlx_wave_speed_where_time0((const double*)ptr(), (const double*)ptr(), nt, nz, plane,
+                                           (double*)ptr(), nullptr),
+                "mlx_wave_speed_where_time0");
         break;
       case 12: {
         // a weak operand is a HOST pointer the call reads: a real double (or NULL), never a fake
