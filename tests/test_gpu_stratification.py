@@ -170,6 +170,28 @@ def test_large_host_fields_are_pipelined(monkeypatch):
     assert np.nanmax(np.abs(tu.values - ref)) <= 90.0 * 1e-12
 
 
+def test_xarray_objects_in_xarray_objects_out(monkeypatch):
+    """With xarray objects (tests/fake_xarray.py stands in: xarray is not installable here) the
+    functions answer in kind, coordinates and attributes included."""
+    import fake_xarray
+    from momlevel_amd import adapters
+
+    monkeypatch.setattr(adapters, "xr", fake_xarray)
+    x = adapters.to_xarray(dset1)
+    n2 = derived.calc_n2(x["thetao"], x["so"])
+    assert isinstance(n2, fake_xarray.DataArray) and n2.dims == ("time", "z_l", "yh", "xh")
+    assert n2.attrs["units"] == "s-2" and "z_l" in n2.coords
+    ref = o.calc_n2(dset1.thetao.values, dset1.so.values, dset1.z_l.values)
+    assert_bit_equal(np.asarray(n2.values), ref)
+    adj = derived.adjust_negative_n2(n2)
+    assert isinstance(adj, fake_xarray.DataArray)
+    assert_bit_equal(np.asarray(adj.values), o.adjust_negative_n2(ref))
+    pres = fake_xarray.DataArray(np.asarray(x["z_l"].values) * 1.0e4, dims=("z_l",))  # (the stand-in
+    # has no arithmetic of its own)
+    tu = derived.calc_stability_angle(x["thetao"], x["so"], pres)
+    assert isinstance(tu, fake_xarray.DataArray) and tu.attrs["units"] == "degrees"
+
+
 def test_float32_upcast_mode_matches_float64_arithmetic():
     T, S = _fields((2, 5, 4, 8), np.float32, 9)
     z = LEVELS["mom6_like"](5)
