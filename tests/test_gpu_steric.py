@@ -940,7 +940,7 @@ def test_a_failing_source_raises_from_steric_and_leaves_no_thread_behind(domain,
     monkeypatch.setattr(engine, "chunk_steps", lambda nt, b, dev, budget_bytes=None: 2)
     with pytest.raises(OSError, match="simulated read error"):
         steric(dl, domain=domain)
-    assert not [t for t in threading.enumerate() if t.name.startswith("mlx-upload")]
+    assert not [t for t in threading.enumerate() if t.name.startswith(("mlx-upload", "mlx-download"))]
     good, _ = steric(d, domain=domain)  # the streams and the staging ring are still usable
     base, _ = steric(d, domain=domain)
     assert_bit_equal(good["steric"].values, base["steric"].values)
@@ -962,6 +962,41 @@ def test_host_inputs_under_a_callers_stream(domain, monkeypatch):
     assert_bit_equal(res["steric"].values, base["steric"].values)
     if domain == "local":
         assert_bit_equal(res["delta_rho"].values, base["delta_rho"].values)
+
+
+def test_concurrent_calls_from_a_thread_pool(monkeypatch):
+    """The reference's functions are called from dask's thread pool (examples/example.ipynb runs on
+    a LocalCluster with threads): several steric() / thermosteric() calls at once, host inputs, both
+    domains, float64 and float32 -- each with its own upload and download workers, all sharing the
+    library's copy team and the device's default stream -- give the bits of the same calls made one
+    after the other, and leave no worker thread behind."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+
+    from momlevel_amd import engine, hostio, thermosteric
+
+    monkeypatch.setattr(engine, "chunk_steps", lambda nt, b, dev, budget_bytes=None: 2)
+    monkeypatch.setattr(hostio, "PIECE_BYTES", 1 << 20)  # several staging pieces per chunk
+    jobs = []
+    for i, (fn, domain, dtype) in enumerate([(steric, "local", np.float64), (steric, "global", np.float64),
+                                             (thermosteric, "local", np.float32), (steric, "local", np.float32),
+                                             (thermosteric, "global", np.float64), (steric, "global", np.float32)]):
+        jobs.append((fn, _masked_dataset(nt=7, nz=12, ny=64, nx=96, seed=40 + i, dtype=dtype), domain))
+
+    def call(job):
+        fn, d, domain = job
+        res, ref = fn(d, domain=domain)
+        return {k: np.asarray(res[k].values) for k in res.data_vars}
+
+    expected = [call(j) for j in jobs]
+    with ThreadPoolExecutor(4) as pool:
+        for _ in range(2):
+            got = list(pool.map(call, jobs))
+            for e, g_ in zip(expected, got):
+                assert set(e) == set(g_)
+                for k in e:
+                    assert_bit_equal(g_[k], e[k], k)
+    assert not [t for t in threading.enumerate() if t.name.startswith(("mlx-upload", "mlx-download"))]
 
 
 def test_time_chunks_stop_early_without_hanging(monkeypatch):
