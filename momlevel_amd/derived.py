@@ -47,6 +47,8 @@ def _broadcast_dims(*arrays):
 def _expand_to(da, dims, sizes):
     """Raw data of ``da`` reshaped/transposed so it broadcasts against ``dims``."""
     data = da.data
+    if da.is_lazy:  # (a dask / netCDF4-like field: read here; the pointwise maps take arrays)
+        data = np.asarray(data)
     order = [d for d in dims if d in da.dims]
     perm = [da.dims.index(d) for d in order]
     if perm != list(range(len(perm))):
@@ -288,7 +290,8 @@ def _stratification(func, thetao, so, pres, eos, zcoord, gravity=-9.8):
     kw = dict(func=func, eos=eos.lower(), gravity=gravity)
     on_device = thetao.is_device or so.is_device
     if not on_device and nt > 1 and nt * nz * plane > _HOST_PIPELINE_ELEMS:
-        out = _stratification_host_rows(thetao.data, so.data, p, z, nt, nz, plane, dev, **kw)
+        out = _stratification_host_rows(thetao.data, so.data, p, z, nt, nz, plane, dev,
+                                        lead=nt if zi == 1 else None, **kw)
         return DataArray(out.reshape(tuple(thetao.shape)), thetao.dims, dict(thetao.coords))
     T = engine.to_device(thetao.data, dev, dt).reshape(nt, nz, plane)
     S = engine.to_device(so.data, dev, dt).reshape(nt, nz, plane)
@@ -303,12 +306,18 @@ _HOST_PIPELINE_ELEMS = 1 << 26
 _HOST_GROUP_ELEMS = 1 << 25
 
 
-def _stratification_host_rows(T, S, p, z, nt, nz, plane, dev, **kw):
+def _stratification_host_rows(T, S, p, z, nt, nz, plane, dev, lead=None, **kw):
     """core.stratification on host fields seen as (nt, nz, plane), group of rows by group: rows
     are independent (the derivative runs along z), so group k+1 uploads (hostio.Uploader) while
-    group k's kernel runs and group k-1's result leaves (hostio.Downloader)."""
-    Tn = np.asarray(T).reshape(nt, nz, plane)
-    Sn = np.asarray(S).reshape(nt, nz, plane)
+    group k's kernel runs and group k-1's result leaves (hostio.Downloader).  ``lead``: the
+    fields are (lead, nz, ...) with ONE dimension before z (the usual (time, z, y, x)): they are
+    then sliced along it as they are -- a lazy field (dask / netCDF4 / h5py-like) is read group by
+    group in the upload worker and never materialised whole."""
+    if lead is not None:
+        Tn, Sn = T, S  # sliced along their own leading axis
+    else:
+        Tn = np.asarray(T).reshape(nt, nz, plane)
+        Sn = np.asarray(S).reshape(nt, nz, plane)
     rows = max(1, _HOST_GROUP_ELEMS // (nz * plane))
     bounds = [(i0, min(i0 + rows, nt)) for i0 in range(0, nt, rows)]
     p_rows = isinstance(p, torch.Tensor) and p.dim() == 3  # a pressure that varies from row to row
@@ -324,7 +333,8 @@ def _stratification_host_rows(T, S, p, z, nt, nz, plane, dev, **kw):
                     j0, j1 = bounds[n + 1]
                     nxt = up.submit([Tn[j0:j1], Sn[j0:j1]])
                 main.wait_event(ready)
-                res = core.stratification(Td, Sd, p[i0:i1] if p_rows else p, z, **kw)
+                res = core.stratification(Td.reshape(i1 - i0, nz, plane), Sd.reshape(i1 - i0, nz, plane),
+                                          p[i0:i1] if p_rows else p, z, **kw)
                 results.submit([(out[i0:i1], res)])
     finally:
         up.close()

@@ -54,6 +54,16 @@ def test_calc_rho(goldens):
                                             dset1.z_l.values * 1.0e4))
 
 
+def test_calc_rho_on_a_lazy_field():
+    """a field that can only be read by slicing (dask / netCDF4 / h5py-like) is read and evaluated"""
+    from lazy_array import CountingLazy
+
+    lazy = DataArray(CountingLazy(dset1.thetao.values), dset1.thetao.dims, dict(dset1.thetao.coords))
+    rho = derived.calc_rho(lazy, dset1.so, dset1.z_l * 1.0e4)
+    assert_bit_equal(rho.values, o.calc_rho(dset1.thetao.values, dset1.so.values,
+                                            dset1.z_l.values * 1.0e4))
+
+
 def test_calc_rho_held_field_broadcast_order():
     """halosteric's call: thetao (z,y,x), so (t,z,y,x) -> dims in first-appearance order."""
     rho = derived.calc_rho(dset1.thetao.isel(time=0), dset1.so, dset1.z_l * 1.0e4)

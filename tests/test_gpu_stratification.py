@@ -162,6 +162,14 @@ def test_large_host_fields_are_pipelined(monkeypatch):
         n2 = derived.calc_n2(DataArray(T, dims, coords), DataArray(S, dims, coords))
         assert [u[0] for u in used] == [2, 2, 1] and isinstance(n2.data, np.ndarray)
         assert_bit_equal(n2.values, o.calc_n2(T, S, z))
+    # a lazy field (dask / netCDF4-like: readable by slicing only) is read group by group
+    from lazy_array import CountingLazy
+
+    T, S = _fields(shape, np.float32, 23)
+    lazy = CountingLazy(T)
+    n2 = derived.calc_n2(DataArray(lazy, dims, coords), DataArray(S, dims, coords))
+    assert lazy.reads and lazy.largest_read == 2 * T[0].nbytes  # never more than one group
+    assert_bit_equal(n2.values, o.calc_n2(T, S, z))
     T, S = _fields(shape, np.float64, 22)
     p4 = np.random.default_rng(4).uniform(1e5, 5e7, shape)
     tu = derived.calc_stability_angle(DataArray(T, dims, coords), DataArray(S, dims, coords),
