@@ -47,10 +47,12 @@ def _broadcast_dims(*arrays):
 def _expand_to(da, dims, sizes):
     """Raw data of ``da`` reshaped/transposed so it broadcasts against ``dims``."""
     data = da.data
-    if da.is_lazy:  # (a dask / netCDF4-like field: read here; the pointwise maps take arrays)
-        data = np.asarray(data)
     order = [d for d in dims if d in da.dims]
     perm = [da.dims.index(d) for d in order]
+    if da.is_lazy:  # a dask / netCDF4-like field
+        if tuple(da.dims) == tuple(dims):
+            return data  # already laid out like the result: read piece by piece (eos/_dispatch.py)
+        data = np.asarray(data)
     if perm != list(range(len(perm))):
         data = data.permute(*perm) if isinstance(data, torch.Tensor) else data.transpose(perm)
     shape = [sizes[d] if d in da.dims else 1 for d in dims]

@@ -29,6 +29,17 @@ def _as_tensor(x, device):
     return hostio.to_device(a, device)  # through our own page-locked staging
 
 
+def _is_lazy(x):
+    """array-shaped, readable only by slicing (dask / netCDF4 / h5py-like): never np.asarray'ed
+    whole here -- the piecewise evaluation reads it piece by piece"""
+    return (not isinstance(x, (np.ndarray, np.generic, torch.Tensor, list, tuple, bool, int, float))
+            and all(hasattr(x, a) for a in ("shape", "dtype", "__getitem__")))
+
+
+def _shape(x):
+    return tuple(x.shape) if _is_lazy(x) else np.shape(x)
+
+
 def _is_weak(x):
     """A python float / int: numpy (>= 2, NEP 50) lets it take the dtype of the arrays it meets.
     numpy scalars (np.float32(1.0), np.float64(1.0)) are NOT weak: they count as arrays."""
@@ -47,7 +58,7 @@ def _kind(x):
         return None
     if _is_weak(x):
         return "weak"
-    dt = x.dtype if isinstance(x, torch.Tensor) else np.asarray(x).dtype
+    dt = x.dtype if isinstance(x, torch.Tensor) or _is_lazy(x) else np.asarray(x).dtype
     name = str(dt).replace("torch.", "")
     if name in ("float16", "bfloat16", "half"):
         raise TypeError(f"{name} operands are not supported: numpy evaluates their part of the "
@@ -79,17 +90,18 @@ def _evaluate_host_chunked(eos, func, T, S, p, gravity):
     k-1's result leaves on another (hostio.Downloader): both directions of the host link are busy
     at once, and the device never holds more than a few pieces (the result is a host array
     anyway)."""
-    arrs = [x if _is_weak(x) else np.asarray(x) for x in (T, S, p if p is not None else 0.0)]
-    shape = np.broadcast_shapes(*(np.shape(a) for a in arrs))
+    arrs = [x if (_is_weak(x) or _is_lazy(x)) else np.asarray(x)
+            for x in (T, S, p if p is not None else 0.0)]
+    shape = np.broadcast_shapes(*(_shape(a) for a in arrs))
     rows = max(1, _HOST_CHUNK_ELEMS // max(1, int(np.prod(shape[1:]))))
     bounds = [(i0, min(i0 + rows, shape[0])) for i0 in range(0, shape[0], rows)]
     device = torch.device("cuda", torch.cuda.current_device())
     main = torch.cuda.current_stream(device)
 
     def part(a, i0, i1):  # slice the leading axis unless the operand broadcasts along it
-        if np.ndim(a) == len(shape) and a.shape[0] == shape[0] and shape[0] > 1:
-            return a[i0:i1]
-        return a
+        if len(_shape(a)) == len(shape) and a.shape[0] == shape[0] and shape[0] > 1:
+            return a[i0:i1]  # (a lazy operand is READ here, piece by piece, in the upload worker's turn)
+        return np.asarray(a) if _is_lazy(a) else a
 
     def pieces(i0, i1):  # (operands of the piece, which of them travel)
         ops = [part(arrs[0], i0, i1), part(arrs[1], i0, i1), None if p is None else part(arrs[2], i0, i1)]
@@ -151,9 +163,10 @@ def evaluate(eos, func, T, S, p, gravity=None):
     """f(T, S, p) with numpy broadcasting; returns the kind of array it was given."""
     core.require_device()
     if not any(isinstance(x, torch.Tensor) for x in (T, S, p)):
-        shape = np.broadcast_shapes(*(np.shape(x) for x in (T, S, p) if x is not None))
+        shape = np.broadcast_shapes(*(_shape(x) for x in (T, S, p) if x is not None))
         if len(shape) >= 1 and int(np.prod(shape)) > _HOST_PIPELINE_ELEMS and shape[0] > 1:
             return _evaluate_host_chunked(eos, func, T, S, p, gravity)
+        T, S, p = (np.asarray(x) if _is_lazy(x) else x for x in (T, S, p))
     on_device = any(isinstance(x, torch.Tensor) and x.is_cuda for x in (T, S, p))
     scalar_in = all(np.ndim(x) == 0 and not isinstance(x, torch.Tensor) for x in (T, S, p))
     device = next(
