@@ -304,6 +304,8 @@ def _enqueue_download(out, dev, stream, ring, pending):
     # that produced `dev`, and the piecewise copies below must not overtake the packing kernel)
     with torch.cuda.stream(stream):
         src = dev.contiguous()
+        if src is not dev:  # the packing kernel reads `dev` on `stream`: its memory must not go
+            dev.record_stream(stream)  # back to its own stream's allocator before that ran
     hb, db = _bytes_view(host), _bytes_view(src)
     _log_range("download destination (pageable: written by host memcpy only)", host.data_ptr(),
                nbytes)
