@@ -328,12 +328,12 @@ def _stratification_host_rows(T, S, p, z, nt, nz, plane, dev, lead=None, **kw):
     up = hostio.Uploader(dev)
     try:
         with hostio.Downloader(dev) as results:
-            nxt = up.submit([Tn[bounds[0][0]:bounds[0][1]], Sn[bounds[0][0]:bounds[0][1]]])
+            nxt = up.submit([hostio.leading_slice(Tn, *bounds[0]), hostio.leading_slice(Sn, *bounds[0])])
             for n, (i0, i1) in enumerate(bounds):
                 (Td, Sd), ready = nxt.result()  # (re-raises what the worker raised)
                 if n + 1 < len(bounds):
                     j0, j1 = bounds[n + 1]
-                    nxt = up.submit([Tn[j0:j1], Sn[j0:j1]])
+                    nxt = up.submit([hostio.leading_slice(Tn, j0, j1), hostio.leading_slice(Sn, j0, j1)])
                 main.wait_event(ready)
                 res = core.stratification(Td.reshape(i1 - i0, nz, plane), Sd.reshape(i1 - i0, nz, plane),
                                           p[i0:i1] if p_rows else p, z, **kw)

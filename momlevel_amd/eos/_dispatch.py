@@ -100,7 +100,7 @@ def _evaluate_host_chunked(eos, func, T, S, p, gravity):
 
     def part(a, i0, i1):  # slice the leading axis unless the operand broadcasts along it
         if len(_shape(a)) == len(shape) and a.shape[0] == shape[0] and shape[0] > 1:
-            return a[i0:i1]  # (a lazy operand is READ here, piece by piece, in the upload worker's turn)
+            return hostio.leading_slice(a, i0, i1)  # (a lazy operand is READ piece by piece, by the upload worker)
         return np.asarray(a) if _is_lazy(a) else a
 
     def pieces(i0, i1):  # (operands of the piece, which of them travel)

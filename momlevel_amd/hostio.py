@@ -413,6 +413,25 @@ class Downloader:
         return False
 
 
+class _DeferredSlice:
+    """``a[i0:i1]`` of an array that is READ by slicing (dask / netCDF4 / h5py-like), not taken
+    yet: the read happens where the value is needed -- in the Uploader's worker thread."""
+
+    def __init__(self, a, i0, i1):
+        self.a, self.i0, self.i1 = a, i0, i1
+        self.dtype = a.dtype
+        self.shape = (i1 - i0,) + tuple(a.shape[1:])
+
+    def __array__(self, dtype=None, copy=None):
+        out = np.asarray(self.a[self.i0:self.i1])
+        return out if dtype is None else out.astype(dtype, copy=False)
+
+
+def leading_slice(a, i0, i1):
+    """``a[i0:i1]`` for the Uploader: a view of a numpy array, a deferred read of anything else."""
+    return a[i0:i1] if isinstance(a, np.ndarray) else _DeferredSlice(a, i0, i1)
+
+
 class Uploader:
     """Host arrays -> fresh device tensors on a worker thread with a stream and a staging ring of
     its own (what engine.TimeChunks does for theta/S, for callers that chunk something else):
