@@ -59,6 +59,34 @@ def test_reference_goldens(goldens):
     assert_bit_equal(one.values, o.calc_wave_speed(ref[0], dz_ref))
 
 
+BLK_Z = np.cumsum(2.0 * 1.075 ** np.arange(7)) * 40.0  # the levels behind wright_vectors' blk_p
+
+
+@pytest.mark.parametrize("prec", ["blk", "f32"])
+def test_n2_from_the_reference_modules_own_alpha_and_beta(wright_vectors, prec):
+    """derived.py:396-401 evaluated with alpha and beta AS THE REFERENCE'S eos/wright.py RETURNED
+    THEM (tests/golden/wright_vectors.npz: outputs of the reference module on these fields at
+    p = z_l * 1e4 + 101325) and numpy.gradient: calc_n2 must give those bits -- float64 fields and
+    float32 fields (numpy's mixed precision: float64 alpha / beta, float32 derivatives)."""
+    v = wright_vectors
+    T, S = v[f"{prec}_T"], v[f"{prec}_S"]
+    assert np.array_equal(v["blk_p"].reshape(-1), BLK_Z * 1.0e4 + 101325.0)
+    dtdz = np.gradient(T, BLK_Z, axis=1, edge_order=2)
+    dsdz = np.gradient(S, BLK_Z, axis=1, edge_order=2)
+    assert dtdz.dtype == T.dtype
+    want = -9.8 * ((v[f"{prec}_alpha"] * dtdz) - (v[f"{prec}_beta"] * dsdz))
+    dims = ("time", "z_l", "yh", "xh")
+    coords = {"z_l": DataArray(BLK_Z, ("z_l",))}
+    got = derived.calc_n2(DataArray(T, dims, coords), DataArray(S, dims, coords))
+    assert_bit_equal(got.values, want, "calc_n2 vs the reference module's alpha / beta")
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = (v[f"{prec}_beta"] * dsdz) / (v[f"{prec}_alpha"] * dtdz)
+        tu_want = np.degrees(np.arctan((1 + r) / (1 - r)))
+    tu = derived.calc_stability_angle(DataArray(T, dims, coords), DataArray(S, dims, coords),
+                                      DataArray(v["blk_p"].reshape(-1), ("z_l",)))
+    assert np.nanmax(np.abs(tu.values - tu_want)) <= 90.0 * 1e-12
+
+
 def _fields(shape, dtype, seed, land=True):
     r = np.random.default_rng(seed)
     T = r.uniform(-2.0, 30.0, shape).astype(dtype)
