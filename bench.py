@@ -596,7 +596,7 @@ def stratification_timings(T, S, g, steps, B1):
          "frac_of_8TBs": round(bpc * cells / ms / 1e6 / HBM_PEAK_GBS, 4)}
     r["steps"] = steps
     r["kernel"] = ("k_stratification<double, 2, kF64, kWright, MLX_STRAT_N2>" if B1 == 8 else
-                   "k_stratification<float, 4, kF32Faithful, kWright, MLX_STRAT_N2>")
+                   "k_stratification<float, 2, kF32Faithful, kWright, MLX_STRAT_N2>")
     band = min(ny, 96)  # whole columns (the derivative runs along z) of `band` rows of one step
     t = steps // 2
     got = res["n2"][t].reshape(nz, ny, nx)[:, :band].cpu().numpy()

@@ -9,8 +9,8 @@
 // The reference evaluates each as a chain of whole-array numpy passes: alpha (an EOS evaluation:
 // density AND its temperature derivative), beta (again), two numpy.gradient calls along z
 // (xarray's differentiate(edge_order=2)), four more arithmetic passes -- ~40 temporaries of the
-// field's size.  k_stratification does it in ONE pass: a thread owns V horizontally adjacent
-// columns of one time step (one 16-byte load per field and level), walks z with a three-level
+// field's size.  k_stratification does it in ONE pass: a thread owns V = 2 horizontally adjacent
+// columns of one time step, walks z with a three-level
 // window of theta / S in registers -- numpy.gradient's stencil -- and evaluates alpha, beta at the
 // centre level with the operator-for-operator device functions of eos_device.hpp.  16 B read +
 // 8 B written per cell at float64 (8 + 8 at float32): the traffic of K0, three times its
@@ -63,6 +63,10 @@ __device__ __forceinline__ Pack<TIn, V> load_pack(const TIn* ptr) {
     typedef __attribute__((ext_vector_type(4))) unsigned int u4;
     const u4 raw = __builtin_nontemporal_load(reinterpret_cast<const u4*>(ptr));
     __builtin_memcpy(r.v, &raw, 16);
+  } else if constexpr (V * sizeof(TIn) == 8 && V > 1) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+    const u2 raw = __builtin_nontemporal_load(reinterpret_cast<const u2*>(ptr));
+    __builtin_memcpy(r.v, &raw, 8);
   } else {
 #pragma unroll
     for (int i = 0; i < V; ++i) r.v[i] = ptr[i];
@@ -324,18 +328,29 @@ extern "C" int mlx_stratification(const void* T, const void* S, int dtype, const
   StratArgs g{T, S, p, p_stride_t, p_stride_z, p_stride_cell, eos, func, coef, uniform, two_dx,
               gravity, nz, plane, out};
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int V = f64 ? 2 : 4;
+#ifndef MLX_TUNE_STRAT_V64
+#define MLX_TUNE_STRAT_V64 2
+#endif
+#ifndef MLX_TUNE_STRAT_V32
+#define MLX_TUNE_STRAT_V32 2
+#endif
+  // cells per thread: two of either type (same-box A/B, scripts/ab_n2.py: four float32 cells per
+  // thread -- one 16-byte load -- cost a wave of occupancy at 116 VGPRs and 11 %: 7.93 vs 7.04-7.17 ms;
+  // one float64 cell per thread loses 12 %: 8.87 vs 9.94-10.0 ms).  Issue-bound: the load width does
+  // not matter, the registers do
+  constexpr int V64 = MLX_TUNE_STRAT_V64, V32 = MLX_TUNE_STRAT_V32;
+  const int V = f64 ? V64 : V32;
   const bool wide = plane % V == 0 && reinterpret_cast<uintptr_t>(T) % 16 == 0 &&
                     reinterpret_cast<uintptr_t>(S) % 16 == 0 &&
                     reinterpret_cast<uintptr_t>(out) % 16 == 0;
   if (dtype == MLX_DTYPE_F64) {
-    if (wide) launch<double, 2, kF64>(g, nt, st);
+    if (wide) launch<double, V64, kF64>(g, nt, st);
     else launch<double, 1, kF64>(g, nt, st);
   } else if (dtype == MLX_DTYPE_F32) {
-    if (wide) launch<float, 4, kF32Faithful>(g, nt, st);
+    if (wide) launch<float, V32, kF32Faithful>(g, nt, st);
     else launch<float, 1, kF32Faithful>(g, nt, st);
   } else {
-    if (wide) launch<float, 4, kF32Upcast>(g, nt, st);
+    if (wide) launch<float, V32, kF32Upcast>(g, nt, st);
     else launch<float, 1, kF32Upcast>(g, nt, st);
   }
   return detail::hip_status(hipGetLastError(), "mlx_stratification launch");
