@@ -358,3 +358,22 @@ def test_operand_kinds_follow_numpys_promotion():
         assert got.dtype == want.dtype == np.float64 and np.array_equal(got, want)
     with pytest.raises(TypeError, match="float16"):
         _dispatch._kind(np.array([10.0], np.float16))
+
+
+def test_deferred_slices_read_only_when_converted():
+    """hostio.leading_slice: a numpy array is sliced as a view at once; anything that is READ by
+    slicing (dask / netCDF4 / h5py-like) is wrapped and read where np.asarray is called on it --
+    in the pipelined host paths that is the upload worker's thread"""
+    from lazy_array import CountingLazy
+    from momlevel_amd import hostio
+
+    a = np.arange(24.0).reshape(4, 3, 2)
+    v = hostio.leading_slice(a, 1, 3)
+    assert isinstance(v, np.ndarray) and np.shares_memory(v, a)
+    lazy = CountingLazy(a.astype(np.float32))
+    d = hostio.leading_slice(lazy, 1, 3)
+    assert not isinstance(d, np.ndarray) and d.shape == (2, 3, 2) and d.dtype == np.float32
+    assert lazy.reads == []  # nothing read yet
+    got = np.ascontiguousarray(d)
+    assert lazy.reads == [2 * 3 * 2 * 4] and np.array_equal(got, a[1:3].astype(np.float32))
+    assert np.asarray(d, dtype=np.float64).dtype == np.float64
