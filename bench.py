@@ -115,17 +115,30 @@ def measured_traffic(cells_per_launch):
 VALU_PEAK_LANE_INSTR_PER_S = 256 * 4 * 16 * 2.4e9
 
 
+def strat_source_sha():
+    """sha256 (16 hex digits) of csrc/momlevel_strat.hip (scripts/summarize_variants.py writes the same)"""
+    import hashlib
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "momlevel_amd", "csrc", "momlevel_strat.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def valu_profiles():
     """{bench key: VALU instructions per cell} from the round's committed SQ_INSTS_VALU passes
     (profiles/r04_*variants_summary.json, written by scripts/summarize_variants.py) -- quoted, like
     roofline.traffic, only while the sha of the kernel sources matches the profiled ones."""
     here = os.path.dirname(os.path.abspath(__file__))
     found, sources = {}, []
-    for name in ("r04_variants_summary.json", "r04_f32_variants_summary.json"):
+    for name in ("r04_variants_summary.json", "r04_f32_variants_summary.json",
+                 "r04_strat_variants_summary.json"):
         try:
             with open(os.path.join(here, "profiles", name)) as f:
                 summ = json.load(f)
-            if summ.get("kernel_source_sha") != kernel_source_sha():
+            if "strat" in name:  # the stratification kernels live in a source file of their own
+                if summ.get("strat_source_sha") != strat_source_sha():
+                    continue
+            elif summ.get("kernel_source_sha") != kernel_source_sha():
                 continue
             prefix = "config5_f32." if "f32" in name else ""
             for k in summ["kernels"]:

@@ -36,6 +36,15 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def strat_source_sha():
+    """sha256 (16 hex digits) of csrc/momlevel_strat.hip: the stratification kernels' own guard"""
+    import hashlib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "momlevel_amd", "csrc", "momlevel_strat.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def one(pattern):
     hits = sorted(glob.glob(pattern, recursive=True))
     return hits[0] if hits else None
@@ -71,6 +80,7 @@ def main(src, prefix):
         "grid": "{}x{}x{}, nt={} resident, {}".format(*plan["grid"], plan["nt"], plan["dtype"]),
         # bench.py quotes these instruction counts only while the kernel sources are the profiled ones
         "kernel_source_sha": kernel_source_sha(),
+        "strat_source_sha": strat_source_sha() if "k_stratification" in MAIN else None,
         "cells_per_launch": cells,
         "notes": __doc__.split("Expects")[1].strip().replace("\n", " "),
         "kernels": [],
