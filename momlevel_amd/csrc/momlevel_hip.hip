@@ -1119,29 +1119,45 @@ constexpr int kTChunkHeld = 64;      // held-field variants and the all-variants
                                      // 1-3.5 % faster (profiles/r02_tune_tchunk.log), steric is flat
 constexpr int kNTIGen = 8;           // generic scalar path
 
-// Time steps per thread of the single-variant fast K2 kernels, chosen PER INSTANTIATION (round 4):
-// (float64 fields: 2 columns per thread, float32: 4), variant, and whether delta_rho is stored.
-// More steps amortise rho0m / dz / the held field over more cells and keep more bytes in flight per
-// wave; fewer steps need fewer registers (column sums + loads in flight) and run more waves per SIMD.
+// Columns and time steps per thread of the single-variant fast K2 kernels, chosen PER INSTANTIATION
+// (round 4): by field type, variant, and whether delta_rho is stored.  More steps amortise rho0m /
+// dz / the held field over more cells and keep more bytes in flight per wave; fewer steps -- and
+// fewer columns -- need fewer registers (column sums + loads in flight) and run more waves per SIMD.
 // Never changes a result: every (time step, column) sum adds its levels in the same order.
-// Measured on one box, one process per library (scripts/ab_k2.py, profiles/r04_tune_k2_nti_*.log).
-// Tuning builds override the whole table: -DMLX_TUNE_NTI64=n / -DMLX_TUNE_NTI32=n.
+// Measured on one box, one process per library (scripts/ab_k2.py, profiles/r04_tune_k2_nti_*.log,
+// profiles/r04_tune_k2_f32_columns.log).  Tuning builds override the tables:
+// -DMLX_TUNE_NTI64=n / -DMLX_TUNE_NTI32=n / -DMLX_TUNE_K2_VEC32=n.
 #ifndef MLX_TUNE_NTI64
 #define MLX_TUNE_NTI64 0
 #endif
 #ifndef MLX_TUNE_NTI32
 #define MLX_TUNE_NTI32 0
 #endif
+#ifndef MLX_TUNE_K2_VEC32
+#define MLX_TUNE_K2_VEC32 0
+#endif
+// float32 fields: FOUR columns per thread (one 16-byte load per field, level and step) only for the
+// steric pass without delta_rho; every other pass runs TWO (8-byte loads): half the registers per
+// step buy twice the steps in flight at the same occupancy -- held-field passes 7-8 % faster without
+// delta_rho, 6-18 % with it, the steric pass with delta_rho 4-12 %; the steric eta-only pass, which
+// streams two fields per cell and stores next to nothing, is 3-5 % slower that way and stays at four.
+constexpr int k2_vec32(int var, bool drho) {
+  if (MLX_TUNE_K2_VEC32) return MLX_TUNE_K2_VEC32;
+  return (var == kVarSteric && !drho) ? 4 : 2;
+}
 constexpr int k2_nti(bool f64, int var, bool drho) {
   if (f64 && MLX_TUNE_NTI64) return MLX_TUNE_NTI64;
   if (!f64 && MLX_TUNE_NTI32) return MLX_TUNE_NTI32;
   // float64: 16 steps (8 and 12 measured 0-4 % slower) -- except the held-field passes WITHOUT
   // delta_rho, 6 % faster at 12: half the streamed bytes of the steric pass per cell, so the
   // occupancy (3 waves per SIMD instead of 2) weighs more than the amortisation.
-  // float32: 6 steps (3 waves per SIMD; 4 and 8 measured 3-10 % slower) -- except the held-field
-  // passes WITH delta_rho, 3-4 % faster at 8: two thirds of their traffic are the float64 stores.
+  // float32, four columns (steric, eta only): 6 steps (3 waves per SIMD; 4 and 8 measured 3-10 %
+  // slower).  float32, two columns: 12 steps for the held-field passes without delta_rho, 16 for
+  // everything that stores delta_rho (8 / 10 / 12 / 16 swept; two thirds and more of those passes'
+  // traffic are the float64 stores).
   if (f64) return (var != kVarSteric && !drho) ? 12 : 16;
-  return (var != kVarSteric && drho) ? 8 : 6;
+  if (var == kVarSteric && !drho) return 6;
+  return drho ? 16 : 12;
 }
 
 constexpr int kKnownFlags = MLX_FLAG_SKIP_DRY | MLX_FLAG_FMA | MLX_FLAG_TCHUNK_MASK;
@@ -1420,8 +1436,10 @@ void k2_flags(const K2Args& a, bool skip, bool fma) {
 template <typename TIn, int VEC, int VAR, int MODE>
 void k2_single(const K2Args& a, bool skip, bool fma) {
   constexpr bool F64 = sizeof(TIn) == 8;
-  if (a.drho != nullptr) k2_flags<TIn, VEC, k2_nti(F64, VAR, true), VAR, MODE, false>(a, skip, fma);
-  else k2_flags<TIn, VEC, k2_nti(F64, VAR, false), VAR, MODE, false>(a, skip, fma);
+  // (float32 fields: the columns per thread are the instantiation's too, k2_vec32)
+  constexpr int V1 = F64 ? VEC : k2_vec32(VAR, true), V0 = F64 ? VEC : k2_vec32(VAR, false);
+  if (a.drho != nullptr) k2_flags<TIn, V1, k2_nti(F64, VAR, true), VAR, MODE, false>(a, skip, fma);
+  else k2_flags<TIn, V0, k2_nti(F64, VAR, false), VAR, MODE, false>(a, skip, fma);
 }
 
 // NTI1: time steps per thread of the generic single-variant kernel (the fast ones: k2_nti);
@@ -1491,7 +1509,11 @@ int steric_local_impl(const void* T, const void* S, const void* T0, const void* 
   //  four columns of float64 polynomial need 254 VGPRs: 64.6 ms instead of 43 for the upcast pass
   //  at the roofline grid, no change for the fused one -- 8-byte loads stream worse than they save.
   //  Neither is a default path.)
-  const int v = !fast ? 1 : ((var == kVarAll && !f64) ? kVec32All : vec_of(dtype));
+  const bool f32_fields = dtype == MLX_DTYPE_F32 || dtype == MLX_DTYPE_F32_UPCAST;
+  const int v = !fast ? 1
+                : (var == kVarAll && !f64) ? kVec32All
+                : f32_fields ? k2_vec32(var, delta_rho_out != nullptr)
+                             : vec_of(dtype);
   const int nti = (var == kVarAll) ? (fast ? (f64 ? kNTI64All : kNTI32All) : kNTIGenAll)
                                    : (fast ? k2_nti(f64, var, delta_rho_out != nullptr) : kNTIGen);
   if (ceil_div(nt, nti) > 65535) return fail(MLX_E_SHAPE, "nt too large for one call: chunk it");
