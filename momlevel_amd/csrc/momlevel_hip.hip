@@ -1145,17 +1145,29 @@ constexpr int k2_vec32(int var, bool drho) {
   if (MLX_TUNE_K2_VEC32) return MLX_TUNE_K2_VEC32;
   return (var == kVarSteric && !drho) ? 4 : 2;
 }
+// float64 fields: two columns per thread (one 16-byte load per field, level and step) -- except the
+// held-field passes WITH delta_rho (what thermosteric(ds) / halosteric(ds) run by default), which
+// take ONE column and 32 steps: 3-13 % faster (16 / 24 / 32 / 40 / 48 steps swept; with one column
+// the eta-only and the steric passes are equal or slower).  Same trade as at float32.
+#ifndef MLX_TUNE_K2_VEC64
+#define MLX_TUNE_K2_VEC64 0
+#endif
+constexpr int k2_vec64(int var, bool drho) {
+  if (MLX_TUNE_K2_VEC64) return MLX_TUNE_K2_VEC64;
+  return (var != kVarSteric && drho) ? 1 : 2;
+}
 constexpr int k2_nti(bool f64, int var, bool drho) {
   if (f64 && MLX_TUNE_NTI64) return MLX_TUNE_NTI64;
   if (!f64 && MLX_TUNE_NTI32) return MLX_TUNE_NTI32;
-  // float64: 16 steps (8 and 12 measured 0-4 % slower) -- except the held-field passes WITHOUT
-  // delta_rho, 6 % faster at 12: half the streamed bytes of the steric pass per cell, so the
-  // occupancy (3 waves per SIMD instead of 2) weighs more than the amortisation.
+  // float64, two columns: 16 steps (8 and 12 measured 0-4 % slower) -- except the held-field passes
+  // WITHOUT delta_rho, 6 % faster at 12: half the streamed bytes of the steric pass per cell, so the
+  // occupancy (3 waves per SIMD instead of 2) weighs more than the amortisation.  float64, one
+  // column (held-field passes with delta_rho): 32 steps.
   // float32, four columns (steric, eta only): 6 steps (3 waves per SIMD; 4 and 8 measured 3-10 %
   // slower).  float32, two columns: 12 steps for the held-field passes without delta_rho, 16 for
   // everything that stores delta_rho (8 / 10 / 12 / 16 swept; two thirds and more of those passes'
   // traffic are the float64 stores).
-  if (f64) return (var != kVarSteric && !drho) ? 12 : 16;
+  if (f64) return (var == kVarSteric) ? 16 : (drho ? 32 : 12);
   if (var == kVarSteric && !drho) return 6;
   return drho ? 16 : 12;
 }
@@ -1436,8 +1448,10 @@ void k2_flags(const K2Args& a, bool skip, bool fma) {
 template <typename TIn, int VEC, int VAR, int MODE>
 void k2_single(const K2Args& a, bool skip, bool fma) {
   constexpr bool F64 = sizeof(TIn) == 8;
-  // (float32 fields: the columns per thread are the instantiation's too, k2_vec32)
-  constexpr int V1 = F64 ? VEC : k2_vec32(VAR, true), V0 = F64 ? VEC : k2_vec32(VAR, false);
+  // (the columns per thread are the instantiation's too: k2_vec32, k2_vec64; theta / S of different
+  // dtypes keep the two columns of their float64 shape)
+  constexpr int V1 = !F64 ? k2_vec32(VAR, true) : (MODE == kF64 ? k2_vec64(VAR, true) : VEC);
+  constexpr int V0 = !F64 ? k2_vec32(VAR, false) : (MODE == kF64 ? k2_vec64(VAR, false) : VEC);
   if (a.drho != nullptr) k2_flags<TIn, V1, k2_nti(F64, VAR, true), VAR, MODE, false>(a, skip, fma);
   else k2_flags<TIn, V0, k2_nti(F64, VAR, false), VAR, MODE, false>(a, skip, fma);
 }
@@ -1513,6 +1527,7 @@ int steric_local_impl(const void* T, const void* S, const void* T0, const void* 
   const int v = !fast ? 1
                 : (var == kVarAll && !f64) ? kVec32All
                 : f32_fields ? k2_vec32(var, delta_rho_out != nullptr)
+                : (dtype == MLX_DTYPE_F64 && var != kVarAll) ? k2_vec64(var, delta_rho_out != nullptr)
                              : vec_of(dtype);
   const int nti = (var == kVarAll) ? (fast ? (f64 ? kNTI64All : kNTI32All) : kNTIGenAll)
                                    : (fast ? k2_nti(f64, var, delta_rho_out != nullptr) : kNTIGen);
