@@ -773,8 +773,8 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
     # (few launches: ramp and tail paid less often) -- VERDICT r2 weak #5.
     free, _ = torch.cuda.mem_get_info(dev)
     big = int(min(nt, max(0, free - (6 << 30)) // (nz * ny * nx * 8)))
-    # whole time blocks of every K2 instantiation (12 or 16 steps per thread at float64)
-    big = big // 48 * 48 if big >= 48 else big // 16 * 16
+    # whole time blocks of every K2 instantiation (12, 16 or 32 steps per thread at float64)
+    big = big // 96 * 96 if big >= 96 else (big // 48 * 48 if big >= 48 else big // 16 * 16)
     if big >= 32:
         dbig = torch.empty((big, nz, ny, nx), dtype=torch.float64, device=dev)
         starts_b = range(0, nt - big + 1, big)
@@ -1038,8 +1038,9 @@ def f32_timings(vol0, pres, g, dev, nt, synth_kw):
     free, _ = torch.cuda.mem_get_info(dev)
     steps_d = int(min(nt, max(0, free - (6 << 30)) // (nz * ny * nx * 8)))
     if steps_d >= 6:
-        steps_d = steps_d // 24 * 24 if steps_d >= 24 else steps_d // 6 * 6  # whole time blocks
-        # of every float32 K2 instantiation (6 or 8 steps per thread)
+        # whole time blocks of the float32 K2 instantiations where the record allows (6, 12 or 16
+        # steps per thread: the full 120-step record ends on a half-filled block of the 16-step ones)
+        steps_d = steps_d // 24 * 24 if steps_d >= 24 else steps_d // 6 * 6
         dbuf = torch.empty((steps_d, nz, ny, nx), dtype=torch.float64, device=dev)
         out["default"].update(local_held_timings(
             T, S, rho0m, vol0, pres, zi, dep, eta, dbuf, range(0, nt - steps_d + 1, steps_d),
