@@ -16,7 +16,7 @@ import torch
 
 from . import core, engine, hostio, util
 from .adapters import accepts_xarray
-from .labeled import DataArray
+from .labeled import DataArray, is_lazy
 
 __all__ = [
     "adjust_negative_n2",
@@ -52,7 +52,7 @@ def _expand_to(da, dims, sizes):
     if da.is_lazy:  # a dask / netCDF4-like field
         if tuple(da.dims) == tuple(dims):
             return data  # already laid out like the result: read piece by piece (eos/_dispatch.py)
-        data = np.asarray(data)
+        data = da.values  # (reads all of it; masked elements of a netCDF4 read become NaN)
     if perm != list(range(len(perm))):
         data = data.permute(*perm) if isinstance(data, torch.Tensor) else data.transpose(perm)
     shape = [sizes[d] if d in da.dims else 1 for d in dims]
@@ -318,8 +318,8 @@ def _stratification_host_rows(T, S, p, z, nt, nz, plane, dev, lead=None, **kw):
     if lead is not None:
         Tn, Sn = T, S  # sliced along their own leading axis
     else:
-        Tn = np.asarray(T).reshape(nt, nz, plane)
-        Sn = np.asarray(S).reshape(nt, nz, plane)
+        Tn = hostio.as_plain(T[...] if is_lazy(T) else T).reshape(nt, nz, plane)
+        Sn = hostio.as_plain(S[...] if is_lazy(S) else S).reshape(nt, nz, plane)
     rows = max(1, _HOST_GROUP_ELEMS // (nz * plane))
     bounds = [(i0, min(i0 + rows, nt)) for i0 in range(0, nt, rows)]
     p_rows = isinstance(p, torch.Tensor) and p.dim() == 3  # a pressure that varies from row to row

@@ -55,7 +55,7 @@ def chunk_steps(nt, bytes_per_step, device, budget_bytes=None):
 
 def _host_tensor(a, dtype=None):
     """numpy array (or view) -> CPU torch tensor sharing its memory when it can."""
-    a = np.asarray(a)
+    a = hostio.as_plain(a)  # (a masked array -- a netCDF4 slice -- means NaN where masked)
     if dtype is not None and a.dtype != dtype:
         a = a.astype(dtype)
     if a.dtype.byteorder not in ("=", "|"):
@@ -71,8 +71,9 @@ class TimeChunks:
     """Iterate a (nt, nz, ny, nx) field pair in device-resident time chunks.
 
     Device-resident fields are sliced (no copy).  Lazy fields (dask / netCDF4 / h5py / zarr
-    arrays, anything sliceable that is not numpy) are READ chunk by chunk -- ``np.asarray(f[t0:t1])``
-    -- so the host never holds more than the chunks in flight.  Host (numpy) fields are copied
+    arrays, anything sliceable that is not numpy) are READ chunk by chunk -- ``as_plain(f[t0:t1])``:
+    masked elements of a netCDF4 slice become NaN, as in the xarray objects the reference sees --
+    so the host never holds more than the chunks in flight.  Host (numpy) fields are copied
     chunk by chunk into a fresh device tensor through hostio's page-locked staging ring, on a
     copy stream: the host fills one staging buffer while the DMA engine drains another, chunk
     k+1 uploads while chunk k's kernels run and its results download on a third stream.  The

@@ -23,7 +23,7 @@ def _as_tensor(x, device):
     if isinstance(x, torch.Tensor):
         x = x.to(device)
         return x if x.dtype in (torch.float32, torch.float64) else x.double()  # ints: see _kind
-    a = np.asarray(x)
+    a = hostio.as_plain(x)
     if a.dtype not in (np.float32, np.float64):
         a = a.astype(np.float64)
     return hostio.to_device(a, device)  # through our own page-locked staging
@@ -58,7 +58,7 @@ def _kind(x):
         return None
     if _is_weak(x):
         return "weak"
-    dt = x.dtype if isinstance(x, torch.Tensor) or _is_lazy(x) else np.asarray(x).dtype
+    dt = x.dtype if isinstance(x, torch.Tensor) or _is_lazy(x) else hostio.as_plain(x).dtype
     name = str(dt).replace("torch.", "")
     if name in ("float16", "bfloat16", "half"):
         raise TypeError(f"{name} operands are not supported: numpy evaluates their part of the "
@@ -101,7 +101,7 @@ def _evaluate_host_chunked(eos, func, T, S, p, gravity):
     def part(a, i0, i1):  # slice the leading axis unless the operand broadcasts along it
         if len(_shape(a)) == len(shape) and a.shape[0] == shape[0] and shape[0] > 1:
             return hostio.leading_slice(a, i0, i1)  # (a lazy operand is READ piece by piece, by the upload worker)
-        return np.asarray(a) if _is_lazy(a) else a
+        return hostio.as_plain(a[...]) if _is_lazy(a) else a
 
     def pieces(i0, i1):  # (operands of the piece, which of them travel)
         ops = [part(arrs[0], i0, i1), part(arrs[1], i0, i1), None if p is None else part(arrs[2], i0, i1)]
@@ -162,11 +162,14 @@ def _evaluate_promoted(eos, func, T, S, p, gravity, device, on_device, scalar_in
 def evaluate(eos, func, T, S, p, gravity=None):
     """f(T, S, p) with numpy broadcasting; returns the kind of array it was given."""
     core.require_device()
+    # a numpy masked array (a netCDF4 read) means NaN where it is masked -- what the reference's
+    # functions are handed once xarray has wrapped it (derived.py:597-639 via apply_ufunc)
+    T, S, p = (hostio.as_plain(x) if isinstance(x, np.ma.MaskedArray) else x for x in (T, S, p))
     if not any(isinstance(x, torch.Tensor) for x in (T, S, p)):
         shape = np.broadcast_shapes(*(_shape(x) for x in (T, S, p) if x is not None))
         if len(shape) >= 1 and int(np.prod(shape)) > _HOST_PIPELINE_ELEMS and shape[0] > 1:
             return _evaluate_host_chunked(eos, func, T, S, p, gravity)
-        T, S, p = (np.asarray(x) if _is_lazy(x) else x for x in (T, S, p))
+        T, S, p = (hostio.as_plain(x[...]) if _is_lazy(x) else x for x in (T, S, p))
     on_device = any(isinstance(x, torch.Tensor) and x.is_cuda for x in (T, S, p))
     scalar_in = all(np.ndim(x) == 0 and not isinstance(x, torch.Tensor) for x in (T, S, p))
     device = next(

@@ -28,6 +28,8 @@ import threading
 import numpy as np
 import torch
 
+from .labeled import as_plain  # numpy masked arrays MEAN NaN (what xarray hands the reference)
+
 _MIB = 1 << 20
 PIECE_BYTES = int(os.environ.get("MOMLEVEL_AMD_STAGING_PIECE_MIB", "64")) * _MIB
 RING_DEPTH = 3
@@ -231,7 +233,7 @@ def to_device(x, device, dtype=None):
             return t if dtype is None or t.dtype == dtype else t.to(dtype)
         host = x.contiguous()
     else:
-        a = np.asarray(x)
+        a = as_plain(x)
         if a.dtype.byteorder not in ("=", "|"):
             a = a.astype(a.dtype.newbyteorder("="))
         if not a.flags["C_CONTIGUOUS"]:
@@ -423,13 +425,15 @@ class _DeferredSlice:
         self.shape = (i1 - i0,) + tuple(a.shape[1:])
 
     def __array__(self, dtype=None, copy=None):
-        out = np.asarray(self.a[self.i0:self.i1])
+        out = as_plain(self.a[self.i0:self.i1])  # (netCDF4 slices are masked arrays)
         return out if dtype is None else out.astype(dtype, copy=False)
 
 
 def leading_slice(a, i0, i1):
     """``a[i0:i1]`` for the Uploader: a view of a numpy array, a deferred read of anything else."""
-    return a[i0:i1] if isinstance(a, np.ndarray) else _DeferredSlice(a, i0, i1)
+    if isinstance(a, np.ndarray) and not isinstance(a, np.ma.MaskedArray):
+        return a[i0:i1]
+    return _DeferredSlice(a, i0, i1)  # (a masked array is NaN-filled slice by slice, by the worker)
 
 
 class Uploader:
@@ -465,7 +469,7 @@ class Uploader:
         out = []
         with torch.cuda.device(self.device):
             for a in arrays:
-                a = np.ascontiguousarray(a)
+                a = np.ascontiguousarray(as_plain(a))
                 if a.dtype not in (np.float32, np.float64):
                     a = a.astype(np.float64)
                 with warnings.catch_warnings():  # read-only views are only read
@@ -490,7 +494,7 @@ class Uploader:
 def to_host(t):
     """Device tensor -> numpy array (through the staging ring when not small; synchronises)."""
     if not (isinstance(t, torch.Tensor) and t.is_cuda):
-        return t.detach().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+        return t.detach().numpy() if isinstance(t, torch.Tensor) else as_plain(t)
     t = t.detach()
     if t.dtype not in (torch.float32, torch.float64) or t.numel() * t.element_size() < SMALL_BYTES:
         return t.cpu().numpy()

@@ -36,14 +36,48 @@ def is_lazy(x):
     return all(hasattr(x, a) for a in ("shape", "dtype", "__getitem__"))
 
 
+def as_plain(a):
+    """What ``xr.DataArray(a)`` holds for a host array ``a`` -- the container every input of the
+    reference arrives in (steric.py:84-96; examples/example.ipynb cell 4).  A ``numpy.ma``
+    masked array -- what ``netCDF4.Variable.__getitem__`` returns wherever a ``_FillValue`` /
+    ``missing_value`` is declared, for the whole variable and for every slice of it -- MEANS NaN at
+    its masked elements: xarray's ``as_compatible_data`` replaces them (``where(~mask, NaN)``) after
+    promoting the dtype so that it can hold one (floating dtypes keep theirs; integers of up to 16
+    bits become float32, wider ones float64 -- ``dtypes.maybe_promote``; a masked array with nothing
+    masked keeps its dtype).  ``np.asarray`` would instead DROP the mask and leave the fill values
+    (1e20 ...) to be computed on.  Anything else goes through ``np.asarray`` untouched: no copy of a
+    plain array, and an unmasked masked array gives a view of its data.  (A dask array is computed
+    first: its chunks may be masked arrays too, and its own ``__array__`` would drop their masks.)"""
+    if not isinstance(a, np.ndarray) and callable(getattr(a, "compute", None)):
+        a = a.compute()
+    if not isinstance(a, np.ma.MaskedArray):
+        return np.asarray(a)
+    mask = np.ma.getmask(a)
+    data = np.ma.getdata(a)
+    if mask is np.ma.nomask or not mask.any():
+        return np.asarray(data)
+    kind = data.dtype.kind
+    if kind == "f":
+        dtype = data.dtype
+    elif kind in "iu":
+        dtype = np.dtype(np.float32 if data.dtype.itemsize <= 2 else np.float64)
+    else:
+        raise TypeError(f"a masked array of dtype {data.dtype} has no NaN to stand for its masked "
+                        "elements (xarray would make it an object array); convert it to a "
+                        "floating dtype first")
+    out = np.array(data, dtype=dtype, order="C")  # a copy: the caller's array is never written
+    out[np.broadcast_to(mask, out.shape)] = np.nan
+    return out
+
+
 def _to_numpy(x):
     if _is_tensor(x):
         from . import hostio
 
         return hostio.to_host(x)
     if is_lazy(x):
-        return np.asarray(x[...])  # reads all of it
-    return np.asarray(x)
+        return as_plain(x[...])  # reads all of it
+    return as_plain(x)
 
 
 class LazyTranspose:
@@ -65,7 +99,7 @@ class LazyTranspose:
         base_key = [slice(None)] * self.ndim
         for view_axis, k in enumerate(key):
             base_key[self.perm[view_axis]] = k
-        block = np.asarray(self.base[tuple(base_key)])
+        block = as_plain(self.base[tuple(base_key)])
         kept = [ax for ax, k in enumerate(key) if not isinstance(k, (int, np.integer))]
         order = sorted(range(len(kept)), key=lambda i: self.perm[kept[i]])  # base order of kept axes
         inv = [order.index(i) for i in range(len(kept))]
@@ -88,7 +122,7 @@ class DataArray:
             attrs = data.attrs if attrs is None else attrs
             data = data.data
         if not _is_tensor(data) and not is_lazy(data):
-            data = np.asarray(data)
+            data = as_plain(data)  # (a numpy masked array becomes NaN-filled here, once)
         ndim = len(data.shape)
         if dims is None:
             dims = tuple(f"dim_{i}" for i in range(ndim))
@@ -179,7 +213,7 @@ class DataArray:
         dims = tuple(d for d, k in zip(self.dims, key) if not isinstance(k, (int, np.integer)))
         data = self.data[key]
         if is_lazy(data) and len(dims) < self.ndim:
-            data = np.asarray(data)  # a slab picked out of a lazy field (the reference state)
+            data = _to_numpy(data)  # a slab picked out of a lazy field (the reference state)
         out = self._like(data, dims, keep_attrs=True)
         for d, k in zip(self.dims, key):
             if d in out.coords and not isinstance(k, (int, np.integer)):
@@ -199,7 +233,7 @@ class DataArray:
         keep = [i for i, n in enumerate(self.shape) if n != 1]
         if len(keep) == self.ndim:
             return self
-        data = self.data if not is_lazy(self.data) else np.asarray(self.data)
+        data = self.data if not is_lazy(self.data) else _to_numpy(self.data)
         data = data.reshape([self.shape[i] for i in keep])
         return self._like(data, tuple(self.dims[i] for i in keep), keep_attrs=True)
 

@@ -22,3 +22,24 @@ class CountingLazy:
     @property
     def largest_read(self):
         return max(self.reads) if self.reads else 0
+
+
+FILL = 1e20  # netCDF's customary _FillValue of float fields
+
+
+def as_masked(array, fill=FILL):
+    """The ``numpy.ma.MaskedArray`` a netCDF4 read of ``array`` gives when its NaNs are stored as
+    ``_FillValue``: the data hold ``fill`` where the mask is set (never NaN)."""
+    array = np.asarray(array)
+    mask = np.isnan(array)
+    return np.ma.masked_array(np.where(mask, array.dtype.type(fill), array), mask=mask)
+
+
+class MaskedLazy(CountingLazy):
+    """``netCDF4.Variable``-like: every slice comes back as a masked array holding the fill value
+    where the file has ``_FillValue`` (``set_auto_mask(True)``, netCDF4's default)."""
+
+    def __getitem__(self, key):
+        block = self._a[key]
+        self.reads.append(int(np.asarray(block).nbytes))
+        return as_masked(block)

@@ -81,6 +81,45 @@ def test_calc_rho_on_a_lazy_field(monkeypatch):
     assert_bit_equal(rho.values, o.calc_rho(dset1.so.values, dset1.thetao.values, dset1.z_l.values * 1.0e4))
 
 
+def test_calc_rho_on_masked_arrays(monkeypatch):
+    """numpy masked arrays (a netCDF4 read: 1e20 under the mask) mean NaN -- xarray has filled them
+    before the reference's calc_rho (derived.py:597-639) sees anything: in memory, as the slices of
+    a lazy field (small: read whole; large: piece by piece in the upload worker), as a field that
+    must be transposed, and handed straight to the numpy-level EOS function."""
+    from lazy_array import MaskedLazy, as_masked
+    from momlevel_amd.eos import _dispatch, wright
+
+    T = dset1.thetao.values.copy()
+    S = dset1.so.values.copy()
+    T[:, 2, 1, :] = np.nan
+    S[:, 2, 1, :] = np.nan
+    T[3, :, :, 4] = np.nan
+    p = dset1.z_l.values * 1.0e4
+    ref = o.calc_rho(T, S, p)
+    assert np.isnan(ref).sum() == np.isnan(T).sum()
+    dims, coords = dset1.thetao.dims, dict(dset1.thetao.coords)
+    pres = dset1.z_l * 1.0e4
+    rho = derived.calc_rho(DataArray(as_masked(T), dims, coords), DataArray(as_masked(S), dims, coords), pres)
+    assert_bit_equal(rho.values, ref)
+    rho = derived.calc_rho(DataArray(MaskedLazy(T), dims, coords), DataArray(as_masked(S), dims, coords), pres)
+    assert_bit_equal(rho.values, ref)
+    got = wright.density(as_masked(T), as_masked(S), p[:, None, None])
+    assert type(got) is np.ndarray
+    assert_bit_equal(got, ref)
+    f32 = wright.density(as_masked(T.astype(np.float32)), as_masked(S.astype(np.float32)), p[:, None, None])
+    assert_bit_equal(f32, o.calc_rho(T.astype(np.float32), S.astype(np.float32), p))
+    monkeypatch.setattr(_dispatch, "_HOST_PIPELINE_ELEMS", 100)
+    monkeypatch.setattr(_dispatch, "_HOST_CHUNK_ELEMS", 2 * 125)  # two time steps a piece
+    lazy = MaskedLazy(T)
+    rho = derived.calc_rho(DataArray(lazy, dims, coords), DataArray(as_masked(S), dims, coords), pres)
+    assert_bit_equal(rho.values, ref)
+    assert lazy.largest_read == 2 * 125 * 8
+    tl = np.ascontiguousarray(np.moveaxis(T, 0, -1))
+    rho = derived.calc_rho(DataArray(as_masked(S), dims, coords),
+                           DataArray(MaskedLazy(tl), ("z_l", "yh", "xh", "time")), pres)
+    assert_bit_equal(rho.values, o.calc_rho(S, T, p))
+
+
 def test_calc_rho_held_field_broadcast_order():
     """halosteric's call: thetao (z,y,x), so (t,z,y,x) -> dims in first-appearance order."""
     rho = derived.calc_rho(dset1.thetao.isel(time=0), dset1.so, dset1.z_l * 1.0e4)

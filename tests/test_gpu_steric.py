@@ -918,6 +918,49 @@ def test_lazy_inputs_are_read_one_time_chunk_at_a_time(domain, order, monkeypatc
     assert_bit_equal(ref["rho"].transpose(*bref["rho"].dims).values, bref["rho"].values)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("domain", ["local", "global"])
+@pytest.mark.parametrize("container", ["masked", "lazy_masked", "lazy_masked_transposed"])
+def test_masked_arrays_mean_nan(container, domain, dtype, monkeypatch):
+    """What netCDF4 hands over where a file declares ``_FillValue``: numpy masked arrays holding
+    1e20 under the mask -- for a whole in-memory variable ("masked") and for every slice of a lazily
+    read one ("lazy_masked").  The reference never sees them: xarray has turned the mask into NaN
+    (``xr.DataArray(masked)``; ``open_mfdataset``, examples/example.ipynb cell 4; steric.py:84-96).
+    steric() on theta/S/volcello/areacello/deptho given so returns the bits of the same call on the
+    NaN-filled plain arrays -- and those are the oracle's (VERDICT r4 next #1)."""
+    from lazy_array import FILL, MaskedLazy, as_masked
+    from momlevel_amd import engine
+
+    d = _masked_dataset(nt=7, dtype=dtype)
+    assert np.isnan(d["thetao"].values).any()
+    base, bref = steric(d, domain=domain)
+    dm = d.copy()
+    dims = d["thetao"].dims
+    order = ("time", "yh", "xh", "z_l") if container.endswith("transposed") else dims
+    for k in ("thetao", "so", "volcello"):
+        arr = np.ascontiguousarray(d[k].transpose(*order).values)
+        held = as_masked(arr) if container == "masked" else MaskedLazy(arr)
+        if container == "masked":
+            assert held.data[np.isnan(arr)][0] == arr.dtype.type(FILL)
+        dm[k] = DataArray(held, order)
+    for k in ("areacello", "deptho"):
+        dm[k] = DataArray(as_masked(d[k].values), d[k].dims)
+    monkeypatch.setattr(engine, "chunk_steps", lambda nt, b, dev, budget_bytes=None: 2)
+    res, ref = steric(dm, domain=domain)
+    assert_bit_equal(res["steric"].values, base["steric"].values, "masked vs NaN-filled inputs")
+    assert_bit_equal(ref["rho"].transpose(*bref["rho"].dims).values, bref["rho"].values)
+    assert float(ref["volo"]) == float(bref["volo"]) and float(ref["masso"]) == float(bref["masso"])
+    if domain == "local":
+        assert_bit_equal(res["delta_rho"].transpose(*dims).values, base["delta_rho"].values)
+        if dtype == np.float64:
+            ores, oref = _oracle(d)
+            assert_bit_equal(res["steric"].values, ores["steric"], "masked inputs vs the oracle")
+            assert_bit_equal(res["delta_rho"].transpose(*dims).values, ores["delta_rho"])
+    else:
+        assert float(res["reference_height"]) == float(base["reference_height"])
+        assert np.abs(res["steric"].values).max() < 1.0  # (1e20 fill values would give ~1e17 m)
+
+
 @pytest.mark.parametrize("domain", ["local", "global"])
 def test_a_failing_source_raises_from_steric_and_leaves_no_thread_behind(domain, monkeypatch):
     """Uploads are staged by a worker thread (engine.TimeChunks): a source that fails in the middle

@@ -1,4 +1,6 @@
-"""CPU, world_size 2 over gloo: the N>1 exchange step of the global steric path.
+"""CPU, world_size 2 and 8 over gloo: the N>1 exchange step of the global steric path (8 ranks =
+BASELINE.json configs[3]'s 2x4 (yh, xh) layout, which a one-GPU box cannot hold with HIP contexts:
+at most 6 processes may use its card at once).
 
 The per-rank partial sums come from the oracle on each rank's horizontal tile
 (the kernels need a GPU); the code under test is the product's exchange + epilogue:
@@ -90,8 +92,8 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_exchange_matches_single_domain():
-    world = 2
+@pytest.mark.parametrize("world", [2, 8])
+def test_exchange_matches_single_domain(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -113,7 +115,9 @@ def test_two_rank_exchange_matches_single_domain():
         # eta = h_ref * log(ratio): compare as an expansion coefficient, abs tol 1e-12
         assert np.allclose(eta / href, ref["expansion_coeff"], rtol=0, atol=1e-12)
     # every rank holds the same answer bit for bit
-    assert np.array_equal(results[0][1], results[1][1])
+    assert sorted(r[0] for r in results) == list(range(world))
+    for r in results[1:]:
+        assert np.array_equal(results[0][1], r[1])
 
 
 def test_exchange_is_identity_without_a_process_group():
@@ -122,11 +126,26 @@ def test_exchange_is_identity_without_a_process_group():
     assert torch.equal(m2, masso) and (v.item(), m0.item(), a.item()) == (2.0, 3.0, 4.0)
 
 
+def test_eight_ranks_tile_the_plane_two_by_four():
+    """north_star: "tiled 2x4 across 8xMI355X" -- (yh, xh) = 2 x 4, rank = ry * 4 + rx, x fastest;
+    at the 0.25-degree grid every tile is 540 x 360 (contiguous x-runs of 360 cells)"""
+    tiles = [synthetic.tile_bounds(1080, 1440, r, 8) for r in range(8)]
+    assert tiles[0] == (0, 540, 0, 360) and tiles[3] == (0, 540, 1080, 1440)
+    assert tiles[4] == (540, 1080, 0, 360) and tiles[7] == (540, 1080, 1080, 1440)
+    cover = np.zeros((1080, 1440), dtype=np.int32)
+    for y0, y1, x0, x1 in tiles:
+        assert (y1 - y0, x1 - x0) == (540, 360)
+        cover[y0:y1, x0:x1] += 1
+    assert (cover == 1).all()
+    with pytest.raises(ValueError):
+        synthetic.tile_bounds(1080, 1442, 0, 8)
+
+
 @pytest.mark.timeout(300)
-def test_two_rank_chunked_exchange_all_variants():
+@pytest.mark.parametrize("world", [2, 8])
+def test_chunked_exchange_all_variants(world):
     """one all-reduce per time chunk, several rows per chunk: result == the single
     domain for every variant, eta[0] == 0 exactly, ranks bit-identical"""
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -147,10 +166,12 @@ def test_two_rank_chunked_exchange_all_variants():
             assert np.allclose(massos[i], ref["masso"], rtol=1e-13, atol=0)
             href = volo / area
             assert np.allclose(etas[i] / href, ref["expansion_coeff"], rtol=0, atol=1e-12)
-        assert np.array_equal(results[0][1][i], results[1][1][i])
+        for r in results[1:]:
+            assert np.array_equal(results[0][1][i], r[1][i])
     heat = o.ocean_heat_content(T, g["volcello"], 1.0, 1.0)
     assert np.allclose(results[0][3], heat, rtol=1e-13, atol=0)
-    assert np.array_equal(results[0][3], results[1][3])
+    for r in results[1:]:
+        assert np.array_equal(results[0][3], r[3])
 
 
 def test_chunked_exchange_without_a_process_group():
