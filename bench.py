@@ -70,25 +70,26 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the local-variant timings")
     ap.add_argument("--cpu-procs", type=int, default=-1,
                     help="processes of the P-process CPU line (-1: min(16, cores); 0 disables)")
+    ap.add_argument("--detail-file", default=None,
+                    help="also write the long-form JSON (the BENCH_DETAIL line) to this file")
     ap.add_argument("--input-dtype", choices=["f64", "f32"], default="f64",
                     help="storage type of theta/S (f32 = BASELINE.json configs[4]; the headline is f64)")
     return ap.parse_args()
 
 
 def kernel_source_sha():
-    """sha256 of the HIP sources -- a committed counter profile is only quoted while it still
-    describes the kernels that are being timed."""
-    import hashlib
+    """sha256 of what the timed kernels are built from (csrc/build.py TIMED_SOURCES: the HIP
+    sources and their headers, momlevel_promote.hip, include/momlevel_hip.h, and the compiler
+    flags) -- a committed counter profile is only quoted while it still describes them."""
+    from momlevel_amd.csrc.build import source_sha
 
-    h = hashlib.sha256()
-    root = os.path.dirname(os.path.abspath(__file__))
-    # (what the translation unit of the timed kernels includes; momlevel_promote.hip is a separate
-    # unit with the untimed any-dtype EOS map)
-    for rel in ("momlevel_amd/csrc/momlevel_hip.hip", "momlevel_amd/csrc/eos_device.hpp",
-                "momlevel_amd/csrc/mlx_internal.hpp"):
-        with open(os.path.join(root, rel), "rb") as f:
-            h.update(f.read())
-    return h.hexdigest()[:16]
+    return source_sha()
+
+
+# (earlier rounds' summaries carry the sha of fewer files and can never match again)
+PROFILE_SUMMARIES = ("r05_summary.json",)
+VARIANT_SUMMARIES = ("r05_variants_summary.json", "r05_f32_variants_summary.json",
+                     "r05_strat_variants_summary.json")
 
 
 def measured_traffic(cells_per_launch):
@@ -96,7 +97,7 @@ def measured_traffic(cells_per_launch):
     were taken on this workload AND on these kernel sources; bench.py itself cannot read
     hardware counters.  A stale profile (sources changed since) yields null, not an old number."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ("r04_summary.json", "r03_summary.json", "r02_summary.json"):
+    for name in PROFILE_SUMMARIES:
         try:
             with open(os.path.join(here, "profiles", name)) as f:
                 s = json.load(f)
@@ -116,22 +117,18 @@ VALU_PEAK_LANE_INSTR_PER_S = 256 * 4 * 16 * 2.4e9
 
 
 def strat_source_sha():
-    """sha256 (16 hex digits) of csrc/momlevel_strat.hip (scripts/summarize_variants.py writes the same)"""
-    import hashlib
+    from momlevel_amd.csrc.build import strat_source_sha as sha
 
-    here = os.path.dirname(os.path.abspath(__file__))
-    with open(os.path.join(here, "momlevel_amd", "csrc", "momlevel_strat.hip"), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+    return sha()
 
 
 def valu_profiles():
     """{bench key: VALU instructions per cell} from the round's committed SQ_INSTS_VALU passes
-    (profiles/r04_*variants_summary.json, written by scripts/summarize_variants.py) -- quoted, like
+    (profiles/r05_*variants_summary.json, written by scripts/summarize_variants.py) -- quoted, like
     roofline.traffic, only while the sha of the kernel sources matches the profiled ones."""
     here = os.path.dirname(os.path.abspath(__file__))
     found, sources = {}, []
-    for name in ("r04_variants_summary.json", "r04_f32_variants_summary.json",
-                 "r04_strat_variants_summary.json"):
+    for name in VARIANT_SUMMARIES:
         try:
             with open(os.path.join(here, "profiles", name)) as f:
                 summ = json.load(f)
@@ -199,6 +196,134 @@ def add_valu_roofline(line, f64_probe=None):
         "definition": "valu_instr_per_cell (SQ_INSTS_VALU x 64 / cells, committed profile of these "
                       "kernel sources) x cells/s / (256 CU x 4 SIMD x 16 lanes x 2.4 GHz)",
         "sources": sources or None,
+    }
+
+
+def per_kernel_table(line):
+    """{bench key: [ms, frac_of_8TBs, frac_of_matching_probe, frac_of_f64_fma_probe]} for every
+    timed extra of the line: the float64 rows, and of the float32 record (config5_f32) the rows of
+    the product's default modes (the other float32 modes stay in the BENCH_DETAIL line)."""
+    table = {}
+
+    def walk(node, path):
+        if not isinstance(node, dict):
+            return
+        if "ms" in node and "frac_of_8TBs" in node:
+            table[".".join(path)] = [node["ms"], node["frac_of_8TBs"],
+                                     node.get("frac_of_matching_probe"),
+                                     node.get("frac_of_f64_fma_probe")]
+            return
+        for k, v in node.items():
+            if path == ["config5_f32"] and k not in ("default",):
+                continue
+            if k in ("roofline", "config", "cpu_baseline", "valu_roofline"):
+                continue
+            walk(v, path + [k])
+
+    walk(line, [])
+    return {k.replace("config5_f32.default.", "f32."): v for k, v in table.items()}
+
+
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                 "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
+                 "cpu_baseline")
+
+
+def compact_line(line, detail_bytes):
+    """The contract line: the contract's keys, roofline (with the per-kernel table and the probes)
+    and cpu_baseline whole; of everything else one line's worth."""
+    out = {k: line[k] for k in CONTRACT_KEYS if k in line}
+    for k in ("cpu_baseline_processes", "cpu_baseline_fused_openmp"):
+        v = line.get(k)
+        if isinstance(v, dict):
+            out[k] = {kk: v[kk] for kk in ("value", "unit", "cores", "error") if kk in v}
+    out["parity"] = line.get("parity")
+    out["eta_t0_is_zero"] = line.get("eta_t0_is_zero")
+    checks = {}
+
+    def walk(node, path):
+        if isinstance(node, dict):
+            for k, v in node.items():
+                if isinstance(v, bool) and ("bit_identical" in k or k.endswith("_is_zero")
+                                            or "equals" in k or k.startswith("k1_default_is")):
+                    checks[".".join(path + [k])] = v
+                else:
+                    walk(v, path + [k])
+
+    walk({k: v for k, v in line.items() if k not in CONTRACT_KEYS}, [])
+    if checks:
+        out["checks_all_true"] = all(checks.values())
+        out["checks_failed"] = [k for k, v in checks.items() if not v]
+        out["checks_count"] = len(checks)
+    ex = line.get("reference_example_call")
+    if isinstance(ex, dict):
+        out["reference_example_call"] = {k: ex[k] for k in (
+            "wall_s", "GB/s_host_link_in_plus_out", "step_bit_identical_to_oracle", "error") if k in ex}
+    if "valu_roofline" in line:
+        out["f64_fma_probe_lane_instr_per_s"] = line["valu_roofline"].get(
+            "f64_fma_probe_lane_instr_per_s")
+    out["detail"] = (f"the line before this one (prefix BENCH_DETAIL, {detail_bytes} bytes) holds "
+                     "every row in full: kernel names, notes, checks, the non-default float32 modes")
+    return out
+
+
+def workload_config(world, grid, nt, nt_req, tile_hw, n_launches, chunk_steps, input_dtype,
+                    backend):
+    """The ``config`` object of the JSON line: which BASELINE.json configuration this run IS (and
+    says so only when it is: the record not shortened, the grid the 0.25-degree one, 8 ranks x 1200
+    steps for configs[3]), the tile layout and the collective.  Pure: tests/test_bench_helpers.py
+    checks the 8-rank 2x4 branch, which no one-GPU box can run."""
+    nz, ny, nx = grid
+    th, tw = tile_hw
+    f32 = input_dtype == "f32"
+    shrunk = nt < nt_req
+    layout = {1: "1x1", 2: "1x2", 4: "2x2", 8: "2x4"}.get(world, f"1x{world}")
+    cells_rank = nt * nz * th * tw
+    if world == 1:
+        workload = (
+            f"OM4 0.25deg synthetic grid {nx}x{ny}x{nz}, {nt} time steps, "
+            f"{'fp32 theta/S (BASELINE.json configs[4])' if f32 else 'fp64'}, global "
+            + ("steric (shortened to fit free HBM: NOT BASELINE.json configs[2], see nt_requested)"
+               if shrunk else "steric (BASELINE.json configs[2])"))
+    else:
+        workload = (
+            f"OM4 0.25deg synthetic grid {nx}x{ny}x{nz} tiled {layout} (yh x xh), {nt} time "
+            f"steps, fp64, global steric: every GPU holds all {nt} steps of its "
+            f"{tw}x{th} tile resident = the cells of {nt / world:g} full-grid steps, walked "
+            f"in {n_launches} time chunks of <= {chunk_steps} steps with one exchange "
+            "per chunk ("
+            + ("NOT BASELINE.json configs[3]: the record was shortened to fit free HBM, see "
+               "nt_requested; " if shrunk else
+               "BASELINE.json configs[3]; " if (world == 8 and nt == 1200
+                                                and (nz, ny, nx) == GRID) else
+               f"configs[3]'s tiling at {world} GPUs -- configs[3] itself is 8 GPUs x 1200 "
+               "steps; ")
+            + "weak scaling: bytes per GPU are fixed, the record grows with N)")
+    return {
+        "workload": workload,
+        "grid_xyz": [nx, ny, nz],
+        "nt_per_gpu_resident": nt,
+        "nt_total": nt,
+        "nt_requested": nt_req,
+        "record_shortened_to_fit_hbm": shrunk,
+        "tile_layout_yx": layout,
+        "tile_xy": [tw, th],
+        "variant": "steric",
+        "domain": "global",
+        "collective": ("none" if world == 1 else
+                       f"{n_launches} per step, one per time chunk: {chunk_steps}(+3 in the first) "
+                       f"f64 per rank, {parallel.exchange_mode()} "
+                       + ("(all_gather_into_tensor + rank-ordered float64 sum: every element of "
+                          "the vector is reduced in the same order)"
+                          if parallel.exchange_mode() == "ordered" else "(all_reduce SUM)")
+                       + ", asynchronous, overlapped with the next chunk's kernel"),
+        "backend": (None if world == 1 else
+                    "nccl (RCCL)" if backend == "nccl" else
+                    backend + " (REHEARSAL: the ranks share GPUs and the exchange "
+                    "is staged through the host; not an xGMI measurement)"),
+        "time_chunks": n_launches,
+        "input_dtype": input_dtype,
+        "hbm_resident_gb": round(2 * cells_rank * (4 if f32 else 8) / 1e9, 1),
     }
 
 
@@ -492,7 +617,6 @@ def main():
             extras["reference_example_call"] = example_call()
 
     if rank == 0:
-        layout = {1: "1x1", 2: "1x2", 4: "2x2", 8: "2x4"}.get(world, f"1x{world}")
         line = {
             "metric": METRIC,
             "value": round(cells_job * a.steps / elapsed / 1e6, 1),
@@ -506,44 +630,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f64" if not f32 else "f64 (float32 theta/S: polynomial in f32 as numpy does, rest f64)",
             "data": "synthetic",
-            "config": {
-                "workload": (
-                    f"OM4 0.25deg synthetic grid {nx}x{ny}x{nz}, {nt} time steps, "
-                    f"{'fp32 theta/S (BASELINE.json configs[4])' if f32 else 'fp64'}, global "
-                    + ("steric (shortened to fit free HBM: NOT BASELINE.json configs[2], see nt_requested)"
-                       if shrunk else "steric (BASELINE.json configs[2])") if world == 1 else
-                    f"OM4 0.25deg synthetic grid {nx}x{ny}x{nz} tiled {layout} (yh x xh), {nt} time "
-                    f"steps, fp64, global steric: every GPU holds all {nt} steps of its "
-                    f"{tw}x{th} tile resident = the cells of {nt / world:g} full-grid steps, walked "
-                    f"in {n_launches} time chunks of <= {chunk_steps} steps with one RCCL all-reduce "
-                    "per chunk ("
-                    + ("NOT BASELINE.json configs[3]: the record was shortened to fit free HBM, see "
-                       "nt_requested; " if shrunk else
-                       "BASELINE.json configs[3]; " if (world == 8 and nt == 1200
-                                                        and (nz, ny, nx) == GRID) else
-                       f"configs[3]'s tiling at {world} GPUs -- configs[3] itself is 8 GPUs x 1200 "
-                       "steps; ")
-                    + "weak scaling: bytes per GPU are fixed, the record grows with N)"),
-                "grid_xyz": [nx, ny, nz],
-                "nt_per_gpu_resident": nt,
-                "nt_total": nt,
-                "nt_requested": nt_req,
-                "record_shortened_to_fit_hbm": shrunk,
-                "tile_layout_yx": layout,
-                "tile_xy": [tw, th],
-                "variant": "steric",
-                "domain": "global",
-                "collective": ("none" if world == 1 else
-                               f"{n_launches} all_reduce per step: {chunk_steps}(+3 in the first) f64 "
-                               "each, asynchronous, overlapped with the next chunk's kernel"),
-                "backend": (None if world == 1 else
-                            "nccl (RCCL)" if dist.get_backend() == "nccl" else
-                            dist.get_backend() + " (REHEARSAL: the ranks share GPUs and the exchange "
-                            "is staged through the host; not an xGMI measurement)"),
-                "time_chunks": n_launches,
-                "input_dtype": a.input_dtype,
-                "hbm_resident_gb": round(2 * cells_rank * (4 if f32 else 8) / 1e9, 1),
-            },
+            "config": workload_config(world, (nz, ny, nx), nt, nt_req, (th, tw), n_launches,
+                                      chunk_steps, a.input_dtype,
+                                      None if world == 1 else dist.get_backend()),
             "roofline": {
                 "kernel": k1_kernel,  # mlx_last_kernel() after the timed launches
                 "kernel_template_arguments": "<element type, cells per pack, packs per thread, "
@@ -574,7 +663,31 @@ def main():
         }
         line.update(extras)
         add_valu_roofline(line, measure_valu_probe(dev) if world == 1 else None)
-        print(json.dumps(line), flush=True)
+        if extras:
+            probes = {"f64" if not f32 else "f32": extras.get("probes")}
+            if "config5_f32" in extras:
+                probes["f32"] = extras["config5_f32"].get("probes")
+            headline_probe = (extras.get("probes") or {}).get("2r")
+            if headline_probe:
+                line["roofline"]["frac_of_matching_probe"] = round(achieved / headline_probe, 4)
+            line["roofline"]["probes"] = probes
+            line["roofline"]["probes_unit"] = (
+                "GB/s of mlx_stream_probe_mix (no arithmetic, one tile per block) per read:write mix "
+                "(<streamed fields in>r[<float64 streams out>w]) on this record")
+            line["roofline"]["per_kernel"] = per_kernel_table(line)
+            line["roofline"]["per_kernel_columns"] = [
+                "ms", "frac_of_8TBs (algorithmic bytes)", "frac_of_matching_probe",
+                "frac_of_f64_fma_probe (null: no committed VALU profile of these sources)"]
+        # The long form first (every row with its kernel name, notes and checks), the contract
+        # line LAST and short: the driver keeps an 8 KB tail of stdout and parses the last line --
+        # round 4's single 25 KB line lost every float64 extra from the record.
+        detail = json.dumps(line)
+        if a.detail_file:
+            with open(a.detail_file, "w") as f:
+                f.write(detail + "\n")
+        if extras:
+            print("BENCH_DETAIL " + detail, flush=True)
+        print(json.dumps(compact_line(line, len(detail))), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -603,10 +716,7 @@ def stratification_timings(T, S, g, steps, B1):
         res["n2"] = core.stratification(Tc, Sc, pz, z)
 
     ms = _time(run, reps=2)
-    bpc = 2 * B1 + 8
-    r = {"Mcells/s": round(cells / ms / 1e3, 1), "ms": round(ms, 3),
-         "algorithmic_bytes_per_cell": bpc, "GB/s": round(bpc * cells / ms / 1e6, 1),
-         "frac_of_8TBs": round(bpc * cells / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    r = _rate(ms, 2 * B1 + 8, cells, mix="2r1w", kernel=False)
     r["steps"] = steps
     r["kernel"] = ("k_stratification<double, 2, kF64, kWright, MLX_STRAT_N2>" if B1 == 8 else
                    "k_stratification<float, 2, kF32Faithful, kWright, MLX_STRAT_N2>")
@@ -619,11 +729,6 @@ def stratification_timings(T, S, g, steps, B1):
     cpu_s = time.perf_counter() - t0
     r["band_bit_identical_to_numpy"] = bool(np.array_equal(got, ref, equal_nan=True))
     r["numpy_oracle_1_thread_Mcells/s"] = round(ref.size / cpu_s / 1e6, 2)  # (on that band)
-    # (the probe writes into the result buffer: only after the check)
-    pms = _time(lambda: core.stream_probe_mix(Tc, Sc, out=res["n2"]), reps=2)
-    r["probe_GB/s"] = round((2 * B1 + 8) * cells / pms / 1e6, 1)
-    r["frac_of_matching_probe"] = round(pms / ms, 4)
-    r["probe"] = "mlx_stream_probe_mix: 2 fields in, float64 out, no arithmetic"
     del res["n2"]
     torch.cuda.empty_cache()  # (the callers size their next buffers from the driver's free memory)
     return r
@@ -703,20 +808,67 @@ def _time(fn, reps=3):
     return best
 
 
+def _rate(ms, bytes_per_cell, cells, mix=None, kernel=True):
+    """One timed pass as a result row.  ``mix``: the read:write mix of its streams ("2r", "1r",
+    "2r1w", "1r1w": streamed fields in, float64 streams out) -- add_probe_fractions() prices the
+    row against the no-arithmetic probe of THAT mix on this box."""
+    r = {"Mcells/s": round(cells / ms / 1e3, 1), "ms": round(ms, 3),
+         "algorithmic_bytes_per_cell": bytes_per_cell,
+         "GB/s": round(bytes_per_cell * cells / ms / 1e6, 1),
+         "frac_of_8TBs": round(bytes_per_cell * cells / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    if kernel:  # the K1 / K2 instantiation the timed call launched (mlx_last_kernel)
+        r["kernel"] = _lib.last_kernel()
+    if mix:
+        r["probe_mix"] = mix
+    return r
+
+
+def measure_probes(T, S, dbuf=None, starts=(), steps=0):
+    """This box's streaming ceilings, GB/s, for the read:write mixes of the timed kernels on the
+    record they run on: mlx_stream_probe_mix (no arithmetic; one tile per block, the fastest shape
+    of scripts/tune_probe.hip's sweep for each mix).  Read-only mixes: one launch over the whole
+    resident record.  Mixes with the float64 output stream: the record in chunks of ``steps`` into
+    the reused buffer ``dbuf``, as the kernels with delta_rho run."""
+    B1 = T.element_size()
+    cells = T.numel()
+    n3 = int(np.prod(T.shape[1:]))
+    out = {"dtype": "float64" if B1 == 8 else "float32"}
+    ms = _time(lambda: core.stream_probe_mix(T, None, write=False), reps=2)
+    out["1r"] = round(B1 * cells / ms / 1e6, 1)
+    ms = _time(lambda: core.stream_probe_mix(T, S, write=False), reps=2)
+    out["2r"] = round(2 * B1 * cells / ms / 1e6, 1)
+    if dbuf is not None and len(starts):
+        done = len(starts) * steps * n3
+        for nin in (1, 2):
+            def run():
+                for t0 in starts:
+                    core.stream_probe_mix(T[t0:t0 + steps], S[t0:t0 + steps] if nin == 2 else None,
+                                          out=dbuf, write=True)
+
+            ms = _time(run, reps=2)
+            out[f"{nin}r1w"] = round((nin * B1 + 8) * done / ms / 1e6, 1)
+        out["write_chunk_steps"] = steps
+    return out
+
+
+def add_probe_fractions(node, probes):
+    """frac_of_matching_probe = the row's GB/s over the probe of its mix, for every row below
+    ``node`` that names one"""
+    if not isinstance(node, dict):
+        return
+    mix = node.get("probe_mix")
+    if mix and probes.get(mix) and "GB/s" in node:
+        node["frac_of_matching_probe"] = round(node["GB/s"] / probes[mix], 4)
+    for v in node.values():
+        add_probe_fractions(v, probes)
+
+
 def local_variant_timings(T, S, vol0, pres, g, dev):
     """Informative: the other variants on the same resident fields (outside the timed region)."""
     nt, nz, ny, nx = T.shape
     cells = nt * nz * ny * nx
     out = {}
     B1 = T.element_size()  # bytes per cell of ONE streamed field: 8 (float64) or 4 (float32)
-
-    def rate(ms, bytes_per_cell, n=cells, kernel=True):
-        r = {"Mcells/s": round(n / ms / 1e3, 1), "ms": round(ms, 3),
-             f"GB/s_at_{bytes_per_cell}B_per_cell": round(bytes_per_cell * n / ms / 1e6, 1),
-             "frac_of_8TBs": round(bytes_per_cell * n / ms / 1e6 / HBM_PEAK_GBS, 4)}
-        if kernel:  # the K1 / K2 instantiation the timed call launched (mlx_last_kernel)
-            r["kernel"] = _lib.last_kernel()
-        return r
 
     # K1's arithmetic: the product default for this dtype (fused on float64, exact on float32;
     # core.arith_default) carries the plain key, the other policy its name as a suffix
@@ -729,27 +881,21 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
     for arith in ("fused", "exact"):
         ms = _time(lambda: core.steric_global_masso(T, S[0], vol0, pres, skip_dry=False,
                                                     arith=arith))
-        out["thermosteric_global" + tag(arith)] = rate(ms, B1)
+        out["thermosteric_global" + tag(arith)] = _rate(ms, B1, cells, "1r")
         ms = _time(lambda: core.steric_global_masso(T[0], S, vol0, pres, skip_dry=False,
                                                     arith=arith))
-        out["halosteric_global" + tag(arith)] = rate(ms, B1)
+        out["halosteric_global" + tag(arith)] = _rate(ms, B1, cells, "1r")
     other = "exact" if default == "fused" else "fused"
     ms = _time(lambda: core.steric_global_masso(T, S, vol0, pres, skip_dry=False, arith=other))
-    out["steric_global" + tag(other)] = rate(ms, 2 * B1)
+    out["steric_global" + tag(other)] = _rate(ms, 2 * B1, cells, "2r")
     # BASELINE.json configs[4]: steric + thermosteric + halosteric (+ heat content) from ONE pass
     # over theta/S, against the sum of the three single-variant launches
     for arith in ("fused", "exact"):
         ms = _time(lambda: core.steric_global_decomp(T, S, T[0], S[0], vol0, pres, skip_dry=False,
                                                      arith=arith))
-        r = rate(ms, 2 * B1)
+        r = _rate(ms, 2 * B1, cells, "2r")
         r["note"] = "all three variants + sum(theta*vol0) per step, theta/S read once"
         out["decomposition_one_pass" + tag(arith)] = r
-    # calibration: this box's plain streaming-read rate through the same 16-byte nt loads
-    # (skipna sum of the theta record) -- the practical ceiling K1's 16 B/cell runs against
-    if B1 == 8:
-        ms = _time(lambda: core.nansum(T))
-        out["stream_read_probe"] = {"GB/s": round(8 * cells / ms / 1e6, 1),
-                                    "note": "mlx_nansum over theta (one 112 GB stream, nt loads)"}
     # the product default (MLX_FLAG_SKIP_DRY): theta/S of all-dry 16-byte packs are never loaded;
     # bit-identical results, fewer HBM bytes than the 16 B/cell the metric counts
     ms = _time(lambda: core.steric_global_masso(T, S, vol0, pres, skip_dry=True))
@@ -766,7 +912,8 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
     ms = _time(lambda: core.steric_local(T, S, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=zi,
                                          deptho=dep, want_delta_rho=False, eta_out=eta,
                                          skip_dry=False))
-    out["local_eta_only"] = rate(ms, 2 * B1)
+    out["local_eta_only"] = _rate(ms, 2 * B1, cells, "2r")
+    probes = None
     # K2 with delta_rho: the 8 B/cell output does not fit beside the record, so it is produced in
     # time chunks into one reused buffer.  Two chunk sizes: 16 steps (the K2 thread's own time
     # block: one occupancy round per launch, 7 launches) and the largest the free HBM holds
@@ -786,18 +933,10 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
                                   -1.0 / 1035.0, z_i=zi, deptho=dep, delta_rho_out=dbig,
                                   eta_out=eta[t0:t0 + big], skip_dry=False)
 
-        def probe_big():
-            for t0 in starts_b:
-                core.stream_probe(T[t0:t0 + big], S[t0:t0 + big], out=dbig)
-
         ms_b = _time(run_big, reps=2)
-        r = rate(ms_b, 2 * B1 + 8, done_b)
+        r = _rate(ms_b, 2 * B1 + 8, done_b, "2r1w")
         r["delta_rho_chunk_steps"] = big
         r["launches"] = len(starts_b)
-        if B1 == 8:
-            pms_b = _time(probe_big, reps=2)
-            r["frac_of_read_write_probe"] = round(pms_b / ms_b, 4)
-            r["read_write_probe_GB/s"] = round(24 * done_b / pms_b / 1e6, 1)
         out["local_with_delta_rho_large_chunks"] = r
         # The held-field instantiations of the local pass (what momlevel.thermosteric(ds) /
         # halosteric(ds) run with the default domain="local", steric.py:150-166): one streamed
@@ -806,8 +945,17 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
         # mix (1 stream in, 1 out), and the eta-only forms against the one-stream read probe.
         out.update(local_held_timings(T, S, rho0m, vol0, pres, zi, dep, eta, dbig, starts_b, big,
                                       g, B1))
+        # this box's no-arithmetic ceilings for every mix, on this record and these chunks
+        probes = measure_probes(T, S, dbig, starts_b, big)
         del dbig
         torch.cuda.empty_cache()
+    if probes is None:
+        probes = measure_probes(T, S)
+    # continuity with rounds 2-4: the skipna sum of the theta record (grid-stride, one pack in
+    # flight per thread) -- a slower shape than the "1r" probe, kept as a second opinion
+    ms = _time(lambda: core.nansum(T))
+    probes["1r_nansum_kernel"] = round(B1 * cells / ms / 1e6, 1)
+    out["probes"] = probes
     chunk = min(nt, 16)
     free, _ = torch.cuda.mem_get_info(dev)
     if free > chunk * nz * ny * nx * 8 + (2 << 30):
@@ -822,38 +970,24 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
                                   eta_out=eta[t0:t0 + chunk], skip_dry=skip)
 
         ms = _time(lambda: run(False), reps=2)
-        out["local_with_delta_rho"] = rate(ms, 2 * B1 + 8, done)
+        out["local_with_delta_rho"] = _rate(ms, 2 * B1 + 8, done, "2r1w")
         out["local_with_delta_rho"]["delta_rho_chunk_steps"] = chunk
         out["local_with_delta_rho"]["launches"] = len(starts)
 
-        # the same traffic with no arithmetic: 16 B read + 8 B written per cell through the same
-        # 16-byte nt loads/stores -- this box's ceiling for the pass above
-        def probe():
-            for t0 in starts:
-                core.stream_probe(T[t0:t0 + chunk], S[t0:t0 + chunk], out=drho)
-
-        if B1 == 8:
-            pms = _time(probe, reps=2)
-            out["stream_read_write_probe"] = {
-                "GB/s": round(24 * done / pms / 1e6, 1), "ms": round(pms, 3),
-                "note": "mlx_stream_probe: out = a + b, 16 B read + 8 B written per element"}
-            out["local_with_delta_rho"]["frac_of_read_write_probe"] = round(pms / ms, 4)
         # K0 (derived.calc_rho: the pointwise EOS map, 16 B read + 8 B written per cell), in the
-        # same 16-step chunks, against the same read+write probe
+        # same 16-step chunks
         def run_k0():
             for t0 in starts:
                 rho = core.eos_map(T[t0:t0 + chunk], S[t0:t0 + chunk], pres)
                 del rho
 
         kms = _time(run_k0, reps=2)
-        out["calc_rho_map"] = rate(kms, 2 * B1 + 8, done, kernel=False)
-        if B1 == 8:
-            out["calc_rho_map"]["frac_of_read_write_probe"] = round(pms / kms, 4)
+        out["calc_rho_map"] = _rate(kms, 2 * B1 + 8, done, "2r1w", kernel=False)
         ms_skip = _time(lambda: run(True), reps=2)
         out["land_skipping"]["local_with_delta_rho_Mcells/s"] = round(done / ms_skip / 1e3, 1)
         del drho
         torch.cuda.empty_cache()
-        # the consumers of alpha / beta: derived.calc_n2 in one pass
+        # out-of-contract extra (kept green, not extended): calc_n2
         out["calc_n2"] = stratification_timings(T, S, g, min(nt, 2 * chunk), B1)
         drho = torch.empty((chunk, nz, ny, nx), dtype=torch.float64, device=dev)
 
@@ -884,12 +1018,13 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
                                              skip_dry=False)
 
             ms3 = _time(run3, reps=2)
-            r = rate(ms3, 2 * B1 + 24, done3)
+            r = _rate(ms3, 2 * B1 + 24, done3)
             r["three_single_variant_launches_ms"] = round(three * done3 / done, 3)
             r["one_pass_speedup"] = round(three * done3 / done / ms3, 3)
             r["note"] = "steric + thermosteric + halosteric delta_rho and eta, theta/S read once"
             out["local_decomposition_one_pass"] = r
             del d3, e3
+    add_probe_fractions(out, probes)
     return out
 
 
@@ -897,21 +1032,14 @@ def local_held_timings(T, S, rho0m, vol0, pres, zi, dep, eta, dbuf, starts, step
                         with_steric=False):
     """K2's held-field instantiations (+ the steric one for float32 records, ``with_steric``) with
     and without delta_rho on the resident record, in chunks of ``steps`` into the reused float64
-    buffer ``dbuf``; each against the stream probe with its own read:write mix, and one slab of each
-    variant against the oracle (numpy on the arrays' own dtype)."""
+    buffer ``dbuf``, and one slab of each variant against the oracle (numpy on the arrays' own
+    dtype).  Each row names the read:write mix whose probe bounds it (add_probe_fractions)."""
     from oracle import momlevel_numpy as o  # the checker
 
     nt, nz, ny, nx = T.shape
     n3 = nz * ny * nx
     done = len(starts) * steps * n3
     out = {}
-
-    def rate(ms, bpc, n):
-        return {"Mcells/s": round(n / ms / 1e3, 1), "ms": round(ms, 3),
-                "algorithmic_bytes_per_cell": bpc,
-                "GB/s": round(bpc * n / ms / 1e6, 1),
-                "frac_of_8TBs": round(bpc * n / ms / 1e6 / HBM_PEAK_GBS, 4),
-                "kernel": _lib.last_kernel()}
 
     def ops(variant, t0, t1):
         Tv = T[0] if variant == "halosteric" else T[t0:t1]
@@ -925,19 +1053,6 @@ def local_held_timings(T, S, rho0m, vol0, pres, zi, dep, eta, dbuf, starts, step
                               want_delta_rho=want, delta_rho_out=dbuf if want else None,
                               eta_out=eta[t0:t0 + steps], skip_dry=False)
 
-    def probe(nin, write):
-        for t0 in starts:
-            a = T[t0:t0 + steps]
-            core.stream_probe_mix(a, S[t0:t0 + steps] if nin == 2 else None,
-                                  out=dbuf if write else None, write=write)
-
-    probes = {}
-
-    def probe_ms(nin, write):
-        if (nin, write) not in probes:
-            probes[(nin, write)] = _time(lambda: probe(nin, write), reps=2)
-        return probes[(nin, write)]
-
     variants = (("steric",) if with_steric else ()) + ("thermosteric", "halosteric")
     pn = pres.cpu().numpy()
     T0n, S0n = hostio.to_host(T[0]), hostio.to_host(S[0])
@@ -949,21 +1064,14 @@ def local_held_timings(T, S, rho0m, vol0, pres, zi, dep, eta, dbuf, starts, step
             if variant == "halosteric" and not want:
                 continue
             ms = _time(lambda: run(variant, want), reps=2)
-            bpc = nin * B1 + (8 if want else 0)
-            r = rate(ms, bpc, done)
+            r = _rate(ms, nin * B1 + (8 if want else 0), done, f"{nin}r" + ("1w" if want else ""))
             if want:  # one slab against the oracle: the last step the run left in the buffer
-                # (before the probe below reuses the buffer)
                 Tn = T0n if variant == "halosteric" else hostio.to_host(T[t_chk])
                 Sn = S0n if variant == "thermosteric" else hostio.to_host(S[t_chk])
                 r["slab_bit_identical_to_oracle"] = local_slab_check(
                     o, Tn, Sn, rho0n, g, pn, hostio.to_host(dbuf[steps - 1]),
                     hostio.to_host(eta[t_chk]))
                 r["time_step_checked"] = int(t_chk)
-            pms = probe_ms(nin, want)
-            r["probe"] = (f"mlx_stream_probe_mix: {nin} x {'float64' if B1 == 8 else 'float32'} in"
-                          + (", 1 x float64 out" if want else ", read-only"))
-            r["probe_GB/s"] = round(bpc * done / pms / 1e6, 1)
-            r["frac_of_matching_probe"] = round(pms / ms, 4)
             r["chunk_steps"], r["launches"] = steps, len(starts)
             key = "local_" + ("" if variant == "steric" else variant + "_") + (
                 "with_delta_rho" if want else "eta_only")
@@ -988,11 +1096,8 @@ def f32_timings(vol0, pres, g, dev, nt, synth_kw):
                          lo=synthetic.SO_LO, scale=synthetic.SO_SCALE, **synth_kw)
     cells = nt * nz * ny * nx
 
-    def rate(ms, bpc):
-        return {"ms": round(ms, 3), "Mcells/s": round(cells / ms / 1e3, 1),
-                "GB/s": round(bpc * cells / ms / 1e6, 1),
-                "frac_of_8TBs": round(bpc * cells / ms / 1e6 / HBM_PEAK_GBS, 4),
-                "algorithmic_bytes_per_cell": bpc, "kernel": _lib.last_kernel()}
+    def rate(ms, bpc, mix):
+        return _rate(ms, bpc, cells, mix)
 
     modes = {"faithful_fused": dict(f32_mode="faithful", arith="fused"),
              "faithful": dict(f32_mode="faithful", arith="exact"),
@@ -1007,13 +1112,13 @@ def f32_timings(vol0, pres, g, dev, nt, synth_kw):
     for mode, kw in modes.items():
         r = {}
         r["steric"] = rate(_time(lambda: core.steric_global_masso(T, S, vol0, pres, skip_dry=False,
-                                                                  **kw)), 8)
+                                                                  **kw)), 8, "2r")
         r["thermosteric"] = rate(_time(lambda: core.steric_global_masso(
-            T, S[0], vol0, pres, skip_dry=False, **kw)), 4)
+            T, S[0], vol0, pres, skip_dry=False, **kw)), 4, "1r")
         r["halosteric"] = rate(_time(lambda: core.steric_global_masso(
-            T[0], S, vol0, pres, skip_dry=False, **kw)), 4)
+            T[0], S, vol0, pres, skip_dry=False, **kw)), 4, "1r")
         r["one_pass"] = rate(_time(lambda: core.steric_global_decomp(
-            T, S, T[0], S[0], vol0, pres, skip_dry=False, **kw)), 8)
+            T, S, T[0], S[0], vol0, pres, skip_dry=False, **kw)), 8, "2r")
         r["one_pass"]["three_launches_ms"] = round(
             r["steric"]["ms"] + r["thermosteric"]["ms"] + r["halosteric"]["ms"], 3)
         out[mode] = r
@@ -1024,7 +1129,7 @@ def f32_timings(vol0, pres, g, dev, nt, synth_kw):
     for mode, kw in modes.items():
         out[mode]["local_eta_only"] = rate(_time(lambda: core.steric_local(
             T, S, rho0m, vol0[0], pres, -1.0 / 1035.0, z_i=zi, deptho=dep, want_delta_rho=False,
-            eta_out=eta, skip_dry=False, **kw)), 8)
+            eta_out=eta, skip_dry=False, **kw)), 8, "2r")
     # what a user gets without choosing anything: the global sums in the fused-tail policy, the
     # local pass exact
     out["default"] = dict({k: out["faithful_fused"][k] for k in ("steric", "thermosteric",
@@ -1042,11 +1147,15 @@ def f32_timings(vol0, pres, g, dev, nt, synth_kw):
         # steps per thread: the full 120-step record ends on a half-filled block of the 16-step ones)
         steps_d = steps_d // 24 * 24 if steps_d >= 24 else steps_d // 6 * 6
         dbuf = torch.empty((steps_d, nz, ny, nx), dtype=torch.float64, device=dev)
+        starts_d = range(0, nt - steps_d + 1, steps_d)
         out["default"].update(local_held_timings(
-            T, S, rho0m, vol0, pres, zi, dep, eta, dbuf, range(0, nt - steps_d + 1, steps_d),
-            steps_d, g, 4, with_steric=True))
+            T, S, rho0m, vol0, pres, zi, dep, eta, dbuf, starts_d, steps_d, g, 4, with_steric=True))
+        probes = measure_probes(T, S, dbuf, starts_d, steps_d)
         del dbuf
         torch.cuda.empty_cache()
+    else:
+        probes = measure_probes(T, S)
+    out["probes"] = probes
     out["default"]["calc_n2"] = stratification_timings(T, S, g, min(nt, 48), 4)
     # derived.calc_pdens on float32 fields (derived.py:477: a python-float pressure, so numpy keeps
     # the whole expression float32): the any-dtype map, 8 B read + 4 B written per cell
@@ -1085,6 +1194,7 @@ def f32_timings(vol0, pres, g, dev, nt, synth_kw):
                      "time_step_checked": t,
                      "masso_rel_err_vs_numpy_float32_oracle": errs,
                      "masso0_equals_masso_t0": bool(rows[0, 0] == rows[1, 0] == rows[2, 0])}
+    add_probe_fractions(out, probes)
     del T, S
     torch.cuda.empty_cache()
     return out

@@ -40,6 +40,39 @@ FLAGS = [
 ]
 
 
+# What the timed kernels are built from: the sources of their translation units, the headers
+# those include, the public header and the compiler flags.  bench.py and the profile summaries
+# stamp this sha on their numbers; a committed counter profile is quoted only while it matches.
+TIMED_SOURCES = [
+    os.path.join(HERE, "momlevel_hip.hip"),
+    os.path.join(HERE, "eos_device.hpp"),
+    os.path.join(HERE, "mlx_internal.hpp"),
+    os.path.join(HERE, "momlevel_promote.hip"),
+    os.path.join(HERE, "eos_promote.hpp"),
+    os.path.join(ROOT, "include", "momlevel_hip.h"),
+]
+
+
+def source_sha(paths=None, flags=True):
+    """sha256 (first 16 hex digits) of ``paths`` (default TIMED_SOURCES) and, with ``flags``, of
+    the compiler flags"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in (TIMED_SOURCES if paths is None else paths):
+        with open(path, "rb") as f:
+            h.update(f.read())
+    if flags:
+        h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def strat_source_sha():
+    """the stratification kernels' own guard: csrc/momlevel_strat.hip (+ what it includes, + flags)"""
+    return source_sha([os.path.join(HERE, "momlevel_strat.hip"), os.path.join(HERE, "eos_device.hpp"),
+                       os.path.join(HERE, "mlx_internal.hpp")])
+
+
 def hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):

@@ -558,52 +558,57 @@ __global__ __launch_bounds__(kBlock) void k_nansum_partial(const double* __restr
   if (threadIdx.x == 0) partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
-// Streaming probe for K2: reads 16 B and writes 8 B per element with the same 16-byte nt loads
-// and stores as the fused local kernel, and no arithmetic to speak of (out = a + b) -- the box's
-// read+write ceiling that `local_with_delta_rho` runs against (bench.py).
-__global__ __launch_bounds__(kBlock) void k_stream_probe(const double* __restrict__ a,
-                                                         const double* __restrict__ b, int64_t n2,
-                                                         double* __restrict__ out) {
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
-       i += (int64_t)gridDim.x * kBlock) {
-    const Pack<double, 2> x = load_pack<double, 2, true>(a + 2 * i);
-    const Pack<double, 2> y = load_pack<double, 2, true>(b + 2 * i);
-    Pack<double, 2> r;
-    r.v[0] = x.v[0] + y.v[0];
-    r.v[1] = x.v[1] + y.v[1];
-    store_pack<2, true>(out + 2 * i, r);
-  }
-}
-
-// The same probe for the read:write mixes of the OTHER instantiations of the local kernel: NIN
-// streams of TIn in (16-byte nt loads: 2 doubles or 4 floats per lane) and, if WRITE, one float64
-// stream out (16-byte nt stores) -- a held-field pass with delta_rho is 1 stream in / 1 out (8 B +
-// 8 B per cell at float64, 4 B + 8 B at float32), the float32 steric pass 2 in / 1 out (8 B + 8 B),
-// the eta-only passes read-only.  Without WRITE the values are summed into a per-thread sink that is
-// stored only if it equals a value no data produces (keeps the loads alive, writes nothing).
-template <typename TIn, int NIN, bool WRITE>
+// Streaming probes: the box's ceiling for each read:write mix of the fused kernels, with no
+// arithmetic to speak of.  NIN streams of TIn in (16-byte nt loads: 2 doubles or 4 floats per lane)
+// and, if WRITE, one float64 stream out (16-byte stores): K1 is 2 in / read-only, a held-field
+// global pass 1 in / read-only, the local pass with delta_rho 2 in / 1 out (16 B + 8 B per cell at
+// float64, 8 B + 8 B at float32), a held-field local pass 1 in / 1 out, the eta-only passes
+// read-only.  Without WRITE the values are summed into a per-thread sink that is stored only if it
+// equals a value no data produces (keeps the loads alive, writes nothing).
+//
+// Shape (round 5, scripts/tune_probe.hip, profiles/r05_tune_probe*.log): ONE TILE PER BLOCK -- a
+// block loads U packs per thread and stream, stores, and ends -- with U and the store policy picked
+// per mix from the sweep.  Round 4's shape (a grid-stride loop, 65536 blocks, one pack in flight
+// per thread) read 3.7 TB/s for "1 x float32 in, 1 x float64 out" on a box where this one reads
+// 6.0, and the kernel it was meant to bound ran at 5.1: a probe slower than the kernel is not a
+// ceiling.  (Beyond 2^23 tiles the blocks stride over the tiles: a HIP grid holds < 2^32 threads.)
+constexpr int64_t kProbeMaxBlocks = (int64_t)1 << 23;
+template <typename TIn, int NIN, bool WRITE, int U, bool NTS>
 __global__ __launch_bounds__(kBlock) void k_stream_probe_mix(const TIn* __restrict__ a,
                                                              const TIn* __restrict__ b,
                                                              int64_t npacks,
                                                              double* __restrict__ out) {
   constexpr int VEC = 16 / sizeof(TIn);
   double sink = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < npacks;
-       i += (int64_t)gridDim.x * kBlock) {
-    const Pack<TIn, VEC> x = load_pack<TIn, VEC, true>(a + VEC * i);
-    Pack<double, VEC> r;
+  const int64_t ntiles = (npacks + kBlock * U - 1) / (kBlock * U);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t base = tile * (kBlock * U) + threadIdx.x;
+    Pack<TIn, VEC> x[U], y[U];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) r.v[k] = (double)x.v[k];
-    if constexpr (NIN == 2) {
-      const Pack<TIn, VEC> y = load_pack<TIn, VEC, true>(b + VEC * i);
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) r.v[k] += (double)y.v[k];
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + (int64_t)u * kBlock;
+      if (i < npacks) {
+        x[u] = load_pack<TIn, VEC, true>(a + VEC * i);
+        if constexpr (NIN == 2) y[u] = load_pack<TIn, VEC, true>(b + VEC * i);
+      }
     }
-    if constexpr (WRITE) {
-      store_pack<VEC, true>(out + VEC * i, r);
-    } else {
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) sink += r.v[k];
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + (int64_t)u * kBlock;
+      if (i < npacks) {
+        Pack<double, VEC> r;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          r.v[k] = (double)x[u].v[k];
+          if constexpr (NIN == 2) r.v[k] += (double)y[u].v[k];
+        }
+        if constexpr (WRITE) {
+          store_pack<VEC, NTS>(out + VEC * i, r);
+        } else {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) sink += r.v[k];
+        }
+      }
     }
   }
   if constexpr (!WRITE) {
@@ -1567,6 +1572,18 @@ int steric_local_impl(const void* T, const void* S, const void* T0, const void* 
 
 }  // namespace
 
+// (U, nontemporal store) per mix: the fastest shape of scripts/tune_probe.hip's sweep on hashed
+// data -- profiles/r05_tune_probe_hashed.log
+template <typename TIn, int NIN, bool WRITE, int U, bool NTS>
+static int launch_probe_mix(const void* a, const void* b, int64_t npacks, double* out,
+                            hipStream_t st) {
+  const int64_t ntiles = ceil_div(npacks, (int64_t)kBlock * U);
+  const dim3 grid((unsigned)(ntiles < kProbeMaxBlocks ? ntiles : kProbeMaxBlocks));
+  hipLaunchKernelGGL((k_stream_probe_mix<TIn, NIN, WRITE, U, NTS>), grid, dim3(kBlock), 0, st,
+                     (const TIn*)a, (const TIn*)b, npacks, out);
+  return hip_status(hipGetLastError(), "k_stream_probe_mix launch");
+}
+
 extern "C" {
 
 int mlx_version(void) { return MLX_ABI_VERSION; }
@@ -1838,17 +1855,6 @@ int mlx_calc_dz(const double* z_i, const double* depth, int64_t nz, int64_t plan
   return hip_status(hipGetLastError(), "k_calc_dz launch");
 }
 
-int mlx_stream_probe(const double* a, const double* b, int64_t n, double* out, void* stream) {
-  if (!a || !b || !out) return fail(MLX_E_NULL, "a, b, out must not be NULL");
-  if (n <= 0 || n % 2) return fail(MLX_E_SHAPE, "n must be > 0 and even");
-  if (!aligned(a, 16) || !aligned(b, 16) || !aligned(out, 16))
-    return fail(MLX_E_ALIGN, "operands must be 16-byte aligned");
-  const int64_t want = ceil_div(n / 2, kBlock);
-  hipLaunchKernelGGL(k_stream_probe, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(kBlock), 0,
-                     (hipStream_t)stream, a, b, n / 2, out);
-  return hip_status(hipGetLastError(), "k_stream_probe launch");
-}
-
 int mlx_stream_probe_mix(const void* a, const void* b, int dtype, int64_t n, double* out,
                          int write_out, void* stream) {
   if (!a || !out) return fail(MLX_E_NULL, "a and out must not be NULL");
@@ -1859,21 +1865,24 @@ int mlx_stream_probe_mix(const void* a, const void* b, int dtype, int64_t n, dou
   if (!aligned(a, 16) || (b && !aligned(b, 16)) || !aligned(out, write_out ? 16 : 8))
     return fail(MLX_E_ALIGN, "operands must be 16-byte aligned");
   const int64_t npacks = n / vec;
-  const int64_t want = ceil_div(npacks, kBlock);
-  const dim3 grid((unsigned)(want < 65536 ? want : 65536));
   hipStream_t st = (hipStream_t)stream;
-#define MLX_LAUNCH_PROBE(TIN, NIN, WRITE)                                                        \
-  hipLaunchKernelGGL((k_stream_probe_mix<TIN, NIN, WRITE>), grid, dim3(kBlock), 0, st,            \
-                     (const TIN*)a, (const TIN*)b, npacks, out)
   if (dtype == MLX_DTYPE_F64) {
-    if (b) { if (write_out) MLX_LAUNCH_PROBE(double, 2, true); else MLX_LAUNCH_PROBE(double, 2, false); }
-    else { if (write_out) MLX_LAUNCH_PROBE(double, 1, true); else MLX_LAUNCH_PROBE(double, 1, false); }
-  } else {
-    if (b) { if (write_out) MLX_LAUNCH_PROBE(float, 2, true); else MLX_LAUNCH_PROBE(float, 2, false); }
-    else { if (write_out) MLX_LAUNCH_PROBE(float, 1, true); else MLX_LAUNCH_PROBE(float, 1, false); }
+    if (b) return write_out ? launch_probe_mix<double, 2, true, 1, true>(a, b, npacks, out, st)
+                            : launch_probe_mix<double, 2, false, 2, true>(a, b, npacks, out, st);
+    return write_out ? launch_probe_mix<double, 1, true, 1, true>(a, b, npacks, out, st)
+                     : launch_probe_mix<double, 1, false, 2, true>(a, b, npacks, out, st);
   }
-#undef MLX_LAUNCH_PROBE
-  return hip_status(hipGetLastError(), "k_stream_probe_mix launch");
+  if (b) return write_out ? launch_probe_mix<float, 2, true, 4, false>(a, b, npacks, out, st)
+                          : launch_probe_mix<float, 2, false, 8, true>(a, b, npacks, out, st);
+  return write_out ? launch_probe_mix<float, 1, true, 1, false>(a, b, npacks, out, st)
+                   : launch_probe_mix<float, 1, false, 2, true>(a, b, npacks, out, st);
+}
+
+// the 2 x float64 in / 1 x float64 out mix under its round-2 name
+int mlx_stream_probe(const double* a, const double* b, int64_t n, double* out, void* stream) {
+  if (!a || !b || !out) return fail(MLX_E_NULL, "a, b, out must not be NULL");
+  if (n <= 0 || n % 2) return fail(MLX_E_SHAPE, "n must be > 0 and even");
+  return mlx_stream_probe_mix(a, b, MLX_DTYPE_F64, n, out, 1, stream);
 }
 
 int mlx_valu_probe(int64_t iters, double* out, int64_t* lane_instructions, void* stream) {

@@ -3,7 +3,7 @@
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  The
 (yh, xh) plane is tiled across ranks (1x2, 2x2, 2x4); every rank runs K1 on its
 own tile for all z and t -- the tiles are independent, nothing is exchanged on
-the data path -- and the only collective is an ``all_reduce(SUM)`` of the packed
+the data path -- and the only collective is the sum over the ranks of the packed
 float64 vector
 
     [ masso(t) for every time step of the chunk | volo | masso0 | sum(areacello) ]
@@ -13,9 +13,20 @@ latency-bound, a few tens of microseconds on xGMI, asynchronous and overlapped w
 chunk's kernels).  A record that fits in HBM can go as ONE chunk; a 1200-step record
 (BASELINE.json configs[3]) is walked in chunks, from resident tensors, host arrays or a
 generator (``steric_global_tile_streamed``).  Every rank
-then evaluates ``h_ref * ln(rhoga0 * volo / masso(t))`` redundantly.  masso0 and
-masso(t) travel in the same vector and are summed in the same rank order, so
-``steric[t=0] == 0`` holds exactly for any world size, as on one GPU.
+then evaluates ``h_ref * ln(rhoga0 * volo / masso(t))`` redundantly.
+
+The sum is RANK-ORDERED (``rank_ordered_sum``): one RCCL collective moves every rank's vector to
+every rank (``all_gather_into_tensor``: world x (nt_chunk+3) doubles, still latency-bound) and each
+rank adds the rows 0, 1, ..., N-1 in that order in float64.  Every ELEMENT of the vector is thereby
+reduced in the same order -- which a library all-reduce does not promise: a ring reduces segment k
+of the vector starting at rank k, so masso0 and masso(t=0) -- the same per-rank partials at two
+positions of the vector -- came out 1 ulp apart in the round-5 rehearsal of the 8-rank 2x4 layout
+over gloo (``steric[t=0] = 1.7e-15`` instead of 0; 2 ranks cannot show it, a + b is commutative).
+With the ordered sum ``steric[t=0] == 0`` holds exactly for any world size, as on one GPU and in
+the reference, for every variant; the result is bit-identical on all ranks, from run to run, and
+between backends (what the gloo rehearsals compute is what RCCL will).  ``MOMLEVEL_AMD_EXCHANGE=
+allreduce`` selects the library's own ``all_reduce(SUM)`` instead (same bytes on the wire per rank
+up to the factor N; results within 1 ulp per element of the ordered sum, no exact-zero guarantee).
 
 The local variants need no collective at all (columns are independent): each
 rank simply runs ``engine.local_steric`` on its tile.
@@ -122,6 +133,63 @@ def launch_local_ranks(n, argv, environ=None, visible_gpus=None, out=None, grace
     return max((abs(c) for c in codes), default=0)
 
 
+def exchange_mode():
+    """"ordered" (default: all-gather + rank-ordered float64 sum) or "allreduce" (the library's
+    all_reduce(SUM)); see the module docstring."""
+    mode = os.environ.get("MOMLEVEL_AMD_EXCHANGE", "ordered")
+    if mode not in ("ordered", "allreduce"):
+        raise ValueError(f"MOMLEVEL_AMD_EXCHANGE={mode!r}: 'ordered' or 'allreduce'")
+    return mode
+
+
+def _in_a_world(group=None, force=False):
+    return (dist.is_available() and dist.is_initialized()
+            and (dist.get_world_size(group) > 1 or force))
+
+
+def rank_ordered_sum(gathered):
+    """(world, n) float64 numpy array of every rank's vector -> their sum, adding the ranks'
+    rows in rank order 0, 1, ..., world-1 (explicitly: numpy's own reduction order over a leading
+    axis is an implementation detail).  Host arithmetic on a few hundred doubles: part of the
+    replicated host epilogue, like the logarithm that follows it."""
+    gathered = np.asarray(gathered, dtype=np.float64)
+    acc = gathered[0].copy()
+    for r in range(1, gathered.shape[0]):
+        acc += gathered[r]
+    return acc
+
+
+class _Exchange:
+    """One sum-over-ranks of a packed float64 vector, started asynchronously.  ``start`` enqueues the
+    collective (RCCL: on its own stream behind the kernels that produced ``vec``; gloo with a device
+    vector -- a rehearsal on fewer GPUs than ranks -- stages through the host and is synchronous);
+    ``result()`` waits and returns the sum as a float64 numpy vector on the host."""
+
+    def __init__(self, vec, group=None):
+        self.mode = exchange_mode()
+        self.work = None
+        world = dist.get_world_size(group)
+        if vec.is_cuda and dist.get_backend(group) == "gloo":
+            vec = vec.cpu()
+        vec = vec.contiguous()
+        if self.mode == "allreduce":
+            self.buf = vec.clone()
+            self.work = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        else:
+            # (flat: rank r's vector lands at [r*n, (r+1)*n) -- the layout gloo and RCCL share)
+            self.buf = torch.empty(world * vec.numel(), dtype=vec.dtype, device=vec.device)
+            self.work = dist.all_gather_into_tensor(self.buf, vec.reshape(-1), group=group,
+                                                    async_op=True)
+        self.world = world
+
+    def result(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        host = self.buf.cpu().numpy()  # (a device buffer: synchronises with the collective)
+        return host if self.mode == "allreduce" else rank_ordered_sum(host.reshape(self.world, -1))
+
+
 def pack_partials(masso, volo, masso0, area_sum):
     """-> one float64 vector [masso(0..nt-1), volo, masso0, area_sum] on masso's device."""
     tail = torch.stack([
@@ -132,20 +200,18 @@ def pack_partials(masso, volo, masso0, area_sum):
 
 
 def exchange_global(masso, volo, masso0, area_sum, group=None):
-    """The path's single exchange step: all-reduce the packed partial sums.
+    """The path's single exchange step: the packed partial sums, summed over the ranks in rank
+    order (module docstring).
 
     Works on device tensors with RCCL ("nccl") and on CPU tensors with gloo.
-    Without an initialised process group (single GPU) it is the identity.
-    Returns (masso (nt,), volo, masso0, area_sum) as tensors on the input device.
+    Without an initialised process group (single GPU) it is the identity (nothing is copied or
+    synchronised: the inputs come back as they are); in a world of several ranks the sums come
+    back as float64 HOST tensors -- ``finalize`` takes either.
+    Returns (masso (nt,), volo, masso0, area_sum).
     """
     vec = pack_partials(masso, volo, masso0, area_sum)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        if vec.is_cuda and dist.get_backend(group) == "gloo":  # rehearsal path, see init_from_env
-            host = vec.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-            vec = host.to(vec.device)
-        else:
-            dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
+    if _in_a_world(group):
+        vec = torch.from_numpy(_Exchange(vec, group).result())
     nt = vec.numel() - 3
     return vec[:nt], vec[nt], vec[nt + 1], vec[nt + 2]
 
@@ -172,28 +238,29 @@ _VARIANTS = ("steric", "thermosteric", "halosteric")
 
 
 class ChunkedExchange:
-    """The data-path collective of the tiled global variants, one all-reduce PER TIME CHUNK
+    """The data-path collective of the tiled global variants, one exchange PER TIME CHUNK
     (SURVEY.md 8e): chunk k contributes the packed float64 vector
 
         [ masso_v(t) for every requested row v and every step t of the chunk ]
         ++ [ volo, masso0, sum(areacello) ]            (first chunk only)
 
-    (``(rows*nt_chunk + 3) * 8`` bytes: latency-bound).  With RCCL the all-reduce is asynchronous:
-    it is enqueued behind the chunk's kernels and overlaps the next chunk's, and nothing is read
-    back before ``finish()``.  Without a process group (one GPU) it is the identity.  The class
-    knows nothing about kernels: ``add`` takes the rank's partial sums as tensors (device tensors
-    from K1 in the product; the gloo tests feed it host tensors).
+    (``(rows*nt_chunk + 3) * 8`` bytes: latency-bound), summed over the ranks in rank order
+    (module docstring: one all-gather + an ordered host sum; MOMLEVEL_AMD_EXCHANGE=allreduce for
+    the library's all-reduce).  With RCCL the collective is asynchronous: it is enqueued behind the
+    chunk's kernels and overlaps the next chunk's, and nothing is read back before ``finish()``.
+    Without a process group (one GPU) it is the identity.  The class knows nothing about kernels:
+    ``add`` takes the rank's partial sums as tensors (device tensors from K1 in the product; the
+    gloo tests feed it host tensors).
     """
 
     def __init__(self, nrows, group=None, force=False):
         """``force``: run the collective even in a world of ONE rank (a sum over one rank is the
-        identity) -- how the RCCL leg (communicator, asynchronous all-reduce on its own stream,
+        identity) -- how the RCCL leg (communicator, asynchronous collective on its own stream,
         ``work.wait()`` ordering) is exercised on a single-GPU box (tests/test_gpu_config4.py)."""
         self.nrows = nrows
         self.group = group
-        self._pending = []  # (vector, work handle or None, nt_chunk, has_tail)
-        self.active = (dist.is_available() and dist.is_initialized()
-                       and (dist.get_world_size(group) > 1 or force))
+        self._pending = []  # (vector or _Exchange, nt_chunk, has_tail)
+        self.active = _in_a_world(group, force)
 
     def add(self, rows, tail=None):
         """rows: (nrows, nt_chunk) partial sums of this rank; tail: (volo, masso0, area_sum)
@@ -204,22 +271,16 @@ class ChunkedExchange:
             parts += [torch.as_tensor(v, dtype=torch.float64, device=rows.device).reshape(1)
                       for v in tail]
         vec = torch.cat(parts)
-        work = None
-        if self.active:
-            if vec.is_cuda and dist.get_backend(self.group) == "gloo":
-                host = vec.cpu()  # rehearsal on fewer GPUs than ranks: staged through the host
-                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
-                vec = host.to(vec.device)
-            else:
-                work = dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._pending.append((vec, work, rows.shape[1], tail is not None))
+        self._pending.append((_Exchange(vec, self.group) if self.active else vec,
+                              rows.shape[1], tail is not None))
 
     def finish(self):
-        """-> (rows (nrows, nt) tensor, volo, masso0, area_sum) of the whole grid."""
+        """-> (rows (nrows, nt) tensor, volo, masso0, area_sum) of the whole grid: float64 host
+        tensors after an exchange, the tensors that were added (untouched) without one."""
         out, tail = [], None
-        for vec, work, ntc, has_tail in self._pending:
-            if work is not None:
-                work.wait()
+        for vec, ntc, has_tail in self._pending:
+            if isinstance(vec, _Exchange):
+                vec = torch.from_numpy(vec.result())
             n = self.nrows * ntc
             out.append(vec[:n].reshape(self.nrows, ntc))
             if has_tail:
@@ -370,17 +431,17 @@ def steric_local_tile(T, S, vol0, pres, z_i, deptho, rhozero=1035.0, variant="st
 # the public, labelled API on ONE RANK'S TILE: same signatures as momlevel_amd.steric & co.
 # ---------------------------------------------------------------------------------------------
 def _sum_over_ranks(group=None):
-    """-> callable summing a float64 numpy vector over the ranks (identity without a group)."""
+    """-> callable summing a float64 numpy vector over the ranks in rank order (identity without
+    a group)."""
 
     def exchange(vec):
         vec = np.ascontiguousarray(vec, dtype=np.float64)
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        if not _in_a_world(group):
             return vec
         t = torch.from_numpy(vec.copy())
         if dist.get_backend(group) == "nccl":
             t = t.cuda()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        return t.cpu().numpy()
+        return _Exchange(t, group).result()
 
     return exchange
 
@@ -393,7 +454,7 @@ def steric(dset, reference=None, coord_names=None, varname_map=None, rhozero=103
     rank's own ``(yh, xh)`` tile of thetao / so / volcello / areacello (/ deptho).  Arguments and
     the ``(result, reference)`` return value are those of ``steric`` (src/momlevel/steric.py:17-31).
 
-    Collectives per call (all latency-bound all-reduces of a few doubles, RCCL over xGMI):
+    Collectives per call (all latency-bound rank-ordered sums of a few doubles, RCCL over xGMI):
       * every domain: an error flag, then sum(areacello) over the tiles (the range check of
         util.validate_areacello is about the whole ocean), then two more error flags around the
         reference state -- a rank that finds its tile unusable makes EVERY rank raise instead of

@@ -85,15 +85,10 @@ def main(src, prefix, kernel="k_steric_global"):
             summary["hbm_traffic_bytes_per_launch"] / summary["cells_per_launch"])
     # the sha bench.py compares against: a counter profile is quoted only for the sources it was
     # taken on (bench.py kernel_source_sha)
-    import hashlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from momlevel_amd.csrc.build import source_sha
 
-    h = hashlib.sha256()
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for rel in ("momlevel_amd/csrc/momlevel_hip.hip", "momlevel_amd/csrc/eos_device.hpp",
-                "momlevel_amd/csrc/mlx_internal.hpp"):
-        with open(os.path.join(root, rel), "rb") as f:
-            h.update(f.read())
-    summary["kernel_source_sha"] = h.hexdigest()[:16]
+    summary["kernel_source_sha"] = source_sha()
     json.dump(summary, open(prefix + "_summary.json", "w"), indent=1)
     print(json.dumps(summary, indent=1))
 

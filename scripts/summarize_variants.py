@@ -22,27 +22,8 @@ import sys
 MAIN = tuple(os.environ.get("MLX_SUMMARY_MAIN", "k_steric_global,k_steric_local").split(","))
 
 
-def kernel_source_sha():
-    """sha256 (first 16 hex digits) of the HIP sources of the timed kernels -- the same files, in the
-    same order, as bench.py's kernel_source_sha()"""
-    import hashlib
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    h = hashlib.sha256()
-    for rel in ("momlevel_amd/csrc/momlevel_hip.hip", "momlevel_amd/csrc/eos_device.hpp",
-                "momlevel_amd/csrc/mlx_internal.hpp"):
-        with open(os.path.join(root, rel), "rb") as f:
-            h.update(f.read())
-    return h.hexdigest()[:16]
-
-
-def strat_source_sha():
-    """sha256 (16 hex digits) of csrc/momlevel_strat.hip: the stratification kernels' own guard"""
-    import hashlib
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "momlevel_amd", "csrc", "momlevel_strat.hip"), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from momlevel_amd.csrc.build import source_sha as kernel_source_sha, strat_source_sha  # noqa: E402
 
 
 def one(pattern):

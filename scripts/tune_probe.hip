@@ -117,14 +117,37 @@ static void sweep_u(Ctx c, const char* name) {
   sweep<TIn, NIN, WRITE, 8>(c, name);
 }
 
+// fill with values that look like theta/S (a splitmix hash of the index): HBM bandwidth should not
+// depend on the data, but power (and with it the clocks) may -- zeros toggle nothing
+__global__ void k_fill(double* x, int64_t n, uint64_t seed) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    uint64_t z = (uint64_t)i + seed + 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; z ^= z >> 31;
+    x[i] = -2.0 + 34.0 * (double)(z >> 11) * 0x1.0p-53;
+  }
+}
+
 int main(int argc, char** argv) {
   const double gib = argc > 1 ? atof(argv[1]) : 8.0;
+  const int fill = argc > 2 ? atoi(argv[2]) : 0;      // 1: hashed values instead of zeros
+  const int ro = argc > 3 ? atoi(argv[3]) : 0;        // 1: read-only mixes only (no output stream)
   const int64_t n = (int64_t)(gib * (1 << 30) / 8) / 4096 * 4096;  // elements per stream
   void *a, *b; double* out;
-  CK(hipMalloc(&a, n * 8)); CK(hipMalloc(&b, n * 8)); CK(hipMalloc((void**)&out, n * 8));
-  CK(hipMemset(a, 0, n * 8)); CK(hipMemset(b, 0, n * 8)); CK(hipMemset(out, 0, n * 8));
-  printf("elements per stream: %lld (%.1f GiB of float64)\n", (long long)n, n * 8.0 / (1 << 30));
+  CK(hipMalloc(&a, n * 8)); CK(hipMalloc(&b, n * 8)); CK(hipMalloc((void**)&out, ro ? 4096 : n * 8));
+  CK(hipMemset(a, 0, n * 8)); CK(hipMemset(b, 0, n * 8)); CK(hipMemset(out, 0, ro ? 4096 : n * 8));
+  if (fill) {
+    hipLaunchKernelGGL(k_fill, dim3(65536), dim3(256), 0, 0, (double*)a, n, 1ull);
+    hipLaunchKernelGGL(k_fill, dim3(65536), dim3(256), 0, 0, (double*)b, n, 77ull);
+    CK(hipDeviceSynchronize());
+  }
+  printf("elements per stream: %lld (%.1f GiB of float64), %s, %s\n", (long long)n,
+         n * 8.0 / (1 << 30), fill ? "hashed values" : "zeros", ro ? "read-only mixes" : "all mixes");
   Ctx c{a, b, out, n, 0};
+  if (ro) {
+    sweep_u<double, 1, false>(c, "1 x f64 in, read-only");
+    sweep_u<double, 2, false>(c, "2 x f64 in, read-only");
+    return 0;
+  }
   sweep_u<double, 1, false>(c, "1 x f64 in, read-only");
   sweep_u<double, 2, false>(c, "2 x f64 in, read-only");
   sweep_u<double, 1, true>(c, "1 x f64 in, 1 x f64 out");

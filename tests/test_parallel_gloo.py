@@ -141,11 +141,42 @@ def test_eight_ranks_tile_the_plane_two_by_four():
         synthetic.tile_bounds(1080, 1442, 0, 8)
 
 
+def test_rank_ordered_sum_adds_rank_by_rank():
+    """every element of the packed vector is reduced in the SAME order -- rank 0, 1, ..., N-1 -- so
+    equal per-rank partials at two positions (masso0 and masso(t=0)) give equal sums.  A library
+    ring all-reduce reduces segment k starting at rank k: with 8 ranks the 8-rank gloo rehearsal
+    measured steric[t=0] = 1.7e-15 instead of 0 (parallel.py, module docstring)."""
+    r = np.random.default_rng(5)
+    col = r.normal(1e18, 1e17, 8)
+    g = np.stack([col, r.normal(0, 1, 8), col], axis=1)  # the same partials at positions 0 and 2
+    got = parallel.rank_ordered_sum(g)
+    acc = 0.0
+    for v in col:
+        acc = acc + v if acc else v
+    assert got[0] == got[2] == acc
+    assert got.dtype == np.float64 and got.shape == (3,)
+    # a different rank order of the same numbers differs in the last bits (why the order matters)
+    others = {float(parallel.rank_ordered_sum(g[np.roll(np.arange(8), k)])[0]) for k in range(8)}
+    assert len(others) > 1
+
+
+def test_exchange_mode_is_validated(monkeypatch):
+    assert parallel.exchange_mode() == "ordered"
+    monkeypatch.setenv("MOMLEVEL_AMD_EXCHANGE", "allreduce")
+    assert parallel.exchange_mode() == "allreduce"
+    monkeypatch.setenv("MOMLEVEL_AMD_EXCHANGE", "ring")
+    with pytest.raises(ValueError):
+        parallel.exchange_mode()
+
+
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 8])
-def test_chunked_exchange_all_variants(world):
-    """one all-reduce per time chunk, several rows per chunk: result == the single
-    domain for every variant, eta[0] == 0 exactly, ranks bit-identical"""
+@pytest.mark.parametrize("world,exchange", [(2, "ordered"), (8, "ordered"), (8, "allreduce")])
+def test_chunked_exchange_all_variants(world, exchange, monkeypatch):
+    """one exchange per time chunk, several rows per chunk: result == the single
+    domain for every variant, ranks bit-identical; eta[0] == 0 EXACTLY with the default
+    rank-ordered sum at any world size -- the library all-reduce (MOMLEVEL_AMD_EXCHANGE=allreduce)
+    only promises 1 ulp"""
+    monkeypatch.setenv("MOMLEVEL_AMD_EXCHANGE", exchange)  # (spawned workers inherit it)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -162,7 +193,10 @@ def test_chunked_exchange_all_variants(world):
         ref, refstate = o.steric(T, S, vol4, g["areacello"], g["z_l"], domain="global",
                                  variant=variant)
         for rank, etas, massos, heat, volo, area in results:
-            assert etas[i][0] == 0.0
+            if exchange == "ordered":
+                assert etas[i][0] == 0.0
+            else:
+                assert abs(etas[i][0] / (volo / area)) <= 1e-14
             assert np.allclose(massos[i], ref["masso"], rtol=1e-13, atol=0)
             href = volo / area
             assert np.allclose(etas[i] / href, ref["expansion_coeff"], rtol=0, atol=1e-12)
