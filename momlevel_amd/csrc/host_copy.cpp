@@ -16,7 +16,9 @@
 // of momlevel_hip.hip so that the kernel sources' hash (bench.py, profiles/) does not move with it.
 // (hipcc compiles every source of the library twice; there is nothing here for the gfx950 pass)
 #if !defined(__HIP_DEVICE_COMPILE__)
+#if defined(__x86_64__)
 #include <immintrin.h>
+#endif
 #include <pthread.h>
 
 #include <atomic>
@@ -39,6 +41,7 @@ __attribute__((visibility("hidden"))) int fail(int code, const char* msg);
 
 namespace {
 
+#if defined(__x86_64__)
 __attribute__((target("avx2"))) void copy_stream_avx2(unsigned char* d, const unsigned char* s,
                                                         size_t n) {
   // head: up to the first 32-byte boundary of the destination
@@ -61,6 +64,11 @@ __attribute__((target("avx2"))) void copy_stream_avx2(unsigned char* d, const un
   _mm_sfence();  // the streaming stores are globally visible before the slice is reported done
   std::memcpy(d, s, n - blocks * 128);
 }
+bool have_streaming_stores() { return __builtin_cpu_supports("avx2"); }
+#else  // any other host: libc's memcpy (which picks its own non-temporal path above a threshold)
+void copy_stream_avx2(unsigned char* d, const unsigned char* s, size_t n) { std::memcpy(d, s, n); }
+bool have_streaming_stores() { return false; }
+#endif
 
 void copy_slice(unsigned char* d, const unsigned char* s, size_t n, bool streaming) {
   if (streaming && n >= 4096)
@@ -150,7 +158,7 @@ extern "C" int mlx_host_copy(void* dst, const void* src, size_t nbytes, int thre
     return mlx::detail::fail(MLX_E_SHAPE, "a range wraps around the address space");
   if (da < sa + nbytes && sa < da + nbytes)
     return mlx::detail::fail(MLX_E_SHAPE, "dst and src overlap");
-  const bool stream_stores = streaming != 0 && __builtin_cpu_supports("avx2");
+  const bool stream_stores = streaming != 0 && have_streaming_stores();
   // slices of whole pages, at least 1 MiB each: below that a hand-over costs more than it saves
   size_t slice = (nbytes + static_cast<size_t>(threads) - 1) / static_cast<size_t>(threads);
   if (slice < (size_t(1) << 20)) slice = size_t(1) << 20;
@@ -160,11 +168,23 @@ extern "C" int mlx_host_copy(void* dst, const void* src, size_t nbytes, int thre
     copy_slice(d, s, nbytes, stream_stores);
     return 0;
   }
-  Team* t = team();
-  std::atomic<int> remaining(parts - 1);
-  bool shared = true;
+  // No C++ exception leaves this extern "C" function: whatever cannot be handed to the
+  // team -- no team (bad_alloc), no worker thread to be had, no room in the queue -- is copied by
+  // this thread.  Slices that WERE queued point at `remaining` on this stack, so from the first
+  // push_back on the function only returns once they are all done.
+  Team* t = nullptr;
+  try {
+    t = team();
+  } catch (...) {
+  }
+  if (t == nullptr) {
+    copy_slice(d, s, nbytes, stream_stores);
+    return 0;
+  }
+  std::atomic<int> remaining(0);
+  int queued = 0;  // slices 1..queued are the team's, 0 and queued+1..parts-1 this thread's
   {
-    std::lock_guard<std::mutex> lk(t->m);
+    std::lock_guard<std::mutex> lk(t->m);  // (workers cannot take a slice before this is released)
     try {
       while (t->workers < parts - 1) {
         std::thread(worker, t).detach();
@@ -172,23 +192,27 @@ extern "C" int mlx_host_copy(void* dst, const void* src, size_t nbytes, int thre
       }
     } catch (...) {  // no more threads to be had: the workers there are do it
     }
-    if (t->workers == 0)
-      shared = false;  // none at all: this thread copies everything
-    else
-      for (int i = 1; i < parts; ++i) {
-        const size_t off = static_cast<size_t>(i) * slice;
-        const size_t n = (off + slice <= nbytes) ? slice : nbytes - off;
-        t->queue.push_back(Slice{d + off, s + off, n, stream_stores, &remaining});
+    if (t->workers > 0) {
+      try {
+        for (int i = 1; i < parts; ++i) {
+          const size_t off = static_cast<size_t>(i) * slice;
+          const size_t n = (off + slice <= nbytes) ? slice : nbytes - off;
+          t->queue.push_back(Slice{d + off, s + off, n, stream_stores, &remaining});
+          ++queued;
+        }
+      } catch (...) {  // bad_alloc in the deque: what is queued stays queued, the rest is ours
       }
+    }
+    remaining.store(queued, std::memory_order_release);
   }
-  if (!shared) {
-    copy_slice(d, s, nbytes, stream_stores);
-    return 0;
-  }
-  t->work.notify_all();
+  if (queued > 0) t->work.notify_all();
   copy_slice(d, s, slice, stream_stores);  // this thread's own share
-  std::unique_lock<std::mutex> lk(t->m);
-  t->done.wait(lk, [&remaining] { return remaining.load(std::memory_order_acquire) == 0; });
+  const size_t done_to = static_cast<size_t>(queued + 1) * slice;
+  if (done_to < nbytes) copy_slice(d + done_to, s + done_to, nbytes - done_to, stream_stores);
+  if (queued > 0) {
+    std::unique_lock<std::mutex> lk(t->m);
+    t->done.wait(lk, [&remaining] { return remaining.load(std::memory_order_acquire) == 0; });
+  }
   return 0;
 }
 #endif  // !__HIP_DEVICE_COMPILE__

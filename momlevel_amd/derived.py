@@ -286,6 +286,16 @@ def _stratification(func, thetao, so, pres, eos, zcoord, gravity=-9.8):
     util.eos_func_from_str(eos, func_name="alpha")  # unknown EOS: the reference's ValueError
     zi, nt, nz, plane = _z_layout(thetao, zcoord)
     z = _level_values(thetao, zcoord)
+    if f32 and str(z.dtype) == "float32":
+        # numpy.gradient takes its coefficients from the coordinate IN THE COORDINATE'S dtype: with a
+        # float32 z and float32 fields the edge rows (every row of an uneven grid) are float32
+        # arithmetic, and calc_n2's own pressure `thetao[zcoord] * 1e4 + patm` is float32 too, so
+        # that numpy evaluates alpha, beta and N^2 in float32 throughout.  The kernel forms the
+        # derivative in float64 and rounds once: not numpy's bits -- refused, like a
+        # float32 pressure on float32 fields.
+        raise TypeError(f"float32 thetao/so with a float32 {zcoord!r} coordinate: numpy would "
+                        "differentiate (and calc_n2 build its pressure) in float32, which no kernel "
+                        "here restates; convert the coordinate to float64")
     dev = engine.device_of(thetao.data, so.data)
     dt = torch.float32 if f32 else torch.float64
     p = None if eos.lower() == "linear" else _strat_pressure(pres, thetao, zcoord, dev, f32)
@@ -314,7 +324,9 @@ def _stratification_host_rows(T, S, p, z, nt, nz, plane, dev, lead=None, **kw):
     group k's kernel runs and group k-1's result leaves (hostio.Downloader).  ``lead``: the
     fields are (lead, nz, ...) with ONE dimension before z (the usual (time, z, y, x)): they are
     then sliced along it as they are -- a lazy field (dask / netCDF4 / h5py-like) is read group by
-    group in the upload worker and never materialised whole."""
+    group in the upload worker and never materialised whole.  (A pressure that varies from row to
+    row -- ``p`` of shape (nt, nz, plane) -- IS resident whole: _strat_pressure expanded it before
+    the groups start; only theta/S and the result are streamed.)"""
     if lead is not None:
         Tn, Sn = T, S  # sliced along their own leading axis
     else:
@@ -350,7 +362,10 @@ def calc_n2(thetao, so, eos="Wright", gravity=-9.8, patm=101325.0, zcoord="z_l",
     ``gravity * ((alpha * dT/dz) - (beta * dS/dz))`` with alpha, beta at
     ``p = thetao[zcoord] * 1e4 + patm`` and d/dz = ``differentiate(zcoord, edge_order=2)``.
     ``interfaces`` (the cell-edge variant) interpolates with xgcm's ``Grid.transform`` in the
-    reference: not built."""
+    reference: not built.  Deviations, deliberate: ``adjust_negative=True`` forwards ``zcoord``
+    (the reference calls ``adjust_negative_n2(n2)`` with its default "z_l", derived.py:409, and so
+    fails on any other name); float32 fields need a float64 coordinate (TypeError otherwise, see
+    _stratification)."""
     if interfaces is not None:
         raise NotImplementedError("calc_n2(interfaces=...) needs xgcm's linear vertical transform "
                                   "(derived.py:389-394): not built; pass interfaces=None")
@@ -399,7 +414,9 @@ def adjust_negative_n2(n2, zcoord="z_l"):
     """Remove negative N^2 after Chelton et al. 1998 (derived.py:30-71): non-positive values
     become NaN, NaN at index 0 OF THE LEADING DIMENSION becomes 1e-8 (the reference writes
     ``adjusted[0]``: the first time step of a (time, z, y, x) field, the surface of a (z, y, x)
-    one), the rest is forward-filled down the column, the original NaN mask is put back."""
+    one), the rest is forward-filled down the column, the original NaN mask is put back.
+    Deviation: the result is float64 whatever ``n2``'s dtype (the reference keeps a float32 n2
+    float32 and writes float32(1e-8)); ``zcoord`` is an addition (the reference ffills "z_l")."""
     adjusted, _, _, _ = _adjust(n2, zcoord)
     adjusted = adjusted.reshape(tuple(n2.shape))
     out = DataArray(adjusted if n2.is_device else hostio.to_host(adjusted), n2.dims, dict(n2.coords))
@@ -414,7 +431,8 @@ def calc_wave_speed(n2, dz, zcoord="z_l"):
     the reference ``n2[0]`` indexes the leading dimension: for a (z, y, x) field it is the surface
     and the result has dims (y, x); for a (time, z, y, x) field it is the first TIME STEP, dims
     (z, y, x), which xarray broadcasts against the (time, y, x) speeds into (z, y, x, time) -- the
-    array whose sum the reference's own test holds (tests/test_derived.py:147-151)."""
+    array whose sum the reference's own test holds (tests/test_derived.py:147-151).  float64 out
+    whatever the dtype of ``n2`` (see adjust_negative_n2)."""
     _, speed, (zi, nt, nz, plane), x = _adjust(n2, zcoord, dz=dz, want_adjusted=False)
     trail_dims, trail_shape = tuple(n2.dims[zi + 1:]), tuple(n2.shape[zi + 1:])
     host = not n2.is_device

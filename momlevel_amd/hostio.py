@@ -46,6 +46,7 @@ _rings = {}
 _rings_lock = threading.Lock()
 
 _range_log = None
+_range_log_lock = threading.Lock()  # the caller's thread, the upload and the download workers all log
 
 
 def _log_range(kind, ptr, nbytes):
@@ -57,9 +58,12 @@ def _log_range(kind, ptr, nbytes):
     path = os.environ.get("MOMLEVEL_AMD_TRANSFER_LOG")
     if not path:
         return
-    if _range_log is None or _range_log.name != path:
-        _range_log = open(path, "a", buffering=1)
-    _range_log.write(f"{kind} [{ptr:#x}, {ptr + nbytes:#x}) {nbytes} bytes\n")
+    with _range_log_lock:  # one handle, whole lines: this log is the evidence if a fault recurs
+        if _range_log is None or _range_log.name != path:
+            if _range_log is not None:
+                _range_log.close()
+            _range_log = open(path, "a", buffering=1)
+        _range_log.write(f"{kind} [{ptr:#x}, {ptr + nbytes:#x}) {nbytes} bytes\n")
 
 
 class _Ring:

@@ -262,6 +262,12 @@ def test_errors():
         derived.calc_n2(T32, S32, eos="linear")
     with pytest.raises(TypeError):
         derived.calc_n2(T32, Sd)
+    # a float32 coordinate with float32 fields: numpy differentiates (and calc_n2 builds its
+    # pressure) in float32 -- refused rather than answered in other bits
+    z32 = {"z_l": DataArray(z.astype(np.float32), ("z_l",))}
+    with pytest.raises(TypeError, match="float32"):
+        derived.calc_n2(DataArray(T.astype(np.float32), dims, z32), DataArray(S.astype(np.float32), dims, z32))
+    derived.calc_n2(DataArray(T, dims, z32), DataArray(S, dims, z32))  # float64 fields: any coordinate
     n2 = derived.calc_n2(Td, Sd)
     with pytest.raises(ValueError):
         derived.calc_wave_speed(n2, DataArray(np.ones((5, 4)), ("z_l", "yh")))
