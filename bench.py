@@ -920,7 +920,7 @@ def local_variant_timings(T, S, vol0, pres, g, dev):
     # (few launches: ramp and tail paid less often) -- VERDICT r2 weak #5.
     free, _ = torch.cuda.mem_get_info(dev)
     big = int(min(nt, max(0, free - (6 << 30)) // (nz * ny * nx * 8)))
-    # whole time blocks of every K2 instantiation (12, 16 or 32 steps per thread at float64)
+    # whole time blocks of every K2 instantiation (8 or 16 steps per thread at float64)
     big = big // 96 * 96 if big >= 96 else (big // 48 * 48 if big >= 48 else big // 16 * 16)
     if big >= 32:
         dbig = torch.empty((big, nz, ny, nx), dtype=torch.float64, device=dev)

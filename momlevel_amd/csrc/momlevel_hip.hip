@@ -767,7 +767,7 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
     const double* __restrict__ z_i, const double* __restrict__ deptho,
     const double* __restrict__ p, int p_mode, int eos, double neg_inv_rhozero, int nt, int nz,
     int64_t plane, int64_t t_stride_T, int64_t t_stride_S, double* __restrict__ drho_out,
-    int64_t drho_vstride, double* __restrict__ eta_out, int64_t eta_vstride) {
+    int64_t drho_vstride, double* __restrict__ eta_out, int64_t eta_vstride, int ntb_major) {
   constexpr int NOUT = (VAR == kVarAll) ? 3 : 1;
   constexpr bool STREAM_T = (VAR != kVarHalo), STREAM_S = (VAR != kVarThermo);
   constexpr bool HELD_T = (VAR == kVarHalo || VAR == kVarAll);
@@ -781,9 +781,27 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
   // add_skipna form: +2-3 % at float32; at float64 neutral for the steric pass (round 3) and 0-2 %
   // for the held-field passes (round 4, profiles/r04_tune_k2_pred_held64.log: inside the scatter)
   constexpr bool PRED = sizeof(TIn) == 4;
-  const int64_t col = (xcd_remap(blockIdx.x, gridDim.x) * kBlock + threadIdx.x) * VEC;
+  // Block -> (column tile, time block).  ntb_major > 0 (round 5): a 1-D grid in which the ntb_major
+  // TIME BLOCKS OF ONE COLUMN TILE are consecutive workgroups of one XCD (workgroups are dealt
+  // round-robin over the 8 XCDs: ids b, b+8, b+16, ... share one, and with it an L2), so that the
+  // siblings run side by side and the time-invariant operands every one of them reads -- rho0m, dz,
+  // the held field: 8-16 B per cell and time block -- come from HBM once and from L2 for the other
+  // ntb_major-1.  With the time blocks on grid.y (ntb_major == 0) a tile's next time block starts
+  // a whole plane of blocks later and re-reads those lines from HBM.  Speed and traffic only:
+  // which thread sums which column in which order does not change.
+  int64_t tile;
+  int tb;
+  if (ntb_major > 0) {
+    const int64_t q = blockIdx.x >> 3;
+    tb = (int)(q % ntb_major);
+    tile = (q / ntb_major) * 8 + (blockIdx.x & 7);
+  } else {
+    tile = xcd_remap(blockIdx.x, gridDim.x);
+    tb = blockIdx.y;
+  }
+  const int64_t col = (tile * kBlock + threadIdx.x) * VEC;
   if (col + VEC > plane) return;  // whole packs only; no barrier below
-  const int t0 = blockIdx.y * NTI;
+  const int t0 = tb * NTI;
   const int64_t n3 = (int64_t)nz * plane;
 
   double acc[NOUT][NTI][VEC];
@@ -1141,6 +1159,9 @@ constexpr int kNTIGen = 8;           // generic scalar path
 #ifndef MLX_TUNE_K2_VEC32
 #define MLX_TUNE_K2_VEC32 0
 #endif
+#ifndef MLX_TUNE_K2_TBMAJOR
+#define MLX_TUNE_K2_TBMAJOR 1
+#endif
 // float32 fields: FOUR columns per thread (one 16-byte load per field, level and step) only for the
 // steric pass without delta_rho; every other pass runs TWO (8-byte loads): half the registers per
 // step buy twice the steps in flight at the same occupancy -- held-field passes 7-8 % faster without
@@ -1150,29 +1171,34 @@ constexpr int k2_vec32(int var, bool drho) {
   if (MLX_TUNE_K2_VEC32) return MLX_TUNE_K2_VEC32;
   return (var == kVarSteric && !drho) ? 4 : 2;
 }
-// float64 fields: two columns per thread (one 16-byte load per field, level and step) -- except the
-// held-field passes WITH delta_rho (what thermosteric(ds) / halosteric(ds) run by default), which
-// take ONE column and 32 steps: 3-13 % faster (16 / 24 / 32 / 40 / 48 steps swept; with one column
-// the eta-only and the steric passes are equal or slower).  Same trade as at float32.
+// float64 fields: two columns per thread (one 16-byte load per field, level and step), every pass.
+// (Round 4 ran the held-field passes WITH delta_rho -- what thermosteric(ds) / halosteric(ds) run by
+// default -- on ONE column and 32 steps: 3-13 % faster while every time block re-read rho0m and the
+// held slab from HBM.  With a tile's time blocks side by side on one XCD (k_steric_local, round 5)
+// those re-reads are L2 hits and the trade reverses: two columns x 8..16 steps and one column x
+// 6..24 steps all measure 15.2-15.8 ms where one column x 32 steps takes 17.2 -- profiles/
+// r05_tune_k2_held_drho.log, r05_tune_k2_nti_tbmajor.log.)
 #ifndef MLX_TUNE_K2_VEC64
 #define MLX_TUNE_K2_VEC64 0
 #endif
 constexpr int k2_vec64(int var, bool drho) {
   if (MLX_TUNE_K2_VEC64) return MLX_TUNE_K2_VEC64;
-  return (var != kVarSteric && drho) ? 1 : 2;
+  return 2;
 }
 constexpr int k2_nti(bool f64, int var, bool drho) {
   if (f64 && MLX_TUNE_NTI64) return MLX_TUNE_NTI64;
   if (!f64 && MLX_TUNE_NTI32) return MLX_TUNE_NTI32;
-  // float64, two columns: 16 steps (8 and 12 measured 0-4 % slower) -- except the held-field passes
-  // WITHOUT delta_rho, 6 % faster at 12: half the streamed bytes of the steric pass per cell, so the
-  // occupancy (3 waves per SIMD instead of 2) weighs more than the amortisation.  float64, one
-  // column (held-field passes with delta_rho): 32 steps.
+  // float64 (two columns): 16 steps for the steric pass (8 and 12 measured 0-4 % slower in round 4,
+  // 8 within 2.5 % either way in round 5); 8 for the held-field passes, with and without delta_rho
+  // -- ONE instantiation per variant: half the streamed bytes of the steric pass per cell, so
+  // occupancy weighs more than amortising the per-level work, and since round 5 a short time block
+  // no longer costs HBM re-reads of rho0m and the held slab (its siblings share them through L2):
+  // eta-only 8 vs 12 steps 2-3 % faster, with delta_rho 8 / 12 / 16 equal within noise.
   // float32, four columns (steric, eta only): 6 steps (3 waves per SIMD; 4 and 8 measured 3-10 %
   // slower).  float32, two columns: 12 steps for the held-field passes without delta_rho, 16 for
-  // everything that stores delta_rho (8 / 10 / 12 / 16 swept; two thirds and more of those passes'
-  // traffic are the float64 stores).
-  if (f64) return (var == kVarSteric) ? 16 : (drho ? 32 : 12);
+  // everything that stores delta_rho (8 / 10 / 12 / 16 swept in round 4, 6 / 8 / 16 / 24 again in
+  // round 5: no shape beats them beyond the box's 8 % run-to-run scatter on these passes).
+  if (f64) return (var == kVarSteric) ? 16 : 8;
   if (var == kVarSteric && !drho) return 6;
   return drho ? 16 : 12;
 }
@@ -1408,6 +1434,7 @@ struct K2Args {
   double *drho, *eta;
   int64_t drho_vstride, eta_vstride;
   bool p3d;  // fast kernels: the pressure is a (z,y,x) field (template argument P3D)
+  int ntb_major;  // > 0: 1-D grid, a tile's time blocks adjacent on one XCD (k_steric_local)
 };
 
 template <typename TIn, int VEC, int NTI, int VAR, int MODE, bool GEN, bool SKIP, bool FMA,
@@ -1419,7 +1446,7 @@ void k2_launch(const K2Args& a) {
                      dim3(kBlock), 0, a.st, (const TIn*)a.T, (const TIn*)a.S, (const TIn*)a.T0,
                      (const TIn*)a.S0, a.rho0m, a.surf, a.dz, a.z_i, a.deptho, a.p, a.p_mode, a.eos,
                      a.neg_inv_rhozero, a.nt, a.nz, a.plane, a.sT, a.sS, a.drho, a.drho_vstride,
-                     a.eta, a.eta_vstride);
+                     a.eta, a.eta_vstride, a.ntb_major);
 }
 
 template <typename TIn, int VEC, int NTI, int VAR, int MODE, bool GEN, bool SKIP, bool FMA>
@@ -1541,6 +1568,15 @@ int steric_local_impl(const void* T, const void* S, const void* T0, const void* 
   if (gx > 2147483647LL) return fail(MLX_E_SHAPE, "plane too large");
   K2Args a;
   a.grid = dim3((unsigned)gx, (unsigned)ceil_div(nt, nti));
+  a.ntb_major = 0;
+  {  // time blocks of a tile side by side on one XCD (see the kernel) when there is more than one
+    const int64_t ntb = ceil_div(nt, nti);
+    const int64_t blocks = ceil_div(gx, 8) * 8 * ntb;
+    if (MLX_TUNE_K2_TBMAJOR && ntb > 1 && blocks <= 2147483647LL) {
+      a.grid = dim3((unsigned)blocks);
+      a.ntb_major = (int)ntb;
+    }
+  }
   a.st = (hipStream_t)stream;
   a.T = T; a.S = S; a.T0 = T0 ? T0 : T; a.S0 = S0 ? S0 : S;
   a.rho0m = rho0m; a.surf = vol0_surface; a.dz = dz; a.z_i = z_i;
