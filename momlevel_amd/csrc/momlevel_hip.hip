@@ -758,8 +758,12 @@ __device__ __forceinline__ double dz_default(double depth, double ztop, double z
 // 16 B read + 3*8 B written per cell instead of 3 x (16 or 8 read + 8 written).  Each field is
 // bit-identical to its single-variant launch (same arithmetic tree, z ascending).
 // P3D (fast kernels): the pressure is a (z,y,x) field, read per level like rho0m (see K1).
+// LDSACC (round 5 experiment, -DMLX_TUNE_K2_LDSACC=1; off in the product): the column sums of the
+// NTI time steps live in LDS ([step][column][thread]: a wave's 64 lanes hit 64 consecutive doubles,
+// conflict-free; every thread owns its slots, no barrier) instead of VGPRs, so that one thread can
+// take 32 steps of one column -- north_star's "LDS-staged z-column tiles", VERDICT r4 next #5.
 template <typename TIn, int VEC, int NTI, int VAR, int MODE, bool GENERIC, bool SKIP, bool FMA,
-          bool P3D = false>
+          bool P3D = false, bool LDSACC = false>
 __global__ __launch_bounds__(kBlock) void k_steric_local(
     const TIn* __restrict__ T, const TIn* __restrict__ S, const TIn* __restrict__ T0,
     const TIn* __restrict__ S0, const double* __restrict__ rho0m,
@@ -804,13 +808,20 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
   const int t0 = tb * NTI;
   const int64_t n3 = (int64_t)nz * plane;
 
-  double acc[NOUT][NTI][VEC];
+  constexpr int NREG = LDSACC ? 1 : NTI;  // (LDSACC: the register array shrinks to a placeholder)
+  double acc[NOUT][NREG][VEC];
+  __shared__ double sacc[LDSACC ? NTI * VEC * kBlock : 1];
+  static_assert(!LDSACC || NOUT == 1, "LDS column sums: single-variant passes only");
 #pragma unroll
   for (int o = 0; o < NOUT; ++o)
 #pragma unroll
-    for (int j = 0; j < NTI; ++j)
+    for (int j = 0; j < NREG; ++j)
 #pragma unroll
       for (int k = 0; k < VEC; ++k) acc[o][j][k] = 0.0;
+  if constexpr (LDSACC) {
+#pragma unroll
+    for (int i = 0; i < NTI * VEC; ++i) sacc[i * kBlock + threadIdx.x] = 0.0;
+  }
 
   Pack<double, VEC> depth;
   if (dz == nullptr) depth = load_pack<double, VEC>(deptho + col);
@@ -957,7 +968,13 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
             const double dr = rho[o][k] - r0.v[k];  // steric.py:152 (NaN where vol0 is NaN)
             d[o].v[k] = dr;
             const double term = dzv.v[k] * dr;          // steric.py:163
-            add_skipna<PRED>(acc[o][j][k], term);             // skipna, z ascending like numpy
+            if constexpr (LDSACC) {
+              double c = sacc[(j * VEC + k) * kBlock + threadIdx.x];
+              add_skipna<PRED>(c, term);
+              sacc[(j * VEC + k) * kBlock + threadIdx.x] = c;
+            } else {
+              add_skipna<PRED>(acc[o][j][k], term);           // skipna, z ascending like numpy
+            }
           }
         }
         if (drho_out != nullptr) {  // wave-uniform: the eta-only mode skips payload fix and store
@@ -981,8 +998,10 @@ __global__ __launch_bounds__(kBlock) void k_steric_local(
       if (t0 + j < nt) {
         Pack<double, VEC> e;
 #pragma unroll
-        for (int k = 0; k < VEC; ++k)
-          e.v[k] = is_nan(surf.v[k]) ? canonical_nan() : neg_inv_rhozero * acc[o][j][k];
+        for (int k = 0; k < VEC; ++k) {
+          const double sum = LDSACC ? sacc[(j * VEC + k) * kBlock + threadIdx.x] : acc[o][LDSACC ? 0 : j][k];
+          e.v[k] = is_nan(surf.v[k]) ? canonical_nan() : neg_inv_rhozero * sum;
+        }
         store_pack<VEC>(eta_out + o * eta_vstride + (int64_t)(t0 + j) * plane + col, e);
       }
     }
@@ -1161,6 +1180,9 @@ constexpr int kNTIGen = 8;           // generic scalar path
 #endif
 #ifndef MLX_TUNE_K2_TBMAJOR
 #define MLX_TUNE_K2_TBMAJOR 1
+#endif
+#ifndef MLX_TUNE_K2_LDSACC
+#define MLX_TUNE_K2_LDSACC 0
 #endif
 // float32 fields: FOUR columns per thread (one 16-byte load per field, level and step) only for the
 // steric pass without delta_rho; every other pass runs TWO (8-byte loads): half the registers per
@@ -1438,11 +1460,12 @@ struct K2Args {
 };
 
 template <typename TIn, int VEC, int NTI, int VAR, int MODE, bool GEN, bool SKIP, bool FMA,
-          bool P3D>
+          bool P3D, bool LDSACC = false>
 void k2_launch(const K2Args& a) {
-  snprintf(g_kernel, sizeof(g_kernel), "k_steric_local<%s,%d,%d,%d,%d,%s,%s,%s%s>",
-           type_name<TIn>(), VEC, NTI, VAR, MODE, tf(GEN), tf(SKIP), tf(FMA), P3D ? ",true" : "");
-  hipLaunchKernelGGL((k_steric_local<TIn, VEC, NTI, VAR, MODE, GEN, SKIP, FMA, P3D>), a.grid,
+  snprintf(g_kernel, sizeof(g_kernel), "k_steric_local<%s,%d,%d,%d,%d,%s,%s,%s%s%s>",
+           type_name<TIn>(), VEC, NTI, VAR, MODE, tf(GEN), tf(SKIP), tf(FMA),
+           (P3D || LDSACC) ? (P3D ? ",true" : ",false") : "", LDSACC ? ",lds" : "");
+  hipLaunchKernelGGL((k_steric_local<TIn, VEC, NTI, VAR, MODE, GEN, SKIP, FMA, P3D, LDSACC>), a.grid,
                      dim3(kBlock), 0, a.st, (const TIn*)a.T, (const TIn*)a.S, (const TIn*)a.T0,
                      (const TIn*)a.S0, a.rho0m, a.surf, a.dz, a.z_i, a.deptho, a.p, a.p_mode, a.eos,
                      a.neg_inv_rhozero, a.nt, a.nz, a.plane, a.sT, a.sS, a.drho, a.drho_vstride,
@@ -1484,6 +1507,14 @@ void k2_single(const K2Args& a, bool skip, bool fma) {
   // dtypes keep the two columns of their float64 shape)
   constexpr int V1 = !F64 ? k2_vec32(VAR, true) : (MODE == kF64 ? k2_vec64(VAR, true) : VEC);
   constexpr int V0 = !F64 ? k2_vec32(VAR, false) : (MODE == kF64 ? k2_vec64(VAR, false) : VEC);
+  if constexpr (MLX_TUNE_K2_LDSACC && VAR != kVarSteric && (MODE == kF64 || MODE == kF32Faithful)) {
+    // the experiment: eta-only held-field passes, exact arithmetic, no dry skipping, z-profile
+    // pressure: 32 steps of one column (float64) / two columns (float32) per thread, sums in LDS
+    if (a.drho == nullptr && !skip && !fma && !a.p3d) {
+      k2_launch<TIn, F64 ? 1 : 2, F64 ? 32 : 16, VAR, MODE, false, false, false, false, true>(a);
+      return;
+    }
+  }
   if (a.drho != nullptr) k2_flags<TIn, V1, k2_nti(F64, VAR, true), VAR, MODE, false>(a, skip, fma);
   else k2_flags<TIn, V0, k2_nti(F64, VAR, false), VAR, MODE, false>(a, skip, fma);
 }
@@ -1556,13 +1587,19 @@ int steric_local_impl(const void* T, const void* S, const void* T0, const void* 
   //  at the roofline grid, no change for the fused one -- 8-byte loads stream worse than they save.
   //  Neither is a default path.)
   const bool f32_fields = dtype == MLX_DTYPE_F32 || dtype == MLX_DTYPE_F32_UPCAST;
-  const int v = !fast ? 1
+  int v = !fast ? 1
                 : (var == kVarAll && !f64) ? kVec32All
                 : f32_fields ? k2_vec32(var, delta_rho_out != nullptr)
                 : (dtype == MLX_DTYPE_F64 && var != kVarAll) ? k2_vec64(var, delta_rho_out != nullptr)
                              : vec_of(dtype);
-  const int nti = (var == kVarAll) ? (fast ? (f64 ? kNTI64All : kNTI32All) : kNTIGenAll)
-                                   : (fast ? k2_nti(f64, var, delta_rho_out != nullptr) : kNTIGen);
+  int nti = (var == kVarAll) ? (fast ? (f64 ? kNTI64All : kNTI32All) : kNTIGenAll)
+                             : (fast ? k2_nti(f64, var, delta_rho_out != nullptr) : kNTIGen);
+  if (MLX_TUNE_K2_LDSACC && fast && (var == kVarHalo || var == kVarThermo) && !delta_rho_out &&
+      !skip && !fma && p_mode != MLX_P_FULL3D &&
+      (dtype == MLX_DTYPE_F64 || dtype == MLX_DTYPE_F32)) {  // (the experiment's shape: k2_single)
+    v = (dtype == MLX_DTYPE_F64) ? 1 : 2;
+    nti = (dtype == MLX_DTYPE_F64) ? 32 : 16;
+  }
   if (ceil_div(nt, nti) > 65535) return fail(MLX_E_SHAPE, "nt too large for one call: chunk it");
   const int64_t gx = ceil_div(plane, (int64_t)kBlock * v);
   if (gx > 2147483647LL) return fail(MLX_E_SHAPE, "plane too large");

@@ -54,8 +54,10 @@ def main():
             T, S, rho0m, vol0[0], pz, -1.0 / 1035.0, eta_out=eta, delta_rho_out=drho, **kw))
         res[f"{tag}_thermo_eta_only"] = best(lambda: core.steric_local(
             T, S[0], rho0m, vol0[0], pz, -1.0 / 1035.0, want_delta_rho=False, eta_out=eta, **kw))
+        res[f"{tag}_thermo_eta_only_fingerprint"] = "%.17g" % eta.nan_to_num(0.0).sum().item()
         res[f"{tag}_halo_eta_only"] = best(lambda: core.steric_local(
             T[0], S, rho0m, vol0[0], pz, -1.0 / 1035.0, want_delta_rho=False, eta_out=eta, **kw))
+        res[f"{tag}_halo_eta_only_fingerprint"] = "%.17g" % eta.nan_to_num(0.0).sum().item()
         res[f"{tag}_thermo_with_delta_rho"] = best(lambda: core.steric_local(
             T, S[0], rho0m, vol0[0], pz, -1.0 / 1035.0, eta_out=eta, delta_rho_out=drho, **kw))
         res[f"{tag}_halo_with_delta_rho"] = best(lambda: core.steric_local(
