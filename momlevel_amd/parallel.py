@@ -54,15 +54,28 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        # device_count() does not initialise the GPU (is_available() does, and opens the device even
+        # when HIP_VISIBLE_DEVICES hides it): a rank that sees no GPU never touches one here -- the
+        # CPU rehearsals of 8 ranks must not put 8 processes on a card that admits 6
+        gpus = torch.cuda.device_count()
         if backend is None:
             # MOMLEVEL_AMD_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer
             # GPUs than ranks (device tensors are staged through the host for the exchange)
-            backend = os.environ.get("MOMLEVEL_AMD_DIST_BACKEND") or (
-                "nccl" if torch.cuda.is_available() else "gloo")
-        if torch.cuda.is_available():  # every backend: the rank's kernels go to ITS GPU
-            torch.cuda.set_device(local_rank % torch.cuda.device_count())
+            backend = os.environ.get("MOMLEVEL_AMD_DIST_BACKEND") or ("nccl" if gpus else "gloo")
+        if gpus:  # every backend: the rank's kernels go to ITS GPU
+            torch.cuda.set_device(local_rank % gpus)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+def host_barrier(group=None):
+    """A barrier that never touches the GPU: ``torch.distributed.barrier()`` initialises the device
+    even on a gloo group (measured on the MI355X box, scripts/diag/kfd_steps.py); an all-reduce of
+    one host double over a gloo group does not.  For ranks that must stay off the card."""
+    if dist.get_backend(group) == "gloo":
+        dist.all_reduce(torch.zeros(1, dtype=torch.float64), group=group)
+    else:
+        dist.barrier(group=group)
 
 
 def rank_environments(n, environ=None, port=None, visible_gpus=None):

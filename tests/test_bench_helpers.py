@@ -114,16 +114,18 @@ def test_self_launcher_runs_the_ranks_and_relays_rank_zero():
         "t = torch.tensor([float(rank + 1)]); dist.all_reduce(t)\n"
         "print('noise from rank', rank) if rank else print(json.dumps({'n_gpus': world, "
         "'sum': t.item(), 'backend': dist.get_backend()}), flush=True)\n"
-        "dist.barrier(); dist.destroy_process_group()\n"
+        "parallel.host_barrier(); dist.destroy_process_group()\n"
         "sys.exit(3 if (rank == 1 and os.environ.get('FAIL_RANK_1')) else 0)\n")
     out = io.StringIO()
-    rc = parallel.launch_local_ranks(2, [sys.executable, "-c", prog], visible_gpus=0, out=out)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="")  # CPU ranks wherever the suite runs
+    rc = parallel.launch_local_ranks(2, [sys.executable, "-c", prog], environ=env, visible_gpus=0,
+                                     out=out)
     assert rc == 0
     lines = [l for l in out.getvalue().splitlines() if l.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0]) == {"n_gpus": 2, "sum": 3.0, "backend": "gloo"}
     assert "noise from rank 1" not in out.getvalue()  # only rank 0's stdout is relayed
     # the worst rank's exit code is the launcher's
-    env = dict(os.environ, FAIL_RANK_1="1")
+    env = dict(os.environ, FAIL_RANK_1="1", HIP_VISIBLE_DEVICES="")
     assert parallel.launch_local_ranks(2, [sys.executable, "-c", prog], environ=env,
                                        visible_gpus=0, out=io.StringIO()) == 3
 
@@ -146,15 +148,17 @@ def test_self_launcher_at_eight_ranks():
         "area = torch.tensor([float((tile[1]-tile[0])*(tile[3]-tile[2]))]); dist.all_reduce(area)\n"
         "print(json.dumps({'n_gpus': world, 'cells': area.item(), 'tile0': tile, "
         "'pid': os.getpid()}), flush=True) if rank == 0 else None\n"
-        "dist.barrier(); dist.destroy_process_group()\n"
+        "parallel.host_barrier(); dist.destroy_process_group()\n"
         "sys.exit(5 if (rank == 6 and os.environ.get('FAIL_RANK_6')) else 0)\n")
     out = io.StringIO()
-    rc = parallel.launch_local_ranks(8, [sys.executable, "-c", prog], visible_gpus=0, out=out)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="")
+    rc = parallel.launch_local_ranks(8, [sys.executable, "-c", prog], environ=env, visible_gpus=0,
+                                     out=out)
     assert rc == 0
     lines = [json.loads(l) for l in out.getvalue().splitlines() if l.startswith("{")]
     assert len(lines) == 1 and lines[0]["n_gpus"] == 8
     assert lines[0]["cells"] == 1080.0 * 1440.0 and lines[0]["tile0"] == [0, 540, 0, 360]
-    env = dict(os.environ, FAIL_RANK_6="1")
+    env = dict(os.environ, FAIL_RANK_6="1", HIP_VISIBLE_DEVICES="")
     assert parallel.launch_local_ranks(8, [sys.executable, "-c", prog], environ=env,
                                        visible_gpus=0, out=io.StringIO()) == 5
     envs = parallel.rank_environments(8, environ={}, visible_gpus=8)

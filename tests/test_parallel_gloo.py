@@ -40,6 +40,7 @@ def _tile_partials(g, T, S, rank, world):
 
 
 def _worker(rank, world, port, q):
+    os.environ["HIP_VISIBLE_DEVICES"] = ""  # CPU ranks: stay off the card wherever the suite runs
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     r, w, _ = parallel.init_from_env(backend="gloo")
@@ -49,7 +50,7 @@ def _worker(rank, world, port, q):
     red = parallel.exchange_global(torch.from_numpy(masso), volo, masso0, area)
     out = parallel.finalize(*red)
     q.put((rank, out["eta"], out["reference_height"], out["volo"], out["area_sum"]))
-    dist.barrier()
+    parallel.host_barrier()
     dist.destroy_process_group()
 
 
@@ -67,6 +68,7 @@ def _tile_rows(g, T, S, rank, world):
 
 def _chunked_worker(rank, world, port, q):
     """ChunkedExchange: three time chunks (2+1+1 steps), four rows, the tail in the first chunk"""
+    os.environ["HIP_VISIBLE_DEVICES"] = ""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     parallel.init_from_env(backend="gloo")
@@ -81,7 +83,7 @@ def _chunked_worker(rank, world, port, q):
     outs = [parallel.finalize(red[i], volo_g, masso0_g, area_g) for i in range(3)]
     q.put((rank, [o_["eta"] for o_ in outs], [o_["masso"] for o_ in outs], red[3].numpy(),
            outs[0]["volo"], outs[0]["area_sum"]))
-    dist.barrier()
+    parallel.host_barrier()
     dist.destroy_process_group()
 
 
@@ -240,7 +242,7 @@ def _failing_worker(rank, world, port, q, scenario):
         q.put((rank, "ok", ""))
     except Exception as exc:  # noqa: BLE001
         q.put((rank, type(exc).__name__, str(exc)))
-    dist.barrier()  # every rank got here: nobody is stuck in a collective
+    parallel.host_barrier()  # every rank got here: nobody is stuck in a collective
     dist.destroy_process_group()
 
 
