@@ -573,12 +573,15 @@ __global__ __launch_bounds__(kBlock) void k_nansum_partial(const double* __restr
 // 6.0, and the kernel it was meant to bound ran at 5.1: a probe slower than the kernel is not a
 // ceiling.  (Beyond 2^23 tiles the blocks stride over the tiles: a HIP grid holds < 2^32 threads.)
 constexpr int64_t kProbeMaxBlocks = (int64_t)1 << 23;
-template <typename TIn, int NIN, bool WRITE, int U, bool NTS>
+// VEC: elements per lane and pack -- 16 bytes' worth, except float32 in / float64 out, where TWO
+// floats per lane (an 8-byte load, ONE 16-byte store: the access widths of K2's two-column float32
+// shape) read 6.6 / 6.1 TB/s where four floats and two stores per lane read 5.9 / 5.7
+// (profiles/r05_tune_probe_f32_out.log) -- and the kernels they bound had reached 5.95 / 5.61.
+template <typename TIn, int NIN, bool WRITE, int U, bool NTS, int VEC = 16 / sizeof(TIn)>
 __global__ __launch_bounds__(kBlock) void k_stream_probe_mix(const TIn* __restrict__ a,
                                                              const TIn* __restrict__ b,
                                                              int64_t npacks,
                                                              double* __restrict__ out) {
-  constexpr int VEC = 16 / sizeof(TIn);
   double sink = 0.0;
   const int64_t ntiles = (npacks + kBlock * U - 1) / (kBlock * U);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -1647,12 +1650,12 @@ int steric_local_impl(const void* T, const void* S, const void* T0, const void* 
 
 // (U, nontemporal store) per mix: the fastest shape of scripts/tune_probe.hip's sweep on hashed
 // data -- profiles/r05_tune_probe_hashed.log
-template <typename TIn, int NIN, bool WRITE, int U, bool NTS>
-static int launch_probe_mix(const void* a, const void* b, int64_t npacks, double* out,
-                            hipStream_t st) {
+template <typename TIn, int NIN, bool WRITE, int U, bool NTS, int VEC = 16 / sizeof(TIn)>
+static int launch_probe_mix(const void* a, const void* b, int64_t n, double* out, hipStream_t st) {
+  const int64_t npacks = n / VEC;
   const int64_t ntiles = ceil_div(npacks, (int64_t)kBlock * U);
   const dim3 grid((unsigned)(ntiles < kProbeMaxBlocks ? ntiles : kProbeMaxBlocks));
-  hipLaunchKernelGGL((k_stream_probe_mix<TIn, NIN, WRITE, U, NTS>), grid, dim3(kBlock), 0, st,
+  hipLaunchKernelGGL((k_stream_probe_mix<TIn, NIN, WRITE, U, NTS, VEC>), grid, dim3(kBlock), 0, st,
                      (const TIn*)a, (const TIn*)b, npacks, out);
   return hip_status(hipGetLastError(), "k_stream_probe_mix launch");
 }
@@ -1937,18 +1940,17 @@ int mlx_stream_probe_mix(const void* a, const void* b, int dtype, int64_t n, dou
   if (n <= 0 || n % vec) return fail(MLX_E_SHAPE, "n must be > 0 and a whole number of 16-byte packs");
   if (!aligned(a, 16) || (b && !aligned(b, 16)) || !aligned(out, write_out ? 16 : 8))
     return fail(MLX_E_ALIGN, "operands must be 16-byte aligned");
-  const int64_t npacks = n / vec;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MLX_DTYPE_F64) {
-    if (b) return write_out ? launch_probe_mix<double, 2, true, 1, true>(a, b, npacks, out, st)
-                            : launch_probe_mix<double, 2, false, 2, true>(a, b, npacks, out, st);
-    return write_out ? launch_probe_mix<double, 1, true, 1, true>(a, b, npacks, out, st)
-                     : launch_probe_mix<double, 1, false, 2, true>(a, b, npacks, out, st);
+    if (b) return write_out ? launch_probe_mix<double, 2, true, 1, true>(a, b, n, out, st)
+                            : launch_probe_mix<double, 2, false, 2, true>(a, b, n, out, st);
+    return write_out ? launch_probe_mix<double, 1, true, 1, true>(a, b, n, out, st)
+                     : launch_probe_mix<double, 1, false, 2, true>(a, b, n, out, st);
   }
-  if (b) return write_out ? launch_probe_mix<float, 2, true, 4, false>(a, b, npacks, out, st)
-                          : launch_probe_mix<float, 2, false, 8, true>(a, b, npacks, out, st);
-  return write_out ? launch_probe_mix<float, 1, true, 1, false>(a, b, npacks, out, st)
-                   : launch_probe_mix<float, 1, false, 2, true>(a, b, npacks, out, st);
+  if (b) return write_out ? launch_probe_mix<float, 2, true, 1, true, 2>(a, b, n, out, st)
+                          : launch_probe_mix<float, 2, false, 8, true>(a, b, n, out, st);
+  return write_out ? launch_probe_mix<float, 1, true, 1, true, 2>(a, b, n, out, st)
+                   : launch_probe_mix<float, 1, false, 2, true>(a, b, n, out, st);
 }
 
 // the 2 x float64 in / 1 x float64 out mix under its round-2 name

@@ -67,6 +67,34 @@ __global__ __launch_bounds__(256) void k_probe(const TIn* __restrict__ a, const 
   if (!WRITE && sink == 0x1.23456789abcdep+1000) out[0] = sink;
 }
 
+// float32 in / float64 out with the access widths of K2's two-column shape: 8-byte loads (2 floats
+// per lane), ONE 16-byte store per lane and pack
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <int NIN, int U, bool LOOP, bool NTS>
+__global__ __launch_bounds__(256) void k_probe_f2(const float* __restrict__ a, const float* __restrict__ b,
+                                                  int64_t npacks, double* __restrict__ out) {
+  const int64_t ntiles = (npacks + 256 * U - 1) / (256 * U);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += LOOP ? gridDim.x : ntiles) {
+    const int64_t base = tile * (256 * U) + threadIdx.x;
+    f2 x[U], y[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + (int64_t)u * 256;
+      if (i < npacks) {
+        x[u] = __builtin_nontemporal_load(reinterpret_cast<const f2*>(a + 2 * i));
+        if (NIN == 2) y[u] = __builtin_nontemporal_load(reinterpret_cast<const f2*>(b + 2 * i));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + (int64_t)u * 256;
+      if (i < npacks)
+        st2<NTS>(out + 2 * i, (double)x[u].x + (NIN == 2 ? (double)y[u].x : 0.0),
+                 (double)x[u].y + (NIN == 2 ? (double)y[u].y : 0.0));
+    }
+  }
+}
+
 static double time_ms(void (*launch)(void*), void* ctx, int reps) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   launch(ctx); CK(hipDeviceSynchronize());
@@ -109,6 +137,29 @@ static void sweep(Ctx c, const char* name) {
   fflush(stdout);
 }
 
+template <int NIN, int U, bool LOOP, bool NTS>
+static void launch_f2(void* p) {
+  Ctx* c = (Ctx*)p;
+  const int64_t npacks = c->n / 2;
+  const int64_t ntiles = (npacks + 256 * U - 1) / (256 * U);
+  const int64_t grid = LOOP ? (c->blocks < ntiles ? c->blocks : ntiles) : ntiles;
+  hipLaunchKernelGGL((k_probe_f2<NIN, U, LOOP, NTS>), dim3((unsigned)grid), dim3(256), 0, 0,
+                     (const float*)c->a, (const float*)c->b, npacks, c->out);
+}
+
+template <int NIN, int U>
+static void sweep_f2(Ctx c, const char* name) {
+  const double bytes = (double)c.n * (NIN * 4 + 8);
+  c.blocks = 256 * 32;
+  double ms = time_ms(launch_f2<NIN, U, true, true>, &c, 3);
+  printf("%-28s U=%d float2 loads, loop 32 blk/CU nt-store %8.3f ms %8.1f GB/s\n", name, U, ms, bytes / ms / 1e6);
+  ms = time_ms(launch_f2<NIN, U, false, true>, &c, 3);
+  printf("%-28s U=%d float2 loads, one tile per block nt-store %8.3f ms %8.1f GB/s\n", name, U, ms, bytes / ms / 1e6);
+  ms = time_ms(launch_f2<NIN, U, false, false>, &c, 3);
+  printf("%-28s U=%d float2 loads, one tile per block plain-st %8.3f ms %8.1f GB/s\n", name, U, ms, bytes / ms / 1e6);
+  fflush(stdout);
+}
+
 template <typename TIn, int NIN, bool WRITE>
 static void sweep_u(Ctx c, const char* name) {
   sweep<TIn, NIN, WRITE, 1>(c, name);
@@ -133,8 +184,8 @@ int main(int argc, char** argv) {
   const int ro = argc > 3 ? atoi(argv[3]) : 0;        // 1: read-only mixes only (no output stream)
   const int64_t n = (int64_t)(gib * (1 << 30) / 8) / 4096 * 4096;  // elements per stream
   void *a, *b; double* out;
-  CK(hipMalloc(&a, n * 8)); CK(hipMalloc(&b, n * 8)); CK(hipMalloc((void**)&out, ro ? 4096 : n * 8));
-  CK(hipMemset(a, 0, n * 8)); CK(hipMemset(b, 0, n * 8)); CK(hipMemset(out, 0, ro ? 4096 : n * 8));
+  CK(hipMalloc(&a, n * 8)); CK(hipMalloc(&b, n * 8)); CK(hipMalloc((void**)&out, ro == 1 ? 4096 : n * 8));
+  CK(hipMemset(a, 0, n * 8)); CK(hipMemset(b, 0, n * 8)); CK(hipMemset(out, 0, ro == 1 ? 4096 : n * 8));
   if (fill) {
     hipLaunchKernelGGL(k_fill, dim3(65536), dim3(256), 0, 0, (double*)a, n, 1ull);
     hipLaunchKernelGGL(k_fill, dim3(65536), dim3(256), 0, 0, (double*)b, n, 77ull);
@@ -143,6 +194,15 @@ int main(int argc, char** argv) {
   printf("elements per stream: %lld (%.1f GiB of float64), %s, %s\n", (long long)n,
          n * 8.0 / (1 << 30), fill ? "hashed values" : "zeros", ro ? "read-only mixes" : "all mixes");
   Ctx c{a, b, out, n, 0};
+  if (ro == 2) {  // the float32-in / float64-out mixes only, both load widths
+    sweep_u<float, 1, true>(c, "1 x f32 in, 1 x f64 out");
+    sweep_f2<1, 1>(c, "1 x f32 in, 1 x f64 out"); sweep_f2<1, 2>(c, "1 x f32 in, 1 x f64 out");
+    sweep_f2<1, 4>(c, "1 x f32 in, 1 x f64 out"); sweep_f2<1, 8>(c, "1 x f32 in, 1 x f64 out");
+    sweep_u<float, 2, true>(c, "2 x f32 in, 1 x f64 out");
+    sweep_f2<2, 1>(c, "2 x f32 in, 1 x f64 out"); sweep_f2<2, 2>(c, "2 x f32 in, 1 x f64 out");
+    sweep_f2<2, 4>(c, "2 x f32 in, 1 x f64 out"); sweep_f2<2, 8>(c, "2 x f32 in, 1 x f64 out");
+    return 0;
+  }
   if (ro) {
     sweep_u<double, 1, false>(c, "1 x f64 in, read-only");
     sweep_u<double, 2, false>(c, "2 x f64 in, read-only");
