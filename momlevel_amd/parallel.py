@@ -173,8 +173,8 @@ def rank_ordered_sum(gathered):
 
 
 class _Exchange:
-    """One sum-over-ranks of a packed float64 vector, started asynchronously.  ``start`` enqueues the
-    collective (RCCL: on its own stream behind the kernels that produced ``vec``; gloo with a device
+    """One sum-over-ranks of a packed float64 vector, started asynchronously.  Construction enqueues
+    the collective (RCCL: on its own stream behind the kernels that produced ``vec``; gloo with a device
     vector -- a rehearsal on fewer GPUs than ranks -- stages through the host and is synchronous);
     ``result()`` waits and returns the sum as a float64 numpy vector on the host."""
 
@@ -185,6 +185,7 @@ class _Exchange:
         if vec.is_cuda and dist.get_backend(group) == "gloo":
             vec = vec.cpu()
         vec = vec.contiguous()
+        self._vec = vec  # (the collective reads it asynchronously: it stays alive until result())
         if self.mode == "allreduce":
             self.buf = vec.clone()
             self.work = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
@@ -200,6 +201,7 @@ class _Exchange:
             self.work.wait()
             self.work = None
         host = self.buf.cpu().numpy()  # (a device buffer: synchronises with the collective)
+        self._vec = None
         return host if self.mode == "allreduce" else rank_ordered_sum(host.reshape(self.world, -1))
 
 
