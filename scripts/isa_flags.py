@@ -224,7 +224,9 @@ def check_file(path, only=None):
 def main():
     paths = sys.argv[1:]
     if not paths:
-        out = os.path.join(ROOT, "build", "isa", "momlevel_hip.s")
+        import tempfile
+
+        out = os.path.join(tempfile.gettempdir(), "momlevel_amd_isa", "momlevel_hip.s")
         os.makedirs(os.path.dirname(out), exist_ok=True)
         paths = [compile_asm(out)]
     rc = 0

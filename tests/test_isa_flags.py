@@ -86,7 +86,11 @@ def _asm_of(src_dir, out):
         if name.endswith((".hip", ".hpp")):
             with open(os.path.join(src_dir, "momlevel_amd", "csrc", name), "rb") as f:
                 h.update(f.read())
-    path = os.path.join(ROOT, "build", "isa", f"{out}_{h.hexdigest()[:16]}.s")
+    # (40 MB apiece: cached in the system's temporary directory, not in the tree -- a tree-local
+    #  cache travelled to the GPU box with every gpurun snapshot)
+    import tempfile
+
+    path = os.path.join(tempfile.gettempdir(), "momlevel_amd_isa", f"{out}_{h.hexdigest()[:16]}.s")
     if not os.path.exists(path):
         os.makedirs(os.path.dirname(path), exist_ok=True)
         isa.compile_asm(path + ".tmp", os.path.join(src_dir, "momlevel_amd", "csrc", "momlevel_hip.hip"))
