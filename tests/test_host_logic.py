@@ -459,3 +459,37 @@ def test_a_dask_like_array_with_masked_chunks_is_computed_before_it_is_filled():
             return self
 
     assert np.array_equal(as_plain(DaskLike()), [1.0, np.nan, 3.0], equal_nan=True)
+
+
+def test_k2_block_mapping_covers_every_tile_and_time_block_once():
+    """k_steric_local's 1-D grid (csrc/momlevel_hip.hip, round 5): block id b -> xcd = b % 8,
+    q = b // 8, time block = q % ntb, tile = (q // ntb) * 8 + xcd, launched with
+    ceil(tiles / 8) * 8 * ntb blocks; blocks whose tile is past the plane exit.  Restated here and
+    checked for what the kernel relies on: every (tile, time block) exactly once for any tile count
+    (also not a multiple of 8), and a tile's ntb time blocks on ONE XCD as consecutive workgroups of
+    it (ids b, b+8, ...) -- the property that turns their re-reads of rho0m / the held slab into L2
+    hits.  The decode in the kernel is these three lines; the GPU suite's ragged shapes run it."""
+    import re
+
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                            "momlevel_amd", "csrc", "momlevel_hip.hip")).read()
+    # the restatement below is the kernel's: keep the two in step
+    assert re.search(r"const int64_t q = blockIdx\.x >> 3;\s*tb = \(int\)\(q % ntb_major\);\s*"
+                     r"tile = \(q / ntb_major\) \* 8 \+ \(blockIdx\.x & 7\);", src)
+    assert "const int64_t blocks = ceil_div(gx, 8) * 8 * ntb;" in src
+    for tiles in (1, 7, 8, 9, 64, 3038):
+        for ntb in (2, 3, 10, 15):
+            blocks = -(-tiles // 8) * 8 * ntb
+            seen = {}
+            for b in range(blocks):
+                q = b >> 3
+                tb, tile = q % ntb, (q // ntb) * 8 + (b & 7)
+                if tile >= tiles:
+                    continue
+                assert (tile, tb) not in seen
+                seen[(tile, tb)] = b
+            assert len(seen) == tiles * ntb
+            for tile in range(tiles):
+                ids = [seen[(tile, tb)] for tb in range(ntb)]
+                assert {i % 8 for i in ids} == {tile % 8}           # one XCD
+                assert [i // 8 for i in ids] == list(range(ids[0] // 8, ids[0] // 8 + ntb))  # adjacent there
