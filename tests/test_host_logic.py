@@ -469,6 +469,7 @@ def test_k2_block_mapping_covers_every_tile_and_time_block_once():
     (also not a multiple of 8), and a tile's ntb time blocks on ONE XCD as consecutive workgroups of
     it (ids b, b+8, ...) -- the property that turns their re-reads of rho0m / the held slab into L2
     hits.  The decode in the kernel is these three lines; the GPU suite's ragged shapes run it."""
+    import os
     import re
 
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
