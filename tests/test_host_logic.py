@@ -494,3 +494,48 @@ def test_k2_block_mapping_covers_every_tile_and_time_block_once():
                 ids = [seen[(tile, tb)] for tb in range(ntb)]
                 assert {i % 8 for i in ids} == {tile % 8}           # one XCD
                 assert [i // 8 for i in ids] == list(range(ids[0] // 8, ids[0] // 8 + ntb))  # adjacent there
+
+
+def test_as_plain_property_random_masked_arrays():
+    """labeled.as_plain against its definition -- xarray's as_compatible_data for masked arrays:
+    where(~mask, data, NaN) after dtypes.maybe_promote -- on random shapes, dtypes, masks (incl.
+    nomask, scalar masks, non-contiguous views); the input is never written."""
+    hypothesis = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+    from hypothesis.extra import numpy as hnp
+
+    from momlevel_amd.labeled import as_plain
+
+    dtypes = st.sampled_from([np.float64, np.float32, np.int8, np.int16, np.uint16, np.int32, np.int64])
+
+    @settings(max_examples=120, deadline=None)
+    @given(st.data())
+    def check(data):
+        dt = np.dtype(data.draw(dtypes))
+        shape = data.draw(hnp.array_shapes(min_dims=0, max_dims=4, max_side=5))
+        elems = (st.floats(-1e6, 1e6, width=32) if dt.kind == "f" else st.integers(-100, 100)
+                 if dt.kind == "i" else st.integers(0, 200))
+        arr = data.draw(hnp.arrays(dt, shape, elements=elems))
+        kind = data.draw(st.sampled_from(["array", "nomask", "all", "none"]))
+        if kind == "array":
+            mask = data.draw(hnp.arrays(np.bool_, shape))
+        else:
+            mask = {"nomask": np.ma.nomask, "all": True, "none": False}[kind]
+        m = np.ma.masked_array(arr.copy(), mask=mask)
+        if m.ndim >= 2 and data.draw(st.booleans()):
+            m = m.T  # a non-contiguous view
+        before = (np.ma.getdata(m).copy(), np.ma.getmaskarray(m).copy())
+        got = as_plain(m)
+        full = np.ma.getmaskarray(m)
+        assert type(got) is np.ndarray and got.shape == m.shape
+        if not full.any():
+            assert got.dtype == dt and np.array_equal(got, np.ma.getdata(m))
+        else:
+            want_dt = dt if dt.kind == "f" else (np.float32 if dt.itemsize <= 2 else np.float64)
+            assert got.dtype == want_dt
+            assert np.array_equal(np.isnan(got), full | (np.isnan(before[0]) if dt.kind == "f" else False))
+            assert np.array_equal(got[~full], before[0][~full].astype(want_dt))
+        assert np.array_equal(np.ma.getdata(m), before[0], equal_nan=True)
+        assert np.array_equal(np.ma.getmaskarray(m), before[1])
+
+    check()
