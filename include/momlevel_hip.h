@@ -38,14 +38,15 @@
 extern "C" {
 #endif
 
-#define MLX_ABI_VERSION 6 /* 2: mlx_eos_map takes flags; mlx_steric_global_decomp, mlx_steric_local_decomp,
+#define MLX_ABI_VERSION 7 /* 2: mlx_eos_map takes flags; mlx_steric_global_decomp, mlx_steric_local_decomp,
                              mlx_stream_probe;
                              MLX_FLAG_FMA, MLX_FLAG_TCHUNK; MLX_P_FULL4D in K1/K2
                              3: mlx_build_kind; a NULL p (linear EOS) requires p_mode MLX_P_SCALAR
                              4: mlx_eos_map_promote (MLX_KIND_*); MLX_DTYPE_T32_S64 / _T64_S32 in K1/K2
                              5: mlx_stream_probe_mix, mlx_valu_probe, mlx_last_kernel
                              6: mlx_host_copy; mlx_stratification, mlx_adjust_negative_n2,
-                                mlx_wave_speed_where_time0 */
+                                mlx_wave_speed_where_time0
+                             7: mlx_host_copy_masked */
 
 /* argument-error codes (negative) */
 #define MLX_E_NULL     (-1) /* a required pointer is NULL                      */
@@ -411,6 +412,17 @@ int mlx_wave_speed_where_time0(const double *n2_t0, const double *speed, int64_t
  * Python: a foreign call, so the GIL is released for its whole duration.
  * ------------------------------------------------------------------------------- */
 int mlx_host_copy(void *dst, const void *src, size_t nbytes, int threads, int streaming);
+
+/* dst[i] = mask[i] ? NaN : src[i] for n elements of elem_size 4 (float32) or 8 (float64) bytes of
+ * HOST memory -- bit patterns are copied, the canonical quiet NaN is written where the mask byte is
+ * non-zero -- split over the same team of `threads` (1..64) threads.  How a numpy masked array (what
+ * netCDF4.Variable.__getitem__ returns where a file declares _FillValue) becomes the NaN-filled
+ * array the reference is handed by xarray (src/momlevel/steric.py:84-96 sees DataArrays only;
+ * momlevel_amd/labeled.py as_plain), at host memory bandwidth.  dst / src element-aligned
+ * (MLX_E_ALIGN); dst must overlap neither src nor mask (MLX_E_SHAPE); elem_size other than 4 / 8:
+ * MLX_E_ENUM.  Touches no device. */
+int mlx_host_copy_masked(void *dst, const void *src, const unsigned char *mask, size_t n,
+                         int elem_size, int threads);
 
 #ifdef __cplusplus
 }

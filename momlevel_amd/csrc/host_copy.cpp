@@ -77,13 +77,52 @@ void copy_slice(unsigned char* d, const unsigned char* s, size_t n, bool streami
     std::memcpy(d, s, n);
 }
 
+// dst[i] = mask[i] ? NaN : src[i] over n elements of 4 or 8 bytes (bit patterns: no float ops, so
+// signalling NaNs and denormals in src pass through untouched).  A plain loop the compiler turns
+// into byte-mask expansion + blend (avx2 where the host has it).
+template <typename U>
+#if defined(__x86_64__)
+__attribute__((target("avx2")))
+#endif
+void fill_masked_avx2(U* __restrict__ d, const U* __restrict__ s, const unsigned char* __restrict__ m,
+                      size_t n, U nan) {
+  for (size_t i = 0; i < n; ++i) d[i] = m[i] ? nan : s[i];
+}
+template <typename U>
+void fill_masked_plain(U* __restrict__ d, const U* __restrict__ s,
+                       const unsigned char* __restrict__ m, size_t n, U nan) {
+  for (size_t i = 0; i < n; ++i) d[i] = m[i] ? nan : s[i];
+}
+void fill_masked(unsigned char* d, const unsigned char* s, const unsigned char* m, size_t n,
+                 int elem) {
+  const bool wide = have_streaming_stores();  // (= the host has avx2)
+  if (elem == 4) {
+    auto* dd = reinterpret_cast<uint32_t*>(d);
+    auto* ss = reinterpret_cast<const uint32_t*>(s);
+    if (wide) fill_masked_avx2<uint32_t>(dd, ss, m, n, 0x7FC00000u);
+    else fill_masked_plain<uint32_t>(dd, ss, m, n, 0x7FC00000u);
+  } else {
+    auto* dd = reinterpret_cast<uint64_t*>(d);
+    auto* ss = reinterpret_cast<const uint64_t*>(s);
+    if (wide) fill_masked_avx2<uint64_t>(dd, ss, m, n, 0x7FF8000000000000ull);
+    else fill_masked_plain<uint64_t>(dd, ss, m, n, 0x7FF8000000000000ull);
+  }
+}
+
 struct Slice {
   unsigned char* d;
   const unsigned char* s;
-  size_t n;
+  size_t n;  // bytes; ELEMENTS when mask != nullptr
   bool streaming;
   std::atomic<int>* remaining;  // on the stack of the call that owns the slice
+  const unsigned char* mask;    // nullptr: a plain copy; else dst = mask ? NaN : src
+  int elem;                     // element size of a masked slice (4 or 8)
 };
+
+void run_slice(const Slice& j) {
+  if (j.mask != nullptr) fill_masked(j.d, j.s, j.mask, j.n, j.elem);
+  else copy_slice(j.d, j.s, j.n, j.streaming);
+}
 
 // The team: detached workers on one queue, shared by every caller (hostio's upload and download
 // threads copy at the same time).  Created on first use, grown to the largest team asked for, never
@@ -108,7 +147,7 @@ void worker(Team* t) {
       job = t->queue.front();
       t->queue.pop_front();
     }
-    copy_slice(job.d, job.s, job.n, job.streaming);
+    run_slice(job);
     if (job.remaining->fetch_sub(1, std::memory_order_acq_rel) == 1) {
       // last slice of its call: the owner either has not looked yet (it will see 0) or sleeps in
       // done.wait -- taking the mutex first orders this notify after its predicate check
@@ -142,6 +181,55 @@ Team* team() {
   return t;
 }
 
+// Run `parts` slices -- slice i covers units [i*per, min((i+1)*per, total)) -- slice 0 on the calling
+// thread, the others on the team; returns when all are done.  No C++ exception leaves it:
+// whatever cannot be handed to the team -- no team (bad_alloc), no worker thread to be had, no room
+// in the queue -- is done by this thread.  Slices that WERE queued point at `remaining` on this
+// stack, so from the first push_back on the function only returns once they are all done.
+template <typename Make>
+void run_parts(int parts, Make make) {
+  if (parts <= 1) {
+    run_slice(make(0, nullptr));
+    return;
+  }
+  Team* t = nullptr;
+  try {
+    t = team();
+  } catch (...) {
+  }
+  std::atomic<int> remaining(0);
+  int queued = 0;  // slices 1..queued are the team's, 0 and queued+1..parts-1 this thread's
+  if (t != nullptr) {
+    std::lock_guard<std::mutex> lk(t->m);  // (workers cannot take a slice before this is released)
+    try {
+      while (t->workers < parts - 1) {
+        std::thread(worker, t).detach();
+        ++t->workers;
+      }
+    } catch (...) {  // no more threads to be had: the workers there are do it
+    }
+    if (t->workers > 0) {
+      try {
+        for (int i = 1; i < parts; ++i) {
+          t->queue.push_back(make(i, &remaining));
+          ++queued;
+        }
+      } catch (...) {  // bad_alloc in the deque: what is queued stays queued, the rest is ours
+      }
+    }
+    remaining.store(queued, std::memory_order_release);
+  }
+  if (queued > 0) t->work.notify_all();
+  run_slice(make(0, nullptr));  // this thread's own share
+  for (int i = queued + 1; i < parts; ++i) run_slice(make(i, nullptr));
+  if (queued > 0) {
+    std::unique_lock<std::mutex> lk(t->m);
+    t->done.wait(lk, [&remaining] { return remaining.load(std::memory_order_acquire) == 0; });
+  }
+}
+
+bool ranges_overlap(uintptr_t a, size_t na, uintptr_t b, size_t nb) { return a < b + nb && b < a + na; }
+
 }  // namespace
 
 extern "C" int mlx_host_copy(void* dst, const void* src, size_t nbytes, int threads,
@@ -156,7 +244,7 @@ extern "C" int mlx_host_copy(void* dst, const void* src, size_t nbytes, int thre
   const uintptr_t da = reinterpret_cast<uintptr_t>(d), sa = reinterpret_cast<uintptr_t>(s);
   if (nbytes > UINTPTR_MAX - da || nbytes > UINTPTR_MAX - sa)
     return mlx::detail::fail(MLX_E_SHAPE, "a range wraps around the address space");
-  if (da < sa + nbytes && sa < da + nbytes)
+  if (ranges_overlap(da, nbytes, sa, nbytes))
     return mlx::detail::fail(MLX_E_SHAPE, "dst and src overlap");
   const bool stream_stores = streaming != 0 && have_streaming_stores();
   // slices of whole pages, at least 1 MiB each: below that a hand-over costs more than it saves
@@ -164,55 +252,49 @@ extern "C" int mlx_host_copy(void* dst, const void* src, size_t nbytes, int thre
   if (slice < (size_t(1) << 20)) slice = size_t(1) << 20;
   slice = (slice + 4095) & ~size_t(4095);
   const int parts = static_cast<int>((nbytes + slice - 1) / slice);
-  if (parts <= 1) {
-    copy_slice(d, s, nbytes, stream_stores);
-    return 0;
-  }
-  // No C++ exception leaves this extern "C" function: whatever cannot be handed to the
-  // team -- no team (bad_alloc), no worker thread to be had, no room in the queue -- is copied by
-  // this thread.  Slices that WERE queued point at `remaining` on this stack, so from the first
-  // push_back on the function only returns once they are all done.
-  Team* t = nullptr;
-  try {
-    t = team();
-  } catch (...) {
-  }
-  if (t == nullptr) {
-    copy_slice(d, s, nbytes, stream_stores);
-    return 0;
-  }
-  std::atomic<int> remaining(0);
-  int queued = 0;  // slices 1..queued are the team's, 0 and queued+1..parts-1 this thread's
-  {
-    std::lock_guard<std::mutex> lk(t->m);  // (workers cannot take a slice before this is released)
-    try {
-      while (t->workers < parts - 1) {
-        std::thread(worker, t).detach();
-        ++t->workers;
-      }
-    } catch (...) {  // no more threads to be had: the workers there are do it
-    }
-    if (t->workers > 0) {
-      try {
-        for (int i = 1; i < parts; ++i) {
-          const size_t off = static_cast<size_t>(i) * slice;
-          const size_t n = (off + slice <= nbytes) ? slice : nbytes - off;
-          t->queue.push_back(Slice{d + off, s + off, n, stream_stores, &remaining});
-          ++queued;
-        }
-      } catch (...) {  // bad_alloc in the deque: what is queued stays queued, the rest is ours
-      }
-    }
-    remaining.store(queued, std::memory_order_release);
-  }
-  if (queued > 0) t->work.notify_all();
-  copy_slice(d, s, slice, stream_stores);  // this thread's own share
-  const size_t done_to = static_cast<size_t>(queued + 1) * slice;
-  if (done_to < nbytes) copy_slice(d + done_to, s + done_to, nbytes - done_to, stream_stores);
-  if (queued > 0) {
-    std::unique_lock<std::mutex> lk(t->m);
-    t->done.wait(lk, [&remaining] { return remaining.load(std::memory_order_acquire) == 0; });
-  }
+  run_parts(parts, [=](int i, std::atomic<int>* remaining) {
+    const size_t off = static_cast<size_t>(i) * slice;
+    const size_t n = (off + slice <= nbytes) ? slice : nbytes - off;
+    return Slice{d + off, s + off, n, stream_stores, remaining, nullptr, 0};
+  });
+  return 0;
+}
+
+// dst[i] = mask[i] ? NaN : src[i] for n elements of elem_size 4 or 8 bytes (float32 / float64 bit
+// patterns), split over the same team: how a numpy masked array -- a netCDF4 read -- becomes the
+// NaN-filled array the reference is handed (momlevel_amd/labeled.py as_plain), at the host's memory
+// bandwidth instead of numpy's single-threaded 0.7-1 GB/s.
+extern "C" int mlx_host_copy_masked(void* dst, const void* src, const unsigned char* mask,
+                                    size_t n, int elem_size, int threads) {
+  if (n == 0) return 0;
+  if (dst == nullptr || src == nullptr || mask == nullptr)
+    return mlx::detail::fail(MLX_E_NULL, "dst, src and mask must not be NULL");
+  if (elem_size != 4 && elem_size != 8)
+    return mlx::detail::fail(MLX_E_ENUM, "elem_size must be 4 or 8");
+  if (threads < 1 || threads > kMaxThreads)
+    return mlx::detail::fail(MLX_E_SHAPE, "threads must be in 1..64");
+  const size_t es = static_cast<size_t>(elem_size);
+  if (n > SIZE_MAX / es) return mlx::detail::fail(MLX_E_SHAPE, "n * elem_size overflows");
+  const size_t nbytes = n * es;
+  auto* d = static_cast<unsigned char*>(dst);
+  auto* s = static_cast<const unsigned char*>(src);
+  const uintptr_t da = reinterpret_cast<uintptr_t>(d), sa = reinterpret_cast<uintptr_t>(s);
+  const uintptr_t ma = reinterpret_cast<uintptr_t>(mask);
+  if (da % es || sa % es) return mlx::detail::fail(MLX_E_ALIGN, "dst / src not element-aligned");
+  if (nbytes > UINTPTR_MAX - da || nbytes > UINTPTR_MAX - sa || n > UINTPTR_MAX - ma)
+    return mlx::detail::fail(MLX_E_SHAPE, "a range wraps around the address space");
+  if (ranges_overlap(da, nbytes, sa, nbytes) || ranges_overlap(da, nbytes, ma, n))
+    return mlx::detail::fail(MLX_E_SHAPE, "dst overlaps src or mask");
+  // slices of whole pages of the mask, at least 256 Ki elements each
+  size_t per = (n + static_cast<size_t>(threads) - 1) / static_cast<size_t>(threads);
+  if (per < (size_t(1) << 18)) per = size_t(1) << 18;
+  per = (per + 4095) & ~size_t(4095);
+  const int parts = static_cast<int>((n + per - 1) / per);
+  run_parts(parts, [=](int i, std::atomic<int>* remaining) {
+    const size_t off = static_cast<size_t>(i) * per;
+    const size_t cnt = (off + per <= n) ? per : n - off;
+    return Slice{d + off * es, s + off * es, cnt, false, remaining, mask + off, elem_size};
+  });
   return 0;
 }
 #endif  // !__HIP_DEVICE_COMPILE__

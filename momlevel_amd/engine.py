@@ -118,7 +118,10 @@ class TimeChunks:
             # a CPU torch tensor is host memory like any numpy array: same staging path, same
             # stream and event discipline (never the runtime's on-the-fly pinning of caller memory)
             src = src.detach().contiguous().numpy()
-        host = _host_tensor(src, np.float32 if dt == torch.float32 else np.float64)
+        # (a masked slice -- a netCDF4 read -- travels as data + mask: NaN is written under the mask
+        #  while each piece is copied into the staging ring, hostio.split_masked)
+        src, mask = hostio.split_masked(src, np.dtype(np.float32 if dt == torch.float32 else np.float64))
+        host = _host_tensor(src)
         with torch.cuda.device(self.device):
             # the chunk belongs to the CONSUMER's stream (the caching allocator ties a block to the
             # stream that was current when it was allocated -- in this worker thread that would be
@@ -129,7 +132,7 @@ class TimeChunks:
             # stream-ordered): everything enqueued there so far goes first
             self._copy_stream.wait_stream(self._main)
             with hostio.roctx_range(f"stage+H2D steps {t0}:{t1} ({host.numel() * host.element_size() >> 20} MiB)"):
-                hostio.upload(host, dev, stream=self._copy_stream, ring=self._ring)
+                hostio.upload(host, dev, stream=self._copy_stream, ring=self._ring, mask=mask)
             ev = torch.cuda.Event()
             ev.record(self._copy_stream)
             dev.record_stream(self._copy_stream)

@@ -175,6 +175,40 @@ def _host_copy(dst, src):
     _native_copy()(dst.data_ptr(), src.data_ptr(), n)
 
 
+def _host_copy_masked(dst, src, mask, elem):
+    """dst[:] = where(mask, NaN, src) for two equally long contiguous uint8 CPU tensors seen as
+    elements of ``elem`` bytes (float32 / float64 bit patterns) and a contiguous numpy bool array with
+    one entry per element: the NaN fill of a masked array done ON THE WAY into the staging buffer --
+    one pass over the bytes, no intermediate array (mlx_host_copy_masked, the same thread team)."""
+    from . import _lib
+
+    n = dst.numel()
+    assert src.numel() == n and n % elem == 0 and mask.size == n // elem
+    rc = _lib.load().mlx_host_copy_masked(dst.data_ptr(), src.data_ptr(), mask.ctypes.data,
+                                          n // elem, elem, host_threads())
+    if rc != 0:
+        raise RuntimeError(f"mlx_host_copy_masked failed ({rc}): {_lib.last_error()}")
+
+
+def split_masked(a, dtype=None):
+    """-> (plain array, mask or None) for the upload of host data ``a``.  A floating numpy masked
+    array that already has the wanted dtype and a C-contiguous native layout travels as its raw data
+    plus its boolean mask -- upload() writes NaN under the mask while it copies each piece into the
+    staging ring -- instead of being NaN-filled into an array of its own first (as_plain: a second
+    pass over the bytes and a fresh allocation per time chunk, 2.3x the wall time of the plain call
+    on the reference's recorded example).  Everything else: (as_plain(a) [cast to dtype], None)."""
+    if isinstance(a, np.ma.MaskedArray):
+        data, mask = np.ma.getdata(a), np.ma.getmask(a)
+        if (mask is not np.ma.nomask and data.dtype.kind == "f" and data.dtype.itemsize in (4, 8)
+                and (dtype is None or data.dtype == dtype) and data.dtype.isnative
+                and data.flags["C_CONTIGUOUS"] and data.nbytes >= SMALL_BYTES):
+            return data, np.ascontiguousarray(np.broadcast_to(mask, data.shape), dtype=np.bool_)
+    a = as_plain(a)
+    if dtype is not None and a.dtype != dtype:
+        a = a.astype(dtype)
+    return a, None
+
+
 class roctx_range:
     """``with roctx_range("H2D chunk 3"):`` -- a roctx range (torch's nvtx binding) when
     MOMLEVEL_AMD_ROCTX=1, nothing otherwise; read by scripts/ingest_profile.py's rocprofv3 run."""
@@ -198,12 +232,13 @@ def new_ring(depth=RING_DEPTH):
     return _Ring(depth)
 
 
-def upload(host, dev, stream=None, ring=None):
+def upload(host, dev, stream=None, ring=None, mask=None):
     """Copy the contiguous CPU tensor ``host`` into the device tensor ``dev`` (same dtype and
     number of elements) through the staging ring, asynchronously on ``stream`` (default: the
     device's current stream).  Returns when the last piece has been ENQUEUED; ``host`` may be
     modified or freed from then on (its bytes are in the staging buffers), ``dev`` is complete
-    once ``stream`` has passed the copies."""
+    once ``stream`` has passed the copies.  ``mask`` (split_masked): a contiguous numpy bool array,
+    one entry per element -- NaN is written where it is set, in the same pass."""
     assert host.dtype == dev.dtype and host.numel() == dev.numel() and host.is_contiguous()
     device = dev.device
     stream = stream if stream is not None else torch.cuda.current_stream(device)
@@ -211,6 +246,9 @@ def upload(host, dev, stream=None, ring=None):
     if nbytes == 0:
         return
     if nbytes < SMALL_BYTES:
+        if mask is not None:
+            host = torch.from_numpy(np.where(mask.reshape(tuple(host.shape)), np.nan,
+                                             host.numpy()).astype(host.numpy().dtype))
         with torch.cuda.stream(stream):
             dev.copy_(host.reshape(dev.shape))  # staged by the runtime itself
         return
@@ -218,10 +256,15 @@ def upload(host, dev, stream=None, ring=None):
     ring = ring if ring is not None else _ring(device)
     _log_range("upload source (caller's memory: read by host memcpy only)", host.data_ptr(), nbytes)
     step = PIECE_BYTES // 8 * 8
+    esz = host.element_size()
+    mask_flat = None if mask is None else mask.reshape(-1)
     for off in range(0, nbytes, step):
         n = min(step, nbytes - off)
         i, buf = ring.acquire()
-        _host_copy(buf[:n], hb[off:off + n])  # caller's bytes -> our staging buffer
+        if mask is None:
+            _host_copy(buf[:n], hb[off:off + n])  # caller's bytes -> our staging buffer
+        else:  # ... with NaN where the caller's masked array is masked
+            _host_copy_masked(buf[:n], hb[off:off + n], mask_flat[off // esz:(off + n) // esz], esz)
         with torch.cuda.stream(stream):
             db[off:off + n].copy_(buf[:n], non_blocking=True)
             ev = torch.cuda.Event()
@@ -428,8 +471,12 @@ class _DeferredSlice:
         self.dtype = a.dtype
         self.shape = (i1 - i0,) + tuple(a.shape[1:])
 
+    def read(self):
+        """the slice as the source returns it (a masked array from a netCDF4-like source)"""
+        return self.a[self.i0:self.i1]
+
     def __array__(self, dtype=None, copy=None):
-        out = as_plain(self.a[self.i0:self.i1])  # (netCDF4 slices are masked arrays)
+        out = as_plain(self.read())  # (masked elements become NaN)
         return out if dtype is None else out.astype(dtype, copy=False)
 
 
@@ -473,7 +520,10 @@ class Uploader:
         out = []
         with torch.cuda.device(self.device):
             for a in arrays:
-                a = np.ascontiguousarray(as_plain(a))
+                if isinstance(a, _DeferredSlice):
+                    a = a.read()  # (here, in the worker: the read of a lazy source)
+                a, mask = split_masked(a)  # (a masked array: NaN-filled while it is staged)
+                a = np.ascontiguousarray(a)
                 if a.dtype not in (np.float32, np.float64):
                     a = a.astype(np.float64)
                 with warnings.catch_warnings():  # read-only views are only read
@@ -484,7 +534,7 @@ class Uploader:
                 # `dev` may reuse memory the consumer's stream is done with: what is enqueued
                 # there so far goes first
                 self.stream.wait_stream(self._main)
-                upload(host, dev, stream=self.stream, ring=self._ring)
+                upload(host, dev, stream=self.stream, ring=self._ring, mask=mask)
                 dev.record_stream(self.stream)
                 out.append(dev)
             ev = torch.cuda.Event()

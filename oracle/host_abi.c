@@ -687,6 +687,31 @@ int mlx_host_copy(void *dst, const void *src, size_t nbytes, int threads, int st
   return 0;
 }
 
+int mlx_host_copy_masked(void *dst, const void *src, const unsigned char *mask, size_t n,
+                         int elem_size, int threads) {
+  /* the checker's build: one plain loop, same contract (include/momlevel_hip.h) */
+  if (n == 0) return 0;
+  if (!dst || !src || !mask) return fail(MLX_E_NULL, "dst, src and mask must not be NULL");
+  if (elem_size != 4 && elem_size != 8) return fail(MLX_E_ENUM, "elem_size must be 4 or 8");
+  if (threads < 1 || threads > 64) return fail(MLX_E_SHAPE, "threads must be in 1..64");
+  if (((uintptr_t)dst | (uintptr_t)src) % (size_t)elem_size)
+    return fail(MLX_E_ALIGN, "dst / src not element-aligned");
+  const unsigned char *s = (const unsigned char *)src, *d = (const unsigned char *)dst;
+  const size_t nbytes = n * (size_t)elem_size;
+  if ((d < s + nbytes && s < d + nbytes) || (d < mask + n && mask < d + nbytes))
+    return fail(MLX_E_SHAPE, "dst overlaps src or mask");
+  if (elem_size == 4) {
+    uint32_t *o = (uint32_t *)dst;
+    const uint32_t *i4 = (const uint32_t *)src;
+    for (size_t i = 0; i < n; ++i) o[i] = mask[i] ? 0x7FC00000u : i4[i];
+  } else {
+    uint64_t *o = (uint64_t *)dst;
+    const uint64_t *i8 = (const uint64_t *)src;
+    for (size_t i = 0; i < n; ++i) o[i] = mask[i] ? 0x7FF8000000000000ull : i8[i];
+  }
+  return 0;
+}
+
 static inline uint64_t splitmix64(uint64_t x) {
   uint64_t z = x + 0x9E3779B97F4A7C15ULL;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;

@@ -23,7 +23,10 @@ from momlevel_amd import core, hostio, synthetic  # noqa: E402
 from momlevel_amd.labeled import DataArray, Dataset  # noqa: E402
 
 
-def run(nt=60, nz=35, reps=2, ny=1080, nx=1440, checker=None, before_call=None):
+def run(nt=60, nz=35, reps=2, ny=1080, nx=1440, checker=None, before_call=None, source="numpy"):
+    """``source``: how thetao / so are held -- "numpy" (plain arrays), "masked" (numpy masked arrays
+    with 1e20 under the mask: an in-memory netCDF4 read) or "masked_lazy" (read slice by slice, every
+    slice a masked array: a netCDF4.Variable; tests/lazy_array.py)."""
     g = synthetic.make_grid(ny, nx, nz)
     vol0 = hostio.to_device(g["volcello"], "cuda")
     kw = dict(seed=synthetic.SEED, mask3d=vol0)
@@ -41,16 +44,30 @@ def run(nt=60, nz=35, reps=2, ny=1080, nx=1440, checker=None, before_call=None):
     d["z_l"] = DataArray(g["z_l"], ("z_l",))
     d["z_i"] = DataArray(g["z_i"], ("z_i",))
     dims = ("time", "z_l", "yh", "xh")
-    d["thetao"] = DataArray(host["thetao"], dims)
-    d["so"] = DataArray(host["so"], dims)
+    if source == "numpy":
+        d["thetao"] = DataArray(host["thetao"], dims)
+        d["so"] = DataArray(host["so"], dims)
+    else:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+        from lazy_array import PrebuiltMaskedLazy as MaskedLazy, as_masked
+
+        held = {name: (MaskedLazy(host[name]) if source == "masked_lazy" else as_masked(host[name]))
+                for name in ("thetao", "so")}
+        t_wrap = time.perf_counter()  # (an in-memory masked array is NaN-filled HERE, once: as_plain)
+        for name in ("thetao", "so"):
+            d[name] = DataArray(held[name], dims)
+        wrap_s = time.perf_counter() - t_wrap
     d["volcello"] = DataArray(np.broadcast_to(g["volcello"].astype(np.float32), shape), dims)
     d["areacello"] = DataArray(g["areacello"].astype(np.float32), ("yh", "xh"))
     d["deptho"] = DataArray(g["deptho"], ("yh", "xh"))
     cells = nt * nz * ny * nx
     out = {"call": "thermosteric(ds)  # domain='local', float32 thetao/so from host memory, delta_rho returned",
+           "source": source,
            "shape_t_z_y_x": list(shape), "cells": cells,
            "host_bytes_in_GB": round(2 * cells * 4 / 1e9, 2),
            "host_bytes_out_GB": round((cells + nt * ny * nx) * 8 / 1e9, 2)}
+    if source != "numpy":
+        out["DataArray_construction_s"] = round(wrap_s, 3)
     walls = []
     res = ref = drho = eta = None
     for _ in range(reps):
@@ -83,8 +100,9 @@ def main():
     ap.add_argument("--nt", type=int, default=60)
     ap.add_argument("--nz", type=int, default=35)
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--source", choices=["numpy", "masked", "masked_lazy"], default="numpy")
     a = ap.parse_args()
-    print(json.dumps(run(a.nt, a.nz, a.reps)), flush=True)
+    print(json.dumps(run(a.nt, a.nz, a.reps, source=a.source)), flush=True)
 
 
 if __name__ == "__main__":

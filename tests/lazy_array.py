@@ -43,3 +43,17 @@ class MaskedLazy(CountingLazy):
         block = self._a[key]
         self.reads.append(int(np.asarray(block).nbytes))
         return as_masked(block)
+
+
+class PrebuiltMaskedLazy(CountingLazy):
+    """As MaskedLazy, but the masked array is built once: slices are VIEWS (no per-read work of the
+    stand-in itself), for timing what the product does with a masked slice."""
+
+    def __init__(self, array):
+        super().__init__(array)
+        self._m = as_masked(array)
+
+    def __getitem__(self, key):
+        block = self._m[key]
+        self.reads.append(int(block.nbytes))
+        return block

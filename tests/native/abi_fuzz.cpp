@@ -162,6 +162,55 @@ int main(int argc, char** argv) {
       fprintf(stderr, "FAIL: mlx_host_copy argument checks\n");
       return 1;
     }
+    // mlx_host_copy_masked on the same buffers: element sizes, offsets, lengths around slice and
+    // vector-width edges, team sizes; guard elements either side
+    unsigned char* mask = (unsigned char*)malloc(cap + 64);
+    for (size_t i = 0; i < cap + 64; ++i) mask[i] = (unsigned char)(((i * 2654435761u) >> 7) % 3 == 0);
+    for (int elem = 4; elem <= 8; elem += 4)
+      for (int threads : teams)
+        for (size_t off = 0; off < 3; ++off)
+          for (size_t n : lens) {
+            const size_t cnt = n / (size_t)elem > 8 ? n / (size_t)elem - 3 * off : n % 7;
+            if (cnt < 4096 && threads > 2) continue;
+            unsigned char* d0 = dst + (1 + off) * (size_t)elem;
+            const unsigned char* s0 = src + off * (size_t)elem;
+            memset(d0 - elem, 0xEE, (size_t)elem);
+            memset(d0 + cnt * (size_t)elem, 0xEE, (size_t)elem);
+            if (mlx_host_copy_masked(d0, s0, mask + off, cnt, elem, threads) != 0) {
+              fprintf(stderr, "FAIL: mlx_host_copy_masked rc (elem %d threads %d n %zu)\n", elem, threads, cnt);
+              return 1;
+            }
+            for (size_t i = 0; i < cnt; ++i) {
+              bool ok;
+              if (elem == 4) {
+                uint32_t got, want; memcpy(&got, d0 + 4 * i, 4); memcpy(&want, s0 + 4 * i, 4);
+                ok = got == (mask[off + i] ? 0x7FC00000u : want);
+              } else {
+                uint64_t got, want; memcpy(&got, d0 + 8 * i, 8); memcpy(&want, s0 + 8 * i, 8);
+                ok = got == (mask[off + i] ? 0x7FF8000000000000ull : want);
+              }
+              if (!ok) {
+                fprintf(stderr, "FAIL: mlx_host_copy_masked value (elem %d threads %d n %zu i %zu)\n", elem, threads, cnt, i);
+                return 1;
+              }
+            }
+            if (d0[-1] != 0xEE || d0[cnt * (size_t)elem] != 0xEE) {
+              fprintf(stderr, "FAIL: mlx_host_copy_masked wrote outside its range\n");
+              return 1;
+            }
+          }
+    if (mlx_host_copy_masked(nullptr, src, mask, 8, 8, 1) != MLX_E_NULL ||
+        mlx_host_copy_masked(dst, src, nullptr, 8, 8, 1) != MLX_E_NULL ||
+        mlx_host_copy_masked(dst, src, mask, 8, 3, 1) != MLX_E_ENUM ||
+        mlx_host_copy_masked(dst, src, mask, 8, 8, 65) != MLX_E_SHAPE ||
+        mlx_host_copy_masked(src + 8, src, mask, 8, 8, 1) != MLX_E_SHAPE ||
+        mlx_host_copy_masked(dst, src, (unsigned char*)dst + 8, 8, 8, 1) != MLX_E_SHAPE ||
+        mlx_host_copy_masked(dst, src, mask, (size_t)-1 / 4, 8, 1) != MLX_E_SHAPE ||
+        mlx_host_copy_masked(nullptr, nullptr, nullptr, 0, 8, 1) != 0) {
+      fprintf(stderr, "FAIL: mlx_host_copy_masked argument checks\n");
+      return 1;
+    }
+    free(mask);
     free(src);
     free(dst);
   }

@@ -116,3 +116,73 @@ def test_host_copy_needs_no_gpu():
     assert lib.mlx_host_copy(outs[0].ctypes.data, a, 64, 0, 1) == -2
     assert lib.mlx_host_copy(outs[0].ctypes.data, a, 64, 65, 1) == -2
     assert lib.mlx_host_copy(None, a, 64, 1, 1) == -1
+
+
+def test_host_copy_masked_needs_no_gpu():
+    """mlx_host_copy_masked (v7): dst = mask ? NaN : src on host memory, float32 and float64 bit
+    patterns (signalling NaNs, denormals, -0.0 in src pass through untouched), one thread or a team,
+    lengths that are not whole slices, guard bytes either side; bad arguments are refused"""
+    lib = _lib.load()
+    r = np.random.default_rng(11)
+    for dt, nan_bits in ((np.float32, 0x7FC00000), (np.float64, 0x7FF8000000000000)):
+        ut = np.uint32 if dt == np.float32 else np.uint64
+        n = (3 << 20) + 1237
+        src = r.integers(0, np.iinfo(ut).max, n, dtype=ut, endpoint=True)  # every bit pattern
+        mask = r.random(n) < 0.3
+        mask[:5000] = True
+        mask[5000:9000] = False
+        want = np.where(mask, ut(nan_bits), src)
+        for threads in (1, 3, 8):
+            for lo, m in ((0, n), (7, n - 19), (4096, 4097), (11, 0), (100, 1)):
+                dst = np.full(n + 2, 0xEEEEEEEE, dtype=ut)
+                rc = lib.mlx_host_copy_masked(dst.ctypes.data + dst.itemsize * (1 + lo),
+                                              src.ctypes.data + src.itemsize * lo,
+                                              mask.ctypes.data + lo, m, dst.itemsize, threads)
+                assert rc == 0, _lib.last_error()
+                assert np.array_equal(dst[1 + lo:1 + lo + m], want[lo:lo + m])
+                assert (dst[:1 + lo] == 0xEEEEEEEE).all() and (dst[1 + lo + m:] == 0xEEEEEEEE).all()
+        out = np.empty(n, dtype=dt)
+        assert lib.mlx_host_copy_masked(out.ctypes.data, src.ctypes.data, mask.ctypes.data, n,
+                                        out.itemsize, 4) == 0
+        assert np.isnan(out[mask]).all()
+    a, mk = src.ctypes.data, mask.ctypes.data
+    d = np.empty(64, dtype=np.float64)
+    assert lib.mlx_host_copy_masked(None, a, mk, 8, 8, 1) == -1
+    assert lib.mlx_host_copy_masked(d.ctypes.data, a, None, 8, 8, 1) == -1
+    assert lib.mlx_host_copy_masked(d.ctypes.data, a, mk, 8, 2, 1) == -3
+    assert lib.mlx_host_copy_masked(d.ctypes.data, a, mk, 8, 8, 0) == -2
+    assert lib.mlx_host_copy_masked(d.ctypes.data + 4, a, mk, 4, 8, 1) == -5
+    assert lib.mlx_host_copy_masked(a + 8, a, mk, 8, 8, 1) == -2 and "overlap" in _lib.last_error()
+    assert lib.mlx_host_copy_masked(d.ctypes.data, a, mk, 0, 8, 1) == 0
+
+
+def test_large_masked_arrays_are_filled_by_the_library():
+    """labeled.as_plain hands floating masked arrays above 4 MiB to mlx_host_copy_masked (the
+    host copy team) -- same result as numpy's where(), the caller's array untouched; small, integer
+    and non-contiguous ones stay with numpy"""
+    from momlevel_amd import labeled
+
+    r = np.random.default_rng(2)
+    a = r.normal(size=(6, 50, 60, 70)).astype(np.float32)  # 5 MB
+    mask = r.random(a.shape) < 0.4
+    m = np.ma.masked_array(a.copy(), mask=mask, fill_value=1e20)
+    m.data[mask] = 1e20
+    calls = []
+    real = labeled._native_fill
+    labeled._native_fill = lambda d, k: calls.append(d.nbytes) or real(d, k)
+    try:
+        got = labeled.as_plain(m)
+        assert calls == [a.nbytes]
+        assert got.dtype == np.float32 and np.array_equal(got, np.where(mask, np.float32(np.nan), a),
+                                                           equal_nan=True)
+        assert (m.data[mask] == np.float32(1e20)).all()
+        got = labeled.as_plain(np.ma.masked_array(a.astype(np.float64), mask=True))  # scalar mask
+        assert calls[-1] == a.size * 8 and np.isnan(got).all()
+        n = len(calls)
+        labeled.as_plain(m[:1])                       # small
+        labeled.as_plain(m.transpose(0, 2, 1, 3))     # not C-contiguous: numpy
+        assert len(calls) == n + 1 and calls[-1] == a.nbytes  # (the transposed one asked, and got None)
+        t = labeled.as_plain(m.transpose(0, 2, 1, 3))
+        assert np.array_equal(t, np.where(mask, np.float32(np.nan), a).transpose(0, 2, 1, 3), equal_nan=True)
+    finally:
+        labeled._native_fill = real

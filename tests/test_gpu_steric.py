@@ -961,6 +961,38 @@ def test_masked_arrays_mean_nan(container, domain, dtype, monkeypatch):
         assert np.abs(res["steric"].values).max() < 1.0  # (1e20 fill values would give ~1e17 m)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("domain", ["local", "global"])
+def test_masked_slices_are_nan_filled_on_their_way_into_the_staging_ring(domain, dtype, monkeypatch):
+    """The masked slices of a lazily read field above hostio.SMALL_BYTES are not NaN-filled into an
+    array of their own: they travel as data + mask and mlx_host_copy_masked writes NaN under the mask
+    while each piece is copied into the page-locked staging buffer (hostio.split_masked / upload).
+    Here with thresholds small enough that the test grid takes that path, in several pieces per
+    chunk with piece edges inside rows: bit-identical to the NaN-filled plain arrays."""
+    from lazy_array import PrebuiltMaskedLazy
+    from momlevel_amd import engine, hostio
+
+    d = _masked_dataset(nt=7, nz=9, ny=28, nx=40, dtype=dtype)
+    base, bref = steric(d, domain=domain)
+    calls = []
+    real = hostio._host_copy_masked
+    monkeypatch.setattr(hostio, "_host_copy_masked",
+                        lambda dst, src, mask, elem: calls.append((dst.numel(), elem)) or real(dst, src, mask, elem))
+    monkeypatch.setattr(hostio, "SMALL_BYTES", 1 << 10)
+    monkeypatch.setattr(hostio, "PIECE_BYTES", 12344)  # (a multiple of 8, not of a row)
+    monkeypatch.setattr(engine, "chunk_steps", lambda nt, b, dev, budget_bytes=None: 3)
+    dm = d.copy()
+    for k in ("thetao", "so"):
+        dm[k] = DataArray(PrebuiltMaskedLazy(np.ascontiguousarray(d[k].values)), d[k].dims)
+    res, ref = steric(dm, domain=domain)
+    assert calls and {e for _, e in calls} == {np.dtype(dtype).itemsize}
+    assert max(n for n, _ in calls) <= 12344 and len(calls) >= 2 * 3 * 3  # fields x chunks x pieces
+    assert_bit_equal(res["steric"].values, base["steric"].values, "fused NaN fill vs NaN-filled inputs")
+    assert_bit_equal(ref["rho"].values, bref["rho"].values)
+    if domain == "local":
+        assert_bit_equal(res["delta_rho"].values, base["delta_rho"].values)
+
+
 @pytest.mark.parametrize("domain", ["local", "global"])
 def test_a_failing_source_raises_from_steric_and_leaves_no_thread_behind(domain, monkeypatch):
     """Uploads are staged by a worker thread (engine.TimeChunks): a source that fails in the middle
