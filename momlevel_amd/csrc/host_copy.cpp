@@ -78,34 +78,78 @@ void copy_slice(unsigned char* d, const unsigned char* s, size_t n, bool streami
 }
 
 // dst[i] = mask[i] ? NaN : src[i] over n elements of 4 or 8 bytes (bit patterns: no float ops, so
-// signalling NaNs and denormals in src pass through untouched).  A plain loop the compiler turns
-// into byte-mask expansion + blend (avx2 where the host has it).
-template <typename U>
-#if defined(__x86_64__)
-__attribute__((target("avx2")))
-#endif
-void fill_masked_avx2(U* __restrict__ d, const U* __restrict__ s, const unsigned char* __restrict__ m,
-                      size_t n, U nan) {
-  for (size_t i = 0; i < n; ++i) d[i] = m[i] ? nan : s[i];
-}
+// signalling NaNs and denormals in src pass through untouched).
 template <typename U>
 void fill_masked_plain(U* __restrict__ d, const U* __restrict__ s,
                        const unsigned char* __restrict__ m, size_t n, U nan) {
   for (size_t i = 0; i < n; ++i) d[i] = m[i] ? nan : s[i];
 }
+#if defined(__x86_64__)
+// avx2: 8 (4) mask bytes widened to 32-bit (64-bit) lanes, compared with zero, blended; the
+// destination -- a page-locked staging buffer the DMA engine reads next, or a fresh array -- written
+// with streaming stores once it is 32-byte aligned (as copy_stream_avx2 does).  The upload of a lazily
+// read masked field runs through here piece by piece and must keep up with the 57 GB/s host link.
+__attribute__((target("avx2"))) void fill_masked32_avx2(uint32_t* d, const uint32_t* s,
+                                                          const unsigned char* m, size_t n) {
+  const uint32_t nanv = 0x7FC00000u;
+  size_t i = 0;
+  while (i < n && (reinterpret_cast<uintptr_t>(d + i) & 31)) {
+    d[i] = m[i] ? nanv : s[i];
+    ++i;
+  }
+  const __m256i nan8 = _mm256_set1_epi32(static_cast<int>(nanv)), zero = _mm256_setzero_si256();
+  for (; i + 16 <= n; i += 16) {
+    const __m128i mb = _mm_loadu_si128(reinterpret_cast<const __m128i*>(m + i));  // 16 mask bytes
+    const __m256i k0 = _mm256_cmpeq_epi32(_mm256_cvtepu8_epi32(mb), zero);         // lanes 0..7: keep?
+    const __m256i k1 = _mm256_cmpeq_epi32(_mm256_cvtepu8_epi32(_mm_srli_si128(mb, 8)), zero);
+    const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i));
+    const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i + 8));
+    _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i), _mm256_blendv_epi8(nan8, a, k0));
+    _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i + 8), _mm256_blendv_epi8(nan8, b, k1));
+  }
+  _mm_sfence();
+  for (; i < n; ++i) d[i] = m[i] ? nanv : s[i];
+}
+__attribute__((target("avx2"))) void fill_masked64_avx2(uint64_t* d, const uint64_t* s,
+                                                          const unsigned char* m, size_t n) {
+  const uint64_t nanv = 0x7FF8000000000000ull;
+  size_t i = 0;
+  while (i < n && (reinterpret_cast<uintptr_t>(d + i) & 31)) {
+    d[i] = m[i] ? nanv : s[i];
+    ++i;
+  }
+  const __m256i nan4 = _mm256_set1_epi64x(static_cast<long long>(nanv)), zero = _mm256_setzero_si256();
+  for (; i + 8 <= n; i += 8) {
+    uint64_t raw;
+    std::memcpy(&raw, m + i, 8);  // 8 mask bytes
+    const __m128i mb = _mm_cvtsi64_si128(static_cast<long long>(raw));
+    const __m256i k0 = _mm256_cmpeq_epi64(_mm256_cvtepu8_epi64(mb), zero);
+    const __m256i k1 = _mm256_cmpeq_epi64(_mm256_cvtepu8_epi64(_mm_srli_si128(mb, 4)), zero);
+    const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i));
+    const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i + 4));
+    _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i), _mm256_blendv_epi8(nan4, a, k0));
+    _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i + 4), _mm256_blendv_epi8(nan4, b, k1));
+  }
+  _mm_sfence();
+  for (; i < n; ++i) d[i] = m[i] ? nanv : s[i];
+}
+#endif
 void fill_masked(unsigned char* d, const unsigned char* s, const unsigned char* m, size_t n,
                  int elem) {
-  const bool wide = have_streaming_stores();  // (= the host has avx2)
   if (elem == 4) {
     auto* dd = reinterpret_cast<uint32_t*>(d);
     auto* ss = reinterpret_cast<const uint32_t*>(s);
-    if (wide) fill_masked_avx2<uint32_t>(dd, ss, m, n, 0x7FC00000u);
-    else fill_masked_plain<uint32_t>(dd, ss, m, n, 0x7FC00000u);
+#if defined(__x86_64__)
+    if (have_streaming_stores()) return fill_masked32_avx2(dd, ss, m, n);
+#endif
+    fill_masked_plain<uint32_t>(dd, ss, m, n, 0x7FC00000u);
   } else {
     auto* dd = reinterpret_cast<uint64_t*>(d);
     auto* ss = reinterpret_cast<const uint64_t*>(s);
-    if (wide) fill_masked_avx2<uint64_t>(dd, ss, m, n, 0x7FF8000000000000ull);
-    else fill_masked_plain<uint64_t>(dd, ss, m, n, 0x7FF8000000000000ull);
+#if defined(__x86_64__)
+    if (have_streaming_stores()) return fill_masked64_avx2(dd, ss, m, n);
+#endif
+    fill_masked_plain<uint64_t>(dd, ss, m, n, 0x7FF8000000000000ull);
   }
 }
 
