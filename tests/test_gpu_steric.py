@@ -378,9 +378,9 @@ def test_cpu_torch_tensors_are_staged_like_numpy_arrays():
 
     real = hostio.upload
 
-    def spy(host, dev, stream=None, ring=None):
+    def spy(host, dev, stream=None, ring=None, mask=None):
         seen.append((host.numel() * host.element_size(), stream is not None))
-        return real(host, dev, stream=stream, ring=ring)
+        return real(host, dev, stream=stream, ring=ring, mask=mask)
 
     hostio.upload, saved = spy, hostio.upload
     try:
