@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Regenerate DESIGN.md section 5.0's tables from the committed evidence: the builder's bench lines
+(profiles/r05_bench_line_*.json) and the counter summaries (profiles/r05_*summary.json).
+
+    python scripts/design_section5.py          # rewrites the block between '### 5.0' and '### 5.1'
+"""
+import glob
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rng(vals, fmt="%.3f"):
+    lo, hi = min(vals), max(vals)
+    return (fmt % lo) if fmt % lo == fmt % hi else f"{fmt % lo}–{fmt % hi}"
+
+
+def main():
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_bench_line_?.json")))
+    lines = [json.load(open(p)) for p in paths]
+    tags = "".join(os.path.basename(p)[-6] for p in paths)
+    last = lines[-1]
+    v = json.load(open(os.path.join(ROOT, "profiles", "r05_variants_summary.json")))
+    v32 = json.load(open(os.path.join(ROOT, "profiles", "r05_f32_variants_summary.json")))
+    s = json.load(open(os.path.join(ROOT, "profiles", "r05_summary.json")))
+    tr = {}
+    for k in v["kernels"]:
+        if k.get("bench_key"):
+            tr[k["bench_key"]] = (k["traffic_over_algorithmic"], k["valu_wave_instr_per_cell"])
+    for k in v32["kernels"]:
+        bk = k.get("bench_key")
+        if bk and not bk.startswith("faithful."):
+            tr["f32." + bk.replace("default.", "").replace("faithful_fused.", "")] = (
+                k["traffic_over_algorithmic"], k["valu_wave_instr_per_cell"])
+    out = []
+    w = out.append
+    w(f"""### 5.0 Round 5 (current kernels; `profiles/r05_*`)
+
+`bench.py` (N=1): 1440×1080×75, 120 steps, fp64, global steric, θ/S resident (223.9 GB). Step = reference state (K0
+rho0 + volo; masso0 is masso(t=0) of the K1 launch) + K1 + stage-2 + area sum + host epilogue, K1 in the product's
+default arithmetic (fused, §3.1). **The output is two lines** since round 5: `BENCH_DETAIL {{…}}` (≈20 KB: every row
+with kernel name, notes, checks, the non-default float32 modes) and, LAST, the contract line (≈5 KB): the contract's
+keys, `roofline` -- with `per_kernel` {{key: [ms, fraction of 8 TB/s at algorithmic bytes, fraction of the matching
+probe, fraction of the live `v_fma_f64` probe]}} and `probes` {{dtype: {{mix: GB/s}}}} -- `cpu_baseline`, parity and a
+checks summary. Round 4's single 25 KB line overflowed the driver's 8 KB stdout tail and lost every float64 extra
+from the record. Numbers below: the builder's {len(lines)} runs of this round (`profiles/r05_bench_line_{{{",".join(tags)}}}.json`,
+one gpurun box each; the K1 / K0 / K2 kernels are the same in all of them, the probes took their final shape with run
+d, the last run is on the final sources `{last["roofline"]["kernel_source_sha"][:8]}…`); counters from
+`profiles/r05_summary.json` / `r05_variants_summary.json` / `r05_f32_variants_summary.json` (final sources; nt = 40
+for the variants). The authoritative line is the driver's `BENCH_r05.json`. (This block is generated:
+`scripts/design_section5.py`.)
+
+| headline | |
+|---|---|""")
+    w(f"| whole-step throughput | **{rng([l['value'] / 1e3 for l in lines], '%.1f')} Gcells/s**, "
+      f"{rng([l['ms_per_step'] for l in lines], '%.2f')} ms/step |")
+    prof = s["bench_lines"].get("bench_trace.log", {}).get("roofline", {})
+    w(f"| K1 launch (HIP events in the timed region) ⇒ 16 B × 1.39968e10 cells = 223.95 GB | "
+      f"{rng([l['roofline']['launch_ms'] for l in lines], '%.2f')} ms ⇒ **{rng([l['roofline']['frac'] for l in lines])} of 8 TB/s**; "
+      f"rocprofv3 `--kernel-trace --stats`: {s['full_batch_launches']} launches, mean {s['full_batch_mean_ms']:.2f} ms "
+      f"({s['full_batch_min_ms']:.2f}–{s['full_batch_max_ms']:.2f}) ⇒ {223.95 / s['full_batch_mean_ms'] / 8:.4f}, against "
+      f"{prof.get('launch_ms', float('nan')):.2f} ms ({prof.get('frac', float('nan')):.4f}) from the HIP events of that same "
+      f"profiled run (`profiles/r05_summary.json` `bench_lines`): the two clocks agree to "
+      f"{abs(prof.get('launch_ms', 0) / s['full_batch_mean_ms'] - 1) * 100:.1f} % |")
+    w(f"| HBM traffic (PMC: 2×FETCH_SIZE + WRITE_SIZE, separate passes) | {s['hbm_traffic_bytes_per_launch'] / 1e9:.2f} GB per "
+      f"launch = {s['hbm_traffic_bytes_per_cell']:.2f} B/cell = **{s['hbm_traffic_bytes_per_cell'] / 16:.3f}×** algorithmic |")
+    p = [l["roofline"]["probes"] for l in lines]
+    fin = [x for x, l in zip(p, lines) if l["roofline"]["kernel_source_sha"] == last["roofline"]["kernel_source_sha"]] or p[-1:]
+    w(f"| same-box ceilings, float64 record (`roofline.probes`, §3.3) | 1 stream read {rng([x['f64']['1r'] for x in p], '%.0f')} GB/s, "
+      f"2 streams read {rng([x['f64']['2r'] for x in p], '%.0f')} (K1 at **{rng([l['roofline']['frac_of_matching_probe'] for l in lines], '%.2f')}** "
+      f"of it), 1 in + 1 out {rng([x['f64']['1r1w'] for x in p], '%.0f')}, 2 in + 1 out {rng([x['f64']['2r1w'] for x in p], '%.0f')}; "
+      f"float32 record (final probes): {rng([x['f32']['1r'] for x in fin], '%.0f')} / {rng([x['f32']['2r'] for x in fin], '%.0f')} / "
+      f"{rng([x['f32']['1r1w'] for x in fin], '%.0f')} / {rng([x['f32']['2r1w'] for x in fin], '%.0f')}; float64 VALU issue "
+      f"(`mlx_valu_probe`) {rng([l['f64_fma_probe_lane_instr_per_s'] / 1e12 for l in lines], '%.1f')}e12 lane-instructions/s |")
+    w(f"| CPU baseline (oracle, numpy, 1 thread, {last['cpu_baseline']['cpu'].replace(' 64-Core Processor', '')}; 6 slabs) | "
+      f"{rng([l['cpu_baseline']['value'] for l in lines], '%.1f')} Mcells/s; 16 processes "
+      f"{rng([l['cpu_baseline_processes']['value'] for l in lines], '%.0f')}; fused C/OpenMP on 16 threads "
+      f"{rng([l['cpu_baseline_fused_openmp']['value'] for l in lines], '%.0f')}; `parity.masso_max_rel_err_vs_oracle` "
+      f"{max(l['parity']['masso_max_rel_err_vs_oracle'] for l in lines):.1e} |")
+    w(f"| the reference's recorded call end to end (`thermosteric(ds)`, 60×35×1080×1440 float32 from host, Δρ returned; "
+      f"PCIe-inclusive, never the bench value) | {rng([min(l['reference_example_call']['wall_s']) for l in lines], '%.2f')} s, "
+      f"{rng([l['reference_example_call']['GB/s_host_link_in_plus_out'] for l in lines], '%.1f')} GB/s in+out, step bit-identical "
+      f"to the oracle |")
+    w("""
+`roofline.per_kernel` (ms and fraction of 8 TB/s: range over the runs; probe / fma fractions: the last run; counter
+traffic over algorithmic bytes and VALU lane-instructions per cell: the committed profiles, nt = 40 -- a 40-step
+record amortises the once-per-tile reads of `rho0m` / the held slab over a third of the bench's 120 steps, which is
+why the float32 η-only held pass reads 1.18× there and 1.035× at nt = 120, §3.3):
+
+| bench key | ms | of 8 TB/s | of its probe | of fma probe | traffic / VALU per cell |
+|---|---|---|---|---|---|""")
+    for k, d in last["roofline"]["per_kernel"].items():
+        vals = [l["roofline"]["per_kernel"][k] for l in lines if k in l["roofline"]["per_kernel"]]
+        t = tr.get(k)
+        w(f"| `{k}` | {rng([x[0] for x in vals], '%.1f')} | {rng([x[1] for x in vals])} | "
+          f"{('%.2f' % d[2]) if d[2] else '—'} | {('%.2f' % d[3]) if d[3] else '—'} | "
+          f"{('%.3f× / %.1f' % t) if t else '—'} |")
+    w("""
+Reading it: K1 steric and K0 sit on the box's own two-stream ceilings (0.94–0.99 of their probes); everything that
+writes Δρ runs at 0.89–0.94 of its read+write probe; what is below 0.8 of its probe is bound by instruction issue
+(0.73–0.85 of the live `v_fma_f64` probe; a `v_rcp_f64` costs 3.3 fma slots, so one IEEE division per cell saturates
+a little below 1.0) -- the exact-arithmetic variants, every float32 held-field / one-pass kernel (4 B per cell cannot
+pay for 23–70 instructions), and the η-only held-field local passes, whose wasted re-reads are gone since round 5
+(§3.3). The float32 passes with Δρ are bimodal from box to box (0.63 vs 0.74).
+""")
+    path = os.path.join(ROOT, "DESIGN.md")
+    text = open(path).read()
+    i0, i1 = text.index("### 5.0 Round 5"), text.index("### 5.1 Earlier rounds")
+    open(path, "w").write(text[:i0] + "\n".join(out) + "\n" + text[i1:])
+    print(f"section 5.0 regenerated from {len(lines)} bench lines")
+
+
+if __name__ == "__main__":
+    main()
