@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import core, hostio
+from .labeled import dtype_name
 
 _GIB = 1 << 30
 
@@ -40,9 +41,7 @@ def to_device(x, device, dtype=None):
 def _stream_dtype(x):
     """float32 fields stay float32 in HBM (half the bytes); everything else -> float64."""
     dt = x.dtype if hasattr(x, "dtype") else np.asarray(x).dtype  # never reads a lazy array
-    if str(dt) in ("torch.float32", "float32"):
-        return torch.float32
-    return torch.float64
+    return torch.float32 if dtype_name(dt) == "float32" else torch.float64  # (any byte order)
 
 
 def chunk_steps(nt, bytes_per_step, device, budget_bytes=None):
@@ -287,7 +286,7 @@ def sum_dtype(x):
     """numpy's result dtype of ``x.sum()`` for a float field: float32 stays float32 (xarray's skipna
     sum is np.sum(where(isnull, 0, x)) in the array's own dtype), anything else is float64 here."""
     dt = x.dtype if hasattr(x, "dtype") else np.asarray(x).dtype
-    return np.float32 if str(dt) in ("torch.float32", "float32") else np.float64
+    return np.float32 if dtype_name(dt) == "float32" else np.float64
 
 
 # ---------------------------------------------------------------------------------------

@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from .. import core, hostio
+from ..labeled import dtype_name
 
 
 def _as_tensor(x, device):
@@ -59,7 +60,7 @@ def _kind(x):
     if _is_weak(x):
         return "weak"
     dt = x.dtype if isinstance(x, torch.Tensor) or _is_lazy(x) else hostio.as_plain(x).dtype
-    name = str(dt).replace("torch.", "")
+    name = dtype_name(dt)  # (byte order does not matter: ">f4" is float32)
     if name in ("float16", "bfloat16", "half"):
         raise TypeError(f"{name} operands are not supported: numpy evaluates their part of the "
                         "equation of state in that precision; convert to float32 or float64")

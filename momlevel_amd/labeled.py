@@ -36,6 +36,20 @@ def is_lazy(x):
     return all(hasattr(x, a) for a in ("shape", "dtype", "__getitem__"))
 
 
+def dtype_name(dt):
+    """"float32", "float64", "int16" ... of a numpy dtype (whatever its BYTE ORDER: ``>f4`` -- what a
+    NetCDF3 file holds and scipy.io.netcdf_file hands out -- is float32 to numpy's promotion and to
+    the reference, which sees it through xarray in native order) or of a torch dtype."""
+    if isinstance(dt, np.dtype) or not str(dt).startswith("torch."):
+        return np.dtype(dt).name
+    return str(dt).replace("torch.", "")
+
+
+def _native(a):
+    """``a`` in the host's byte order (a copy only when it is not)"""
+    return a if a.dtype.isnative else a.astype(a.dtype.newbyteorder("="))
+
+
 def as_plain(a):
     """What ``xr.DataArray(a)`` holds for a host array ``a`` -- the container every input of the
     reference arrives in (steric.py:84-96; examples/example.ipynb cell 4).  A ``numpy.ma``
@@ -47,13 +61,16 @@ def as_plain(a):
     masked keeps its dtype).  ``np.asarray`` would instead DROP the mask and leave the fill values
     (1e20 ...) to be computed on.  Anything else goes through ``np.asarray`` untouched: no copy of a
     plain array, and an unmasked masked array gives a view of its data.  (A dask array is computed
-    first: its chunks may be masked arrays too, and its own ``__array__`` would drop their masks.)"""
+    first: its chunks may be masked arrays too, and its own ``__array__`` would drop their masks.)
+    The result is always in the host's BYTE ORDER: big-endian data (NetCDF3 on disk) are float32 /
+    float64 like any other to numpy and to the reference; every dtype test downstream compares with
+    the native types."""
     if not isinstance(a, np.ndarray) and callable(getattr(a, "compute", None)):
         a = a.compute()
     if not isinstance(a, np.ma.MaskedArray):
-        return np.asarray(a)
+        return _native(np.asarray(a))
     mask = np.ma.getmask(a)
-    data = np.ma.getdata(a)
+    data = _native(np.ma.getdata(a))
     if mask is np.ma.nomask or not mask.any():
         return np.asarray(data)
     kind = data.dtype.kind
@@ -186,9 +203,8 @@ class DataArray:
 
     @property
     def dtype(self):
-        if _is_tensor(self.data):
-            return np.dtype(str(self.data.dtype).replace("torch.", ""))
-        return np.dtype(self.data.dtype)
+        # (native byte order whatever a lazy source stores: reads come back native, as_plain)
+        return np.dtype(dtype_name(self.data.dtype))
 
     @property
     def is_lazy(self):

@@ -175,8 +175,9 @@ def _annual_mean_array(values, years, weights):
 
 def _np_dtype(var):
     """numpy dtype of a labelled variable WITHOUT copying device data to the host."""
-    dt = var.data.dtype
-    return np.dtype(str(dt).replace("torch.", "")) if not isinstance(dt, np.dtype) else dt
+    from .labeled import dtype_name
+
+    return np.dtype(dtype_name(var.data.dtype))
 
 
 class AnnualPlan:

@@ -57,3 +57,45 @@ class PrebuiltMaskedLazy(CountingLazy):
         block = self._m[key]
         self.reads.append(int(block.nbytes))
         return block
+
+
+class NetCDFVar:
+    """A variable of a ``scipy.io.netcdf_file`` (a REAL NetCDF-3 reader: big-endian data on disk,
+    ``maskandscale=True`` -> every read is a numpy masked array honouring ``_FillValue`` /
+    ``missing_value``) with the three attributes momlevel_amd asks of a lazy source: ``shape``,
+    ``dtype``, slicing.  (netCDF4 / h5py / zarr variables have them; scipy's lacks ``dtype``.)"""
+
+    def __init__(self, var):
+        self._v = var
+        self.shape = tuple(var.shape)
+        self.dtype = var.data.dtype  # ">f4" / ">f8": the file's byte order
+        self.ndim = len(self.shape)
+        self.reads = []
+
+    def __getitem__(self, key):
+        block = self._v[key]
+        self.reads.append(int(np.asarray(block).nbytes))
+        return block
+
+    def __len__(self):
+        return self.shape[0]
+
+
+def write_netcdf3(path, dset, fill=FILL):
+    """``dset`` (a momlevel_amd Dataset of numpy-backed variables) as a NetCDF-3 file: NaN cells
+    stored as ``_FillValue`` (what MOM6 writes for land), dims and coordinates as they are."""
+    from scipy.io import netcdf_file
+
+    with netcdf_file(path, "w") as f:
+        for name in ("time", "z_l", "z_i", "yh", "xh"):
+            f.createDimension(name, len(dset[name].values))
+        for name in dset.variables:
+            da = dset[name]
+            a = np.asarray(da.values)
+            code = "f" if a.dtype == np.float32 else "d"
+            v = f.createVariable(name, code, tuple(da.dims))
+            nan = np.isnan(a)
+            v[:] = np.where(nan, a.dtype.type(fill), a)
+            if nan.any():
+                v._FillValue = a.dtype.type(fill)
+                v.missing_value = a.dtype.type(fill)

@@ -120,6 +120,32 @@ def test_calc_rho_on_masked_arrays(monkeypatch):
     assert_bit_equal(rho.values, o.calc_rho(S, T, p))
 
 
+def test_big_endian_fields_compute_in_their_own_precision():
+    """">f4" arrays (NetCDF-3 on disk; scipy.io.netcdf_file) are float32 to numpy: the polynomial is
+    evaluated in float32 (eos/wright.py:44-46 on float32 arrays), not upcast to float64 because a
+    dtype test did not recognise the byte order.  Same bits as the native arrays, for the numpy-level
+    EOS functions (tuned and promote kernels) and for calc_rho."""
+    from momlevel_amd.eos import wright
+
+    T = dset1.thetao.values.astype(np.float32)
+    S = dset1.so.values.astype(np.float32)
+    p = dset1.z_l.values[:, None, None] * 1.0e4
+    for func in (wright.density, wright.alpha, wright.beta, wright.drho_dtemp):
+        want = func(T, S, p)
+        got = func(T.astype(">f4"), S.astype(">f4"), p.astype(">f8"))
+        assert got.dtype == want.dtype
+        assert_bit_equal(got, want, func.__name__)
+    want = wright.density(T, S, 2.0e5)  # python-float pressure: float32 throughout (the promote kernel)
+    got = wright.density(T.astype(">f4"), S.astype(">f4"), 2.0e5)
+    assert got.dtype == want.dtype == np.float32
+    assert_bit_equal(got, want)
+    assert_bit_equal(want, o.wright_density(T, S, 2.0e5))
+    dims, coords = dset1.thetao.dims, dict(dset1.thetao.coords)
+    rho = derived.calc_rho(DataArray(T.astype(">f4"), dims, coords), DataArray(S.astype(">f4"), dims, coords),
+                           dset1.z_l * 1.0e4)
+    assert_bit_equal(rho.values, o.calc_rho(T, S, dset1.z_l.values * 1.0e4))
+
+
 def test_calc_rho_held_field_broadcast_order():
     """halosteric's call: thetao (z,y,x), so (t,z,y,x) -> dims in first-appearance order."""
     rho = derived.calc_rho(dset1.thetao.isel(time=0), dset1.so, dset1.z_l * 1.0e4)

@@ -993,6 +993,53 @@ def test_masked_slices_are_nan_filled_on_their_way_into_the_staging_ring(domain,
         assert_bit_equal(res["delta_rho"].values, base["delta_rho"].values)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("domain", ["local", "global"])
+def test_steric_from_a_netcdf3_file(domain, dtype, tmp_path, monkeypatch):
+    """The advertised lazy route with a REAL reader: the dataset is written as a NetCDF-3 file (NaN
+    cells as _FillValue 1e20, what MOM6 writes on land) and read back through scipy.io.netcdf_file
+    with ``maskandscale=True`` -- every read is a BIG-ENDIAN numpy masked array.  The 4-D fields stay
+    on disk and are read one time chunk at a time; steric() returns the bits of the same call on the
+    in-memory NaN-filled arrays (for float32 fields that means numpy's float32 polynomial, not a
+    silent float64 upcast of ">f4"), i.e. the oracle's."""
+    from scipy.io import netcdf_file
+
+    from lazy_array import NetCDFVar, write_netcdf3
+    from momlevel_amd import engine
+
+    d = _masked_dataset(nt=7, dtype=dtype)
+    base, bref = steric(d, domain=domain)
+    path = str(tmp_path / "ocean.nc")
+    write_netcdf3(path, d)
+    monkeypatch.setattr(engine, "chunk_steps", lambda nt, b, dev, budget_bytes=None: 2)
+    f = netcdf_file(path, "r", mmap=False, maskandscale=True)
+    try:
+        dl = Dataset()
+        lazies = {}
+        for name, var in f.variables.items():
+            if len(var.shape) == 4:
+                lazies[name] = NetCDFVar(var)
+                dl[name] = DataArray(lazies[name], tuple(var.dimensions))
+            else:
+                dl[name] = DataArray(var[:], tuple(var.dimensions))  # a masked array or a plain one
+        assert str(lazies["thetao"].dtype) == (">f4" if dtype == np.float32 else ">f8")
+        assert dl["thetao"].dtype == np.dtype(dtype) and dl["thetao"].is_lazy
+        assert isinstance(lazies["thetao"][0:1], np.ma.MaskedArray)
+        res, ref = steric(dl, domain=domain)
+        step = d["thetao"].values[0].nbytes
+        assert max(lazies["thetao"].reads) <= 2 * step  # never more than one time chunk
+    finally:
+        f.close()
+    assert_bit_equal(res["steric"].values, base["steric"].values, "NetCDF-3 file vs in-memory arrays")
+    assert_bit_equal(ref["rho"].values, bref["rho"].values)
+    assert float(ref["volo"]) == float(bref["volo"])
+    if domain == "local":
+        assert_bit_equal(res["delta_rho"].values, base["delta_rho"].values)
+        ores, _ = _oracle(d)
+        if dtype == np.float64:
+            assert_bit_equal(res["steric"].values, ores["steric"])
+
+
 @pytest.mark.parametrize("domain", ["local", "global"])
 def test_a_failing_source_raises_from_steric_and_leaves_no_thread_behind(domain, monkeypatch):
     """Uploads are staged by a worker thread (engine.TimeChunks): a source that fails in the middle

@@ -539,3 +539,52 @@ def test_as_plain_property_random_masked_arrays():
         assert np.array_equal(np.ma.getmaskarray(m), before[1])
 
     check()
+
+
+def test_big_endian_data_are_float32_and_float64_like_any_other(tmp_path):
+    """NetCDF-3 stores big-endian; scipy.io.netcdf_file hands out ">f4" / ">f8" (masked) arrays.
+    numpy -- and the reference, which sees such data through xarray in native order -- treats them as
+    float32 / float64; a dtype test written ``str(dt) == "float32"`` or ``dt in (np.float32, ...)``
+    does not (``np.dtype(">f4") == np.float32`` is False) and would send float32 fields down the
+    float64 path.  Every entry of host data returns native byte order; every dtype query goes through
+    labeled.dtype_name."""
+    from scipy.io import netcdf_file
+
+    from lazy_array import NetCDFVar, write_netcdf3
+    from momlevel_amd import engine
+    from momlevel_amd.eos import _dispatch
+    from momlevel_amd.labeled import as_plain, dtype_name
+
+    be = np.arange(6, dtype=">f4").reshape(2, 3)
+    assert dtype_name(be.dtype) == "float32" and dtype_name(np.dtype(">f8")) == "float64"
+    got = as_plain(be)
+    assert got.dtype == np.float32 and got.dtype.isnative and np.array_equal(got, be)
+    m = as_plain(np.ma.masked_array(be, mask=[[0, 1, 0], [0, 0, 0]]))
+    assert m.dtype == np.float32 and m.dtype.isnative and np.isnan(m[0, 1]) and m[1, 2] == 5
+    assert DataArray(be).dtype == np.float32
+    assert _dispatch._kind(be) == "f32" and _dispatch._kind(be.astype(">f8")) == "f64"
+    assert str(engine._stream_dtype(be)) == "torch.float32" and engine.sum_dtype(be) is np.float32
+    t = engine._host_tensor(be)
+    assert str(t.dtype) == "torch.float32" and np.array_equal(t.numpy(), be)
+    # ... and from a real file
+    d = generate_test_data()
+    d32 = d.copy()
+    for k in ("thetao", "so"):
+        a = d[k].values.astype(np.float32)
+        a[:, 0, 1, :] = np.nan
+        d32[k] = DataArray(a, d[k].dims)
+    path = str(tmp_path / "t.nc")
+    write_netcdf3(path, d32)
+    f = netcdf_file(path, "r", mmap=False, maskandscale=True)
+    try:
+        v = NetCDFVar(f.variables["thetao"])
+        assert str(v.dtype) == ">f4" and isinstance(v[0:1], np.ma.MaskedArray)
+        da = DataArray(v, tuple(f.variables["thetao"].dimensions))
+        assert da.is_lazy and da.dtype == np.float32
+        vals = da.values
+        assert vals.dtype == np.float32 and vals.dtype.isnative
+        assert np.array_equal(vals, d32["thetao"].values, equal_nan=True)
+        slab = da.isel({"time": 2}).squeeze().values
+        assert np.array_equal(slab, d32["thetao"].values[2], equal_nan=True)
+    finally:
+        f.close()
