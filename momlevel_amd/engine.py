@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import core, hostio
-from .labeled import dtype_name
+from .labeled import check_field_dtype, dtype_name
 
 _GIB = 1 << 30
 
@@ -41,7 +41,8 @@ def to_device(x, device, dtype=None):
 def _stream_dtype(x):
     """float32 fields stay float32 in HBM (half the bytes); everything else -> float64."""
     dt = x.dtype if hasattr(x, "dtype") else np.asarray(x).dtype  # never reads a lazy array
-    return torch.float32 if dtype_name(dt) == "float32" else torch.float64  # (any byte order)
+    # (any byte order; float16 / long double fields are refused, not upcast: check_field_dtype)
+    return torch.float32 if check_field_dtype(dt) == "float32" else torch.float64
 
 
 def chunk_steps(nt, bytes_per_step, device, budget_bytes=None):

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from .. import core, hostio
-from ..labeled import dtype_name
+from ..labeled import check_field_dtype
 
 
 def _as_tensor(x, device):
@@ -60,10 +60,7 @@ def _kind(x):
     if _is_weak(x):
         return "weak"
     dt = x.dtype if isinstance(x, torch.Tensor) or _is_lazy(x) else hostio.as_plain(x).dtype
-    name = dtype_name(dt)  # (byte order does not matter: ">f4" is float32)
-    if name in ("float16", "bfloat16", "half"):
-        raise TypeError(f"{name} operands are not supported: numpy evaluates their part of the "
-                        "equation of state in that precision; convert to float32 or float64")
+    name = check_field_dtype(dt, "operands")  # (byte order does not matter: ">f4" is float32)
     return "f32" if name == "float32" else "f64"
 
 

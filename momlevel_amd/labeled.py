@@ -45,6 +45,22 @@ def dtype_name(dt):
     return str(dt).replace("torch.", "")
 
 
+_UNSUPPORTED = ("float16", "bfloat16", "half", "float128", "longdouble", "complex64", "complex128",
+                "complex256")
+
+
+def check_field_dtype(dt, what="theta / salinity"):
+    """numpy evaluates the equation of state on float16 (or long double) arrays IN that precision --
+    the python-float constants of eos/wright.py take the arrays' dtype -- which no kernel here
+    restates; rather than answer in other bits (a silent float64 upcast), such fields are refused.
+    float32 / float64 pass; integers and booleans compute as float64, as in numpy."""
+    name = dtype_name(dt)
+    if name in _UNSUPPORTED:
+        raise TypeError(f"{name} {what} are not supported: numpy evaluates their part of the "
+                        "equation of state in that precision; convert to float32 or float64")
+    return name
+
+
 def _native(a):
     """``a`` in the host's byte order (a copy only when it is not)"""
     return a if a.dtype.isnative else a.astype(a.dtype.newbyteorder("="))

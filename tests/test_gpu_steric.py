@@ -993,6 +993,18 @@ def test_masked_slices_are_nan_filled_on_their_way_into_the_staging_ring(domain,
         assert_bit_equal(res["delta_rho"].values, base["delta_rho"].values)
 
 
+@pytest.mark.parametrize("domain", ["local", "global"])
+def test_float16_fields_are_refused_on_the_steric_path_too(domain):
+    """numpy evaluates eos/wright.py on float16 arrays in float16; a silent float64 upcast would
+    answer in other bits.  The EOS functions refused such operands already; steric() now does too."""
+    d = _masked_dataset(nt=3)
+    d16 = d.copy()
+    d16["thetao"] = DataArray(d["thetao"].values.astype(np.float16), d["thetao"].dims)
+    with pytest.raises(TypeError, match="float16"):
+        steric(d16, domain=domain)
+    steric(d, domain=domain)  # (and the next call works)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("domain", ["local", "global"])
 def test_steric_from_a_netcdf3_file(domain, dtype, tmp_path, monkeypatch):

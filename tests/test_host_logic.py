@@ -588,3 +588,15 @@ def test_big_endian_data_are_float32_and_float64_like_any_other(tmp_path):
         assert np.array_equal(slab, d32["thetao"].values[2], equal_nan=True)
     finally:
         f.close()
+
+
+def test_field_dtypes_that_numpy_would_compute_in_are_refused_not_upcast():
+    from momlevel_amd import engine
+    from momlevel_amd.labeled import check_field_dtype
+
+    assert check_field_dtype(np.dtype(">f4")) == "float32" and check_field_dtype(np.int16) == "int16"
+    for bad in (np.float16, np.longdouble, np.complex128):
+        with pytest.raises(TypeError, match="not supported"):
+            check_field_dtype(np.dtype(bad))
+        with pytest.raises(TypeError):
+            engine._stream_dtype(np.zeros(3, dtype=bad))
