@@ -186,3 +186,35 @@ def test_large_masked_arrays_are_filled_by_the_library():
         assert np.array_equal(t, np.where(mask, np.float32(np.nan), a).transpose(0, 2, 1, 3), equal_nan=True)
     finally:
         labeled._native_fill = real
+
+
+def test_plain_and_masked_copies_share_the_team_concurrently():
+    """the upload worker (masked slices), the download worker (plain copies) and the caller's thread
+    (as_plain of an in-memory masked array) all use ONE team of native threads at the same time"""
+    import threading
+
+    lib = _lib.load()
+    r = np.random.default_rng(5)
+    n = (4 << 20) + 333
+    src = r.normal(size=n).astype(np.float32)
+    mask = r.random(n) < 0.5
+    want = np.where(mask, np.float32(np.nan), src)
+    errors = []
+
+    def masked():
+        for _ in range(6):
+            out = np.empty(n, dtype=np.float32)
+            if lib.mlx_host_copy_masked(out.ctypes.data, src.ctypes.data, mask.ctypes.data, n, 4, 5) != 0 \
+                    or not np.array_equal(out, want, equal_nan=True):
+                errors.append("masked")
+
+    def plain():
+        for _ in range(6):
+            out = np.empty(n, dtype=np.float32)
+            if lib.mlx_host_copy(out.ctypes.data, src.ctypes.data, n * 4, 4, 1) != 0 or not np.array_equal(out, src):
+                errors.append("plain")
+
+    jobs = [threading.Thread(target=f) for f in (masked, plain, masked, plain)]
+    [j.start() for j in jobs]
+    [j.join() for j in jobs]
+    assert errors == []
