@@ -136,6 +136,34 @@ def _native_fill(data, mask):
     return out
 
 
+class LazySource:
+    """``shape`` / ``dtype`` / slicing for a sliceable source that lacks a ``dtype`` attribute of its
+    own -- ``scipy.io.netcdf_file`` variables keep theirs on ``.data`` -- so that it is read slice by
+    slice like any netCDF4 / h5py / zarr variable instead of being np.asarray'ed into nonsense."""
+
+    def __init__(self, source, dtype):
+        self.source = source
+        self.shape = tuple(source.shape)
+        self.dtype = np.dtype(dtype)
+        self.ndim = len(self.shape)
+
+    def __getitem__(self, key):
+        return self.source[key]
+
+    def __len__(self):
+        return self.shape[0]
+
+
+def _as_lazy_source(x):
+    """x itself, or a LazySource around it when it is array-shaped and sliceable but keeps its dtype
+    elsewhere (``x.data.dtype``)"""
+    if (not _is_tensor(x) and not isinstance(x, (np.ndarray, np.generic, list, tuple, int, float, bool))
+            and hasattr(x, "shape") and hasattr(x, "__getitem__") and not hasattr(x, "dtype")
+            and hasattr(getattr(x, "data", None), "dtype")):
+        return LazySource(x, x.data.dtype)
+    return x
+
+
 def _to_numpy(x):
     if _is_tensor(x):
         from . import hostio
@@ -187,6 +215,7 @@ class DataArray:
             coords = data.coords if coords is None else coords
             attrs = data.attrs if attrs is None else attrs
             data = data.data
+        data = _as_lazy_source(data)  # (a scipy.io netcdf variable: no dtype attribute of its own)
         if not _is_tensor(data) and not is_lazy(data):
             data = as_plain(data)  # (a numpy masked array becomes NaN-filled here, once)
         ndim = len(data.shape)

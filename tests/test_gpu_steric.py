@@ -1029,8 +1029,11 @@ def test_steric_from_a_netcdf3_file(domain, dtype, tmp_path, monkeypatch):
         dl = Dataset()
         lazies = {}
         for name, var in f.variables.items():
-            if len(var.shape) == 4:
-                lazies[name] = NetCDFVar(var)
+            if len(var.shape) == 4 and name == "so":
+                dl[name] = DataArray(var, tuple(var.dimensions))  # the scipy variable as it is
+                assert dl[name].is_lazy and dl[name].dtype == np.dtype(dtype)
+            elif len(var.shape) == 4:
+                lazies[name] = NetCDFVar(var)  # (counts the reads)
                 dl[name] = DataArray(lazies[name], tuple(var.dimensions))
             else:
                 dl[name] = DataArray(var[:], tuple(var.dimensions))  # a masked array or a plain one

@@ -577,6 +577,12 @@ def test_big_endian_data_are_float32_and_float64_like_any_other(tmp_path):
     write_netcdf3(path, d32)
     f = netcdf_file(path, "r", mmap=False, maskandscale=True)
     try:
+        # a scipy variable handed over as it is (it has no dtype attribute): wrapped, stays lazy
+        raw = DataArray(f.variables["thetao"], tuple(f.variables["thetao"].dimensions))
+        assert raw.is_lazy and raw.dtype == np.float32 and raw.shape == d32["thetao"].shape
+        assert np.array_equal(raw.values, d32["thetao"].values, equal_nan=True)
+        assert np.array_equal(raw.isel({"time": 1}).values, d32["thetao"].values[1], equal_nan=True)
+        del raw
         v = NetCDFVar(f.variables["thetao"])
         assert str(v.dtype) == ">f4" and isinstance(v[0:1], np.ma.MaskedArray)
         da = DataArray(v, tuple(f.variables["thetao"].dimensions))
