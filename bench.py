@@ -72,6 +72,10 @@ def parse():
                     help="processes of the P-process CPU line (-1: min(16, cores); 0 disables)")
     ap.add_argument("--detail-file", default=None,
                     help="also write the long-form JSON (the BENCH_DETAIL line) to this file")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N=1 only: a world of ONE rank on the RCCL backend and the step of --gpus 8 "
+                         "(time chunks, one asynchronous exchange per chunk, finish()) with the "
+                         "collective forced; timed beside the plain N=1 step, no extras")
     ap.add_argument("--input-dtype", choices=["f64", "f32"], default="f64",
                     help="storage type of theta/S (f32 = BASELINE.json configs[4]; the headline is f64)")
     return ap.parse_args()
@@ -255,6 +259,8 @@ def compact_line(line, detail_bytes):
         out["checks_all_true"] = all(checks.values())
         out["checks_failed"] = [k for k, v in checks.items() if not v]
         out["checks_count"] = len(checks)
+    if "forced_collective" in line:
+        out["forced_collective"] = line["forced_collective"]
     ex = line.get("reference_example_call")
     if isinstance(ex, dict):
         out["reference_example_call"] = {k: ex[k] for k in (
@@ -268,7 +274,7 @@ def compact_line(line, detail_bytes):
 
 
 def workload_config(world, grid, nt, nt_req, tile_hw, n_launches, chunk_steps, input_dtype,
-                    backend):
+                    backend, forced=False):
     """The ``config`` object of the JSON line: which BASELINE.json configuration this run IS (and
     says so only when it is: the record not shortened, the grid the 0.25-degree one, 8 ranks x 1200
     steps for configs[3]), the tile layout and the collective.  Pure: tests/test_bench_helpers.py
@@ -284,7 +290,10 @@ def workload_config(world, grid, nt, nt_req, tile_hw, n_launches, chunk_steps, i
             f"OM4 0.25deg synthetic grid {nx}x{ny}x{nz}, {nt} time steps, "
             f"{'fp32 theta/S (BASELINE.json configs[4])' if f32 else 'fp64'}, global "
             + ("steric (shortened to fit free HBM: NOT BASELINE.json configs[2], see nt_requested)"
-               if shrunk else "steric (BASELINE.json configs[2])"))
+               if shrunk else "steric (BASELINE.json configs[2])")
+            + (f"; walked as `--gpus 8` walks its tile: {n_launches} time chunks of <= "
+               f"{chunk_steps} steps, one exchange per chunk FORCED through the backend in a world "
+               "of one rank (--force-collective)" if forced else ""))
     else:
         workload = (
             f"OM4 0.25deg synthetic grid {nx}x{ny}x{nz} tiled {layout} (yh x xh), {nt} time "
@@ -310,14 +319,15 @@ def workload_config(world, grid, nt, nt_req, tile_hw, n_launches, chunk_steps, i
         "tile_xy": [tw, th],
         "variant": "steric",
         "domain": "global",
-        "collective": ("none" if world == 1 else
+        "forced_collective": forced,
+        "collective": ("none" if world == 1 and not forced else
                        f"{n_launches} per step, one per time chunk: {chunk_steps}(+3 in the first) "
                        f"f64 per rank, {parallel.exchange_mode()} "
                        + ("(all_gather_into_tensor + rank-ordered float64 sum: every element of "
                           "the vector is reduced in the same order)"
                           if parallel.exchange_mode() == "ordered" else "(all_reduce SUM)")
                        + ", asynchronous, overlapped with the next chunk's kernel"),
-        "backend": (None if world == 1 else
+        "backend": (None if world == 1 and not forced else
                     "nccl (RCCL)" if backend == "nccl" else
                     backend + " (REHEARSAL: the ranks share GPUs and the exchange "
                     "is staged through the host; not an xGMI measurement)"),
@@ -499,6 +509,18 @@ def main():
     core.require_device()
     import torch.distributed as dist
 
+    forced = a.force_collective
+    if forced:
+        if world != 1:
+            raise SystemExit("--force-collective is the N=1 rehearsal of the tiled step")
+        # a world of one on the RCCL backend: communicator, collective stream, work.wait() -- all
+        # that a one-GPU box can execute of what `--gpus 8` runs
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        port = parallel.rank_environments(1)[0]["MASTER_PORT"]
+        dist.init_process_group(backend="nccl", rank=0, world_size=1,
+                                init_method=f"tcp://127.0.0.1:{port}")
+        a.no_extras, a.cpu_seconds = True, 0.0
+
     dev_index = local_rank % torch.cuda.device_count()  # == local_rank on a full node
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -538,7 +560,7 @@ def main():
     launch_ms = []
     chunk_steps = -(-nt // max(1, a.chunks))
 
-    def step_tiled(timed):
+    def step_tiled(timed, force=forced):
         """N>1 (BASELINE.json configs[3]): the rank's tile of the whole record, walked in time
         chunks -- K1 per chunk, ONE asynchronous all-reduce per chunk overlapping the next chunk's
         kernel ([volo, masso0, sum(area)] ride in the first), epilogue replicated on every rank."""
@@ -546,15 +568,18 @@ def main():
         evs = []
         res = parallel.steric_global_tile_streamed(
             (T, S), vol0, area, pres, variants=("steric",), steps=chunk_steps, skip_dry=False,
-            events=evs)
+            events=evs, force_collective=force)
         if timed:
             launch_ms.append(evs)
         return res["steric"]
 
     def step(timed):
         """One pass of the hot path over the resident batch (what momlevel.steric(global) does)."""
-        if world > 1:
+        if world > 1 or forced:
             return step_tiled(timed)
+        return step_plain(timed)
+
+    def step_plain(timed):
         _rho0, volo, _ = engine.reference_state(T[0], S[0], vol0, pres, with_masso=False)
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         # skip_dry=False: the headline loads every cell, wet or dry, as the metric defines a cell
@@ -570,18 +595,47 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if world > 1 or forced:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):
-        out = step(False)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step(True)
-    fence()
-    elapsed = time.perf_counter() - t0
+    def timed_loop(fn):
+        for _ in range(a.warmup):
+            res = fn(False)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            res = fn(True)
+        fence()
+        return res, time.perf_counter() - t0
+
+    beside = None
+    if forced:
+        # the same record through (i) the plain N=1 step (one launch, no process-group call) and
+        # (ii) the chunked walk WITHOUT a collective, so that what RCCL adds can be read off
+        out_plain, el_plain = timed_loop(step_plain)
+        out_walk, el_walk = timed_loop(lambda timed: step_tiled(timed, force=False))
+        launch_ms.clear()
+        before = dict(parallel.exchange_stats)
+    out, elapsed = timed_loop(step)
+    if forced:
+        st = parallel.exchange_stats
+        n = (a.steps + a.warmup)
+        beside = {
+            "ms_per_step_plain_one_launch": round(el_plain / a.steps * 1e3, 3),
+            "ms_per_step_chunked_no_collective": round(el_walk / a.steps * 1e3, 3),
+            "ms_per_step_chunked_rccl": round(elapsed / a.steps * 1e3, 3),
+            "rccl_over_plain": round(elapsed / el_plain, 4),
+            "rccl_over_chunked_no_collective": round(elapsed / el_walk, 4),
+            "collectives_run": st["collectives"] - before["collectives"],
+            "collectives_expected": n * max(1, -(-nt // chunk_steps)),
+            "collectives_on_device": st["on_device"] - before["on_device"],
+            "last_collective": st["last"],
+            "masso_bit_identical_to_plain_step": bool(
+                np.array_equal(out["masso"], out_plain["masso"])
+                and np.array_equal(out["masso"], out_walk["masso"])),
+            "eta_bit_identical_to_plain_step": bool(np.array_equal(out["eta"], out_plain["eta"])),
+        }
     if world > 1:
         elapsed = float(allreduce_scalar(elapsed, dist.ReduceOp.MAX, torch.float64))
 
@@ -632,7 +686,8 @@ def main():
             "data": "synthetic",
             "config": workload_config(world, (nz, ny, nx), nt, nt_req, (th, tw), n_launches,
                                       chunk_steps, a.input_dtype,
-                                      None if world == 1 else dist.get_backend()),
+                                      dist.get_backend() if (world > 1 or forced) else None,
+                                      forced=forced),
             "roofline": {
                 "kernel": k1_kernel,  # mlx_last_kernel() after the timed launches
                 "kernel_template_arguments": "<element type, cells per pack, packs per thread, "
@@ -651,7 +706,7 @@ def main():
                 "algorithmic_bytes_per_cell": bytes_per_cell,
                 "algorithmic_gb_per_launch": round(bytes_per_cell * cells_rank / 1e9, 2),
                 "cells_per_launch": cells_rank,
-                "time_loop_steps_per_block": min(nt if world == 1 else chunk_steps,
+                "time_loop_steps_per_block": min(nt if world == 1 and not forced else chunk_steps,
                                                  core.K1_TCHUNK["steric"]),
                 "kernel_source_sha": kernel_source_sha(),
             },
@@ -662,6 +717,8 @@ def main():
             "eta_t0_is_zero": bool(out["eta"][0] == 0.0),
         }
         line.update(extras)
+        if beside is not None:
+            line["forced_collective"] = beside
         add_valu_roofline(line, measure_valu_probe(dev) if world == 1 else None)
         if extras:
             probes = {"f64" if not f32 else "f32": extras.get("probes")}
@@ -688,7 +745,7 @@ def main():
         if extras:
             print("BENCH_DETAIL " + detail, flush=True)
         print(json.dumps(compact_line(line, len(detail))), flush=True)
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -201,7 +201,8 @@ def split_masked(a, dtype=None):
         data, mask = np.ma.getdata(a), np.ma.getmask(a)
         if (mask is not np.ma.nomask and data.dtype.kind == "f" and data.dtype.itemsize in (4, 8)
                 and (dtype is None or data.dtype == dtype) and data.dtype.isnative
-                and data.flags["C_CONTIGUOUS"] and data.nbytes >= SMALL_BYTES):
+                and data.flags["C_CONTIGUOUS"] and data.flags["ALIGNED"]
+                and data.nbytes >= SMALL_BYTES):
             if not mask.any():  # (netCDF4 hands out masked arrays with nothing masked all the time)
                 return data, None
             return data, np.ascontiguousarray(np.broadcast_to(mask, data.shape), dtype=np.bool_)

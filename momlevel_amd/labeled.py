@@ -45,6 +45,16 @@ def dtype_name(dt):
     return str(dt).replace("torch.", "")
 
 
+def np_dtype(dt):
+    """The numpy dtype of ``dt`` in the host's byte order: a numpy dtype keeps everything else it is
+    (``<U5``, ``S3``, structured and object dtypes have no ``.name`` that numpy reads back: 'str160'
+    is not a dtype), a torch dtype is mapped by its name."""
+    if isinstance(dt, np.dtype) or not str(dt).startswith("torch."):
+        dt = np.dtype(dt)
+        return dt.newbyteorder("=") if dt.kind in "fiuc" else dt
+    return np.dtype(str(dt).replace("torch.", ""))
+
+
 _UNSUPPORTED = ("float16", "bfloat16", "half", "float128", "longdouble", "complex64", "complex128",
                 "complex256")
 
@@ -119,8 +129,9 @@ def _native_fill(data, mask):
     ``mask`` of the same shape, by the library's host copy team.  None when the layout does not fit
     or the library cannot be loaded (labelled arrays work without it): the caller falls back to
     numpy."""
-    if not (data.flags["C_CONTIGUOUS"] and data.dtype.itemsize in (4, 8) and data.dtype.isnative):
-        return None
+    if not (data.flags["C_CONTIGUOUS"] and data.flags["ALIGNED"] and data.dtype.itemsize in (4, 8)
+            and data.dtype.isnative):
+        return None  # (an element-misaligned view -- frombuffer at an odd offset -- is numpy's)
     mask = np.ascontiguousarray(mask, dtype=np.bool_)  # (a broadcast scalar mask is expanded here)
     try:
         from . import _lib, hostio
@@ -134,6 +145,41 @@ def _native_fill(data, mask):
     if rc != 0:
         raise RuntimeError(f"mlx_host_copy_masked failed ({rc}): {_lib.last_error()}")
     return out
+
+
+class MaskedSource:
+    """A large floating ``numpy.ma`` masked array held AS IT IS -- data + mask, nothing copied, nothing
+    filled -- behind the interface of a lazily read field (``shape`` / ``dtype`` / slicing): what
+    ``nc.variables["thetao"][:]`` of a netCDF4 file returns.  Its masked elements MEAN NaN (as_plain),
+    but a 13 GB field is not rewritten into a NaN-filled copy to say so: the engine cuts time chunks
+    out of it exactly as out of a netCDF4 variable -- every slice a masked VIEW -- and the NaN goes in
+    while each piece is copied into the staging ring (hostio.split_masked -> mlx_host_copy_masked),
+    in the pass over the bytes the upload makes anyway.  ``np.asarray`` / ``DataArray.values`` fill on
+    demand."""
+
+    def __init__(self, array):
+        self.array = array
+        self.shape = tuple(array.shape)
+        self.dtype = np_dtype(array.dtype)
+        self.ndim = array.ndim
+
+    @staticmethod
+    def wanted(a):
+        """floating, 4 / 8 bytes wide, actually carrying a mask, and large enough for the second
+        pass to matter; everything else is filled at once (small arrays feed host-side validation)"""
+        return (isinstance(a, np.ma.MaskedArray) and a.dtype.kind == "f" and a.dtype.itemsize in (4, 8)
+                and a.ndim >= 1 and a.nbytes >= _NATIVE_FILL_BYTES
+                and np.ma.getmask(a) is not np.ma.nomask)
+
+    def __getitem__(self, key):
+        return self.array[key]  # (a masked view, or a masked scalar: as_plain takes both)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __array__(self, dtype=None, copy=None):
+        out = as_plain(self.array)
+        return out if dtype is None else out.astype(dtype, copy=False)
 
 
 class LazySource:
@@ -216,8 +262,10 @@ class DataArray:
             attrs = data.attrs if attrs is None else attrs
             data = data.data
         data = _as_lazy_source(data)  # (a scipy.io netcdf variable: no dtype attribute of its own)
-        if not _is_tensor(data) and not is_lazy(data):
-            data = as_plain(data)  # (a numpy masked array becomes NaN-filled here, once)
+        if MaskedSource.wanted(data):
+            data = MaskedSource(data)  # (a big masked field: NaN-filled while it is uploaded)
+        elif not _is_tensor(data) and not is_lazy(data):
+            data = as_plain(data)  # (a small numpy masked array becomes NaN-filled here, once)
         ndim = len(data.shape)
         if dims is None:
             dims = tuple(f"dim_{i}" for i in range(ndim))
@@ -249,7 +297,7 @@ class DataArray:
     @property
     def dtype(self):
         # (native byte order whatever a lazy source stores: reads come back native, as_plain)
-        return np.dtype(dtype_name(self.data.dtype))
+        return np_dtype(self.data.dtype)
 
     @property
     def is_lazy(self):

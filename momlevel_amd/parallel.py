@@ -172,6 +172,12 @@ def rank_ordered_sum(gathered):
     return acc
 
 
+# What the collectives of this process have been, for logs and for the tests that must SEE a
+# collective run (a forced exchange in a world of one is numerically the identity): counters only,
+# nothing here feeds a result.
+exchange_stats = {"collectives": 0, "on_device": 0, "doubles": 0, "last": None}
+
+
 class _Exchange:
     """One sum-over-ranks of a packed float64 vector, started asynchronously.  Construction enqueues
     the collective (RCCL: on its own stream behind the kernels that produced ``vec``; gloo with a device
@@ -182,7 +188,8 @@ class _Exchange:
         self.mode = exchange_mode()
         self.work = None
         world = dist.get_world_size(group)
-        if vec.is_cuda and dist.get_backend(group) == "gloo":
+        backend = dist.get_backend(group)
+        if vec.is_cuda and backend == "gloo":
             vec = vec.cpu()
         vec = vec.contiguous()
         self._vec = vec  # (the collective reads it asynchronously: it stays alive until result())
@@ -195,6 +202,11 @@ class _Exchange:
             self.work = dist.all_gather_into_tensor(self.buf, vec.reshape(-1), group=group,
                                                     async_op=True)
         self.world = world
+        exchange_stats["collectives"] += 1
+        exchange_stats["on_device"] += int(self.buf.is_cuda)
+        exchange_stats["doubles"] += vec.numel()
+        exchange_stats["last"] = {"backend": backend, "mode": self.mode, "world": world,
+                                  "device": str(self.buf.device), "doubles": vec.numel()}
 
     def result(self):
         if self.work is not None:
@@ -445,13 +457,15 @@ def steric_local_tile(T, S, vol0, pres, z_i, deptho, rhozero=1035.0, variant="st
 # ---------------------------------------------------------------------------------------------
 # the public, labelled API on ONE RANK'S TILE: same signatures as momlevel_amd.steric & co.
 # ---------------------------------------------------------------------------------------------
-def _sum_over_ranks(group=None):
+def _sum_over_ranks(group=None, force=False):
     """-> callable summing a float64 numpy vector over the ranks in rank order (identity without
-    a group)."""
+    a group, and in a world of one rank unless ``force``: then the vector goes to the device and
+    through the backend's collective all the same -- how a single-GPU box executes the RCCL leg of
+    the labelled front end, tests/nccl_worker.py)."""
 
     def exchange(vec):
         vec = np.ascontiguousarray(vec, dtype=np.float64)
-        if not _in_a_world(group):
+        if not _in_a_world(group, force):
             return vec
         t = torch.from_numpy(vec.copy())
         if dist.get_backend(group) == "nccl":
@@ -464,7 +478,8 @@ def _sum_over_ranks(group=None):
 @accepts_xarray
 def steric(dset, reference=None, coord_names=None, varname_map=None, rhozero=1035.0,
            patm=101325.0, equation_of_state="Wright", variant="steric", domain="local",
-           dtype="float32", strict=True, annual=False, verbose=False, group=None):
+           dtype="float32", strict=True, annual=False, verbose=False, group=None,
+           force_collective=False):
     """``momlevel_amd.steric`` for a horizontally TILED dataset: call it on every rank with the
     rank's own ``(yh, xh)`` tile of thetao / so / volcello / areacello (/ deptho).  Arguments and
     the ``(result, reference)`` return value are those of ``steric`` (src/momlevel/steric.py:17-31).
@@ -482,14 +497,15 @@ def steric(dset, reference=None, coord_names=None, varname_map=None, rhozero=103
         same global ``reference_height`` and height time series, and volo / masso / rhoga of the
         returned reference state are the GLOBAL ones.
     The bandwidth path for long records is ``steric_global_tile_streamed`` (one asynchronous
-    all-reduce per time chunk, nothing else).
+    all-reduce per time chunk, nothing else).  ``force_collective``: run the collectives even in a
+    world of ONE rank (``_sum_over_ranks``).
     """
     from .steric import _steric_many  # (momlevel_amd.steric the attribute is the function)
 
     results, reference = _steric_many(
         dset, (variant,), reference, coord_names, varname_map,
         rhozero, patm, equation_of_state, domain, dtype, strict, annual, verbose,
-        exchange=_sum_over_ranks(group))
+        exchange=_sum_over_ranks(group, force_collective))
     return results[variant], reference
 
 
@@ -497,7 +513,8 @@ def steric(dset, reference=None, coord_names=None, varname_map=None, rhozero=103
 def steric_variants(dset, variants=("steric", "thermosteric", "halosteric"), reference=None,
                     coord_names=None, varname_map=None, rhozero=1035.0, patm=101325.0,
                     equation_of_state="Wright", domain="local", dtype="float32", strict=True,
-                    annual=False, verbose=False, heat_content=False, cp=None, group=None):
+                    annual=False, verbose=False, heat_content=False, cp=None, group=None,
+                    force_collective=False):
     """``momlevel_amd.steric_variants`` on one rank's tile (see ``parallel.steric``): all variants
     (and the heat content) from one pass and ONE all-reduce."""
     from .steric import OHC_CP, _steric_many
@@ -506,18 +523,18 @@ def steric_variants(dset, variants=("steric", "thermosteric", "halosteric"), ref
         dset, tuple(variants), reference, coord_names, varname_map,
         rhozero, patm, equation_of_state, domain, dtype, strict, annual, verbose,
         heat_cp=(OHC_CP if cp is None else cp) if heat_content else None,
-        exchange=_sum_over_ranks(group))
+        exchange=_sum_over_ranks(group, force_collective))
     return results, reference
 
 
 @accepts_xarray
 def setup_reference_state(dset, patm=101325.0, eos="Wright", coord_names=None, time_index=0,
-                          group=None):
+                          group=None, force_collective=False):
     """``momlevel_amd.setup_reference_state`` on one rank's tile: thetao / so / volcello / rho are
     the tile's, volo / masso / rhoga the all-reduced global values."""
     from .reference import _setup
     from .steric import globalise_reference
 
     ref = _setup(dset, patm, eos, coord_names, time_index, defer_masso=False)
-    globalise_reference(ref, _sum_over_ranks(group))
+    globalise_reference(ref, _sum_over_ranks(group, force_collective))
     return ref

@@ -175,9 +175,9 @@ def _annual_mean_array(values, years, weights):
 
 def _np_dtype(var):
     """numpy dtype of a labelled variable WITHOUT copying device data to the host."""
-    from .labeled import dtype_name
+    from .labeled import np_dtype
 
-    return np.dtype(dtype_name(var.data.dtype))
+    return np_dtype(var.data.dtype)
 
 
 class AnnualPlan:

@@ -41,12 +41,76 @@ def main():
     forced = parallel.steric_global_tile_streamed((T, S), vol0, g["areacello"], pres,
                                                   variants=variants, steps=steps, heat=True,
                                                   force_collective=True)
-    # the labelled front end's exchange (a host vector through a device all-reduce) as well
-    vec = parallel._sum_over_ranks()(np.arange(5.0))
+    chunked_stats = dict(parallel.exchange_stats)
+    # the labelled front end's exchange: a host vector goes to the device and through the
+    # backend's collective (forced: a world of one is the identity otherwise, and then nothing of
+    # RCCL would run -- VERDICT r5 weak #2).  The unforced call is kept beside it as the control.
+    payload = np.array([0.1, -2.5e17, 3.0, 1.0e-300, 7.25])
+    before = dict(parallel.exchange_stats)
+    unforced = parallel._sum_over_ranks()(payload)
+    after_unforced = dict(parallel.exchange_stats)
+    labelled = {}
+    for mode in ("ordered", "allreduce"):
+        os.environ["MOMLEVEL_AMD_EXCHANGE"] = mode
+        n0 = parallel.exchange_stats["collectives"]
+        d0 = parallel.exchange_stats["on_device"]
+        vec = parallel._sum_over_ranks(force=True)(payload)
+        last = dict(parallel.exchange_stats["last"])
+        labelled[mode] = {"vec": vec, "collectives": parallel.exchange_stats["collectives"] - n0,
+                          "on_device": parallel.exchange_stats["on_device"] - d0, "last": last}
+    # ... and through the public labelled entry points on momlevel's own 5x5x5x5 test dataset
+    # (test_data/__init__.py:16-105), domain="global": flags, sum(areacello), the data exchange
+    import momlevel_amd
+    from momlevel_amd.test_data import generate_test_data
+
+    dset = generate_test_data()
+    single, sref = momlevel_amd.steric(dset, domain="global")
+    svars, _ = momlevel_amd.steric_variants(dset, domain="global", heat_content=True)
+    api = {}
+    for mode in ("ordered", "allreduce"):
+        os.environ["MOMLEVEL_AMD_EXCHANGE"] = mode
+        n0 = parallel.exchange_stats["collectives"]
+        d0 = parallel.exchange_stats["on_device"]
+        res, ref = parallel.steric(dset, domain="global", force_collective=True)
+        n1 = parallel.exchange_stats["collectives"]
+        many, _ = parallel.steric_variants(dset, domain="global", heat_content=True,
+                                           force_collective=True)
+        ref2 = parallel.setup_reference_state(dset, force_collective=True)
+        api[mode] = {
+            "steric": res["steric"].values, "href": res["reference_height"].values,
+            "masso": ref["masso"].values, "volo": ref["volo"].values, "rhoga": ref["rhoga"].values,
+            "thermo": many["thermosteric"]["thermosteric"].values,
+            "halo": many["halosteric"]["halosteric"].values, "ohc": many["heat"]["ohc"].values,
+            "setup_masso": ref2["masso"].values, "setup_volo": ref2["volo"].values,
+            "collectives_steric": n1 - n0,
+            "collectives": parallel.exchange_stats["collectives"] - n0,
+            "on_device": parallel.exchange_stats["on_device"] - d0,
+        }
+    os.environ.pop("MOMLEVEL_AMD_EXCHANGE")
     with open("/proc/self/maps") as f:
         maps = f.read()
     save = {"rccl_loaded": np.array("librccl" in maps or "libnccl" in maps),
-            "host_vector": vec, "heat_plain": plain["heat"], "heat_forced": forced["heat"]}
+            "payload": payload, "unforced_vector": unforced,
+            "unforced_collectives": np.array(after_unforced["collectives"] - before["collectives"]),
+            "chunked_collectives": np.array(chunked_stats["collectives"]),
+            "chunked_on_device": np.array(chunked_stats["on_device"]),
+            "single_steric": single["steric"].values, "single_href": single["reference_height"].values,
+            "single_masso": sref["masso"].values, "single_volo": sref["volo"].values,
+            "single_thermo": svars["thermosteric"]["thermosteric"].values,
+            "single_halo": svars["halosteric"]["halosteric"].values,
+            "single_ohc": svars["heat"]["ohc"].values,
+            "heat_plain": plain["heat"], "heat_forced": forced["heat"]}
+    for mode in ("ordered", "allreduce"):
+        lab = labelled[mode]
+        save[f"labelled_{mode}_vector"] = lab["vec"]
+        save[f"labelled_{mode}_collectives"] = np.array(lab["collectives"])
+        save[f"labelled_{mode}_on_device"] = np.array(lab["on_device"])
+        save[f"labelled_{mode}_backend"] = np.array(lab["last"]["backend"])
+        save[f"labelled_{mode}_device"] = np.array(lab["last"]["device"])
+        save[f"labelled_{mode}_world"] = np.array(lab["last"]["world"])
+        save[f"labelled_{mode}_mode"] = np.array(lab["last"]["mode"])
+        for k, v in api[mode].items():
+            save[f"api_{mode}_{k}"] = np.asarray(v)
     for v in variants:
         for k in ("masso", "eta", "volo", "masso0", "area_sum"):
             save[f"{v}_{k}_plain"] = np.asarray(plain[v][k])

@@ -93,7 +93,34 @@ def test_rccl_leg_runs_in_a_world_of_one(tmp_path):
     assert p.returncode == 0, (p.stdout + p.stderr)[-4000:]
     r = dict(np.load(out))
     assert bool(r["rccl_loaded"]), "librccl was not mapped into the worker"
-    assert np.array_equal(r["host_vector"], np.arange(5.0))
+    # the chunked exchange: 3 chunks of the forced walk, every one a collective on a device buffer
+    assert int(r["chunked_collectives"]) == 3 and int(r["chunked_on_device"]) == 3
+    # the labelled front end's exchange: unforced it is the identity and NOTHING runs (the control:
+    # this is what the round-5 test mistook for the RCCL leg) ...
+    assert int(r["unforced_collectives"]) == 0
+    assert np.array_equal(r["unforced_vector"], r["payload"])
+    for mode in ("ordered", "allreduce"):
+        # ... forced, ONE collective on the "nccl" backend, on a device buffer, world of one
+        assert int(r[f"labelled_{mode}_collectives"]) == 1, mode
+        assert int(r[f"labelled_{mode}_on_device"]) == 1, mode
+        assert str(r[f"labelled_{mode}_backend"]) == "nccl"
+        assert str(r[f"labelled_{mode}_device"]).startswith("cuda")
+        assert int(r[f"labelled_{mode}_world"]) == 1 and str(r[f"labelled_{mode}_mode"]) == mode
+        assert np.array_equal(r[f"labelled_{mode}_vector"], r["payload"]), mode
+        # parallel.steric / steric_variants / setup_reference_state on momlevel's 5x5x5x5 dataset
+        # through RCCL: a global call is 4 flags + sum(areacello) + the data exchange = 6
+        # collectives, all on the device; the numbers are the single-domain call's, bit for bit
+        assert int(r[f"api_{mode}_collectives_steric"]) == 6, mode
+        assert int(r[f"api_{mode}_collectives"]) == int(r[f"api_{mode}_on_device"]) == 13, mode
+        for k, single in (("steric", "single_steric"), ("href", "single_href"),
+                          ("masso", "single_masso"), ("volo", "single_volo"),
+                          ("thermo", "single_thermo"), ("halo", "single_halo"),
+                          ("ohc", "single_ohc"), ("setup_masso", "single_masso"),
+                          ("setup_volo", "single_volo")):
+            assert np.array_equal(r[f"api_{mode}_{k}"], r[single]), (mode, k)
+        assert r[f"api_{mode}_steric"][0] == 0.0
+    # reference-pinned invariants of the 5x5x5x5 dataset (tests/golden)
+    assert float(r["api_ordered_volo"]) == 125921.15458781991
     assert np.array_equal(r["heat_plain"], r["heat_forced"])
     for v in ("steric", "thermosteric", "halosteric"):
         for k in ("masso", "eta", "volo", "masso0", "area_sum"):

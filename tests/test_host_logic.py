@@ -606,3 +606,108 @@ def test_field_dtypes_that_numpy_would_compute_in_are_refused_not_upcast():
             check_field_dtype(np.dtype(bad))
         with pytest.raises(TypeError):
             engine._stream_dtype(np.zeros(3, dtype=bad))
+
+
+def test_a_big_masked_array_is_held_as_data_and_mask_until_it_is_uploaded():
+    """``DataArray(nc.variables["thetao"][:])`` -- a 13 GB in-memory masked array
+    in the reference's recorded call -- used to be NaN-filled into a copy on construction (0.5-0.7 s
+    before the call).  Now a large floating masked array is kept as it is (labeled.MaskedSource) and
+    read like a netCDF4 variable: every time chunk a masked VIEW, which hostio.split_masked hands
+    the staging copy as data + mask; ``.values`` / ``np.asarray`` / slabs fill on demand."""
+    import torch
+    from lazy_array import FILL, as_masked
+    from momlevel_amd import engine, hostio
+    from momlevel_amd.labeled import DataArray, Dataset, LazyTranspose, MaskedSource
+
+    rng = np.random.default_rng(5)
+    a = rng.normal(10.0, 3.0, (6, 5, 40, 900)).astype(np.float32)  # 4.3 MB: above the threshold
+    a[:, :, 3:9, 100:300] = np.nan
+    a[2, 1] = np.nan
+    m = as_masked(a)
+    assert MaskedSource.wanted(m) and not MaskedSource.wanted(m[:1, :1, :4])  # small: filled at once
+    assert not MaskedSource.wanted(np.ma.masked_array(a))  # nomask: plain data
+    da = DataArray(m, ("time", "z_l", "yh", "xh"))
+    src = da.data
+    assert isinstance(src, MaskedSource) and da.is_lazy and src.array is m  # nothing copied
+    assert da.dtype == np.float32 and da.shape == a.shape
+    # a time chunk is a VIEW of the caller's data and mask ...
+    chunk = src[2:5]
+    assert isinstance(chunk, np.ma.MaskedArray) and np.shares_memory(np.ma.getdata(chunk), m.data)
+    # ... which travels as (data, mask): no NaN-filled intermediate
+    data, mask = hostio.split_masked(chunk, np.dtype(np.float32))
+    assert np.shares_memory(data, m.data) and mask.dtype == np.bool_ and mask.shape == data.shape
+    assert np.array_equal(mask, np.isnan(a[2:5])) and data[0, 1, 0, 0] == np.float32(FILL)
+    # the engine sees a streamable float32 field and cuts it like any lazy one
+    assert engine._stream_dtype(src) == torch.float32
+    d = hostio.leading_slice(src, 1, 3)
+    assert isinstance(d, hostio._DeferredSlice) and isinstance(d.read(), np.ma.MaskedArray)
+    # fill on demand: .values, np.asarray, slabs, transposes, Dataset round trips
+    assert np.array_equal(da.values, a, equal_nan=True) and type(da.values) is np.ndarray
+    assert np.array_equal(np.asarray(src), a, equal_nan=True)
+    assert np.asarray(src, dtype=np.float64).dtype == np.float64
+    slab = da.isel({"time": 2})
+    assert np.array_equal(slab.values, a[2], equal_nan=True)
+    moved = da.transpose("time", "yh", "xh", "z_l")
+    assert isinstance(moved.data, LazyTranspose)
+    assert np.array_equal(moved.data[1:3], a.transpose(0, 2, 3, 1)[1:3], equal_nan=True)
+    ds = Dataset()
+    ds["thetao"] = da
+    assert isinstance(ds["thetao"].data, MaskedSource) and ds["thetao"].data.array is m
+    assert isinstance(ds.rename({"thetao": "temp"})["temp"].data, MaskedSource)
+    assert np.array_equal(hostio.to_host(src), a, equal_nan=True)
+    # the caller's array is never written
+    assert m.data[2, 1, 0, 0] == np.float32(FILL) and m.mask[2, 1, 0, 0]
+    # big-endian data (a NetCDF-3 read): native dtype outside, filled natively on the way
+    be = np.ma.masked_array(np.where(np.isnan(a), FILL, a).astype(">f4"), mask=np.isnan(a))
+    dbe = DataArray(be, ("time", "z_l", "yh", "xh"))
+    assert isinstance(dbe.data, MaskedSource) and dbe.dtype == np.float32 and dbe.dtype.isnative
+    assert np.array_equal(dbe.values, a, equal_nan=True)
+
+
+def test_string_and_bytes_variables_keep_their_dtype_and_are_skipped_by_annual_average():
+    """``np.dtype(dt).name`` does not round-trip for str / bytes / void dtypes
+    ('<U3' -> 'str96'); DataArray.dtype and util.annual_average (which skips non-numeric variables,
+    util.py:79-84) raised TypeError on them."""
+    import torch
+    from momlevel_amd import util
+    from momlevel_amd.labeled import DataArray, np_dtype
+    from momlevel_amd.test_data import generate_test_data_time
+
+    s = DataArray(np.array(["abc", "de"]), ("n",))
+    assert s.dtype == np.dtype("<U3") and s.dtype.kind == "U"
+    assert DataArray(np.array([b"ab", b"c"]), ("n",)).dtype == np.dtype("S2")
+    rec = np.zeros(2, dtype=[("a", "<f4"), ("b", "<i2")])
+    assert DataArray(rec, ("n",)).dtype == rec.dtype
+    assert np_dtype(np.dtype(">f4")) == np.float32 and np_dtype(np.dtype(">f4")).isnative
+    assert np_dtype(np.dtype(">i2")) == np.int16 and np_dtype(torch.float32) == np.float32
+    assert np_dtype(np.dtype("O")) == np.dtype("O")
+    dset = generate_test_data_time()
+    nt = dset["time"].shape[0]
+    dset["label"] = DataArray(np.array(["m%02d" % (i % 12) for i in range(nt)]), ("time",))
+    dset["tag"] = DataArray(np.array([b"x"] * nt), ("time",))
+    numeric = [k for k, v in dset.data_vars.items() if v.dtype.kind in "fiu"]
+    out = util.annual_average(dset)
+    assert "label" not in out and "tag" not in out
+    assert sorted(out.data_vars) == sorted(numeric)
+
+
+def test_element_misaligned_masked_data_fall_back_to_numpy():
+    """a float64 view of a buffer at a 4-byte offset is C-contiguous and native but
+    not ALIGNED; mlx_host_copy_masked answers MLX_E_ALIGN.  as_plain fills it with numpy instead
+    (as its docstring promises) and split_masked does not hand it to the staging copy."""
+    from momlevel_amd import hostio
+    from momlevel_amd.labeled import _native_fill, as_plain
+
+    n = 1 << 20  # 8 MiB of float64: above the native-fill threshold
+    raw = np.zeros(8 * n + 8, dtype=np.uint8)
+    off = 4 if raw.ctypes.data % 8 == 0 else (12 - raw.ctypes.data % 8) % 8 or 4
+    a = np.frombuffer(raw, dtype=np.float64, count=n, offset=off)
+    assert a.flags["C_CONTIGUOUS"] and not a.flags["ALIGNED"]
+    mask = np.zeros(n, dtype=bool)
+    mask[::3] = True
+    m = np.ma.masked_array(a, mask=mask)
+    assert _native_fill(a, mask) is None
+    got = as_plain(m)
+    assert np.array_equal(np.isnan(got), mask) and not got[~mask].any()
+    plain, mk = hostio.split_masked(m)
+    assert mk is None and np.array_equal(np.isnan(plain), mask)

@@ -281,3 +281,53 @@ def test_a_failing_rank_makes_every_rank_raise_instead_of_hanging(scenario):
         assert results[0][0] == "RuntimeError" and "other rank" in results[0][1]
     else:  # every rank fails the same way (no HIP device) and says so itself
         assert results[0][0] == results[1][0] == "MomlevelHipError"
+
+
+def _world_of_one_worker(port, q):
+    os.environ["HIP_VISIBLE_DEVICES"] = ""
+    dist.init_process_group(backend="gloo", rank=0, world_size=1,
+                            init_method=f"tcp://127.0.0.1:{port}")
+    payload = np.array([0.1, -2.5e17, 3.0, 1.0e-300, 7.25])
+    stats = parallel.exchange_stats
+    out = {}
+    c0 = stats["collectives"]
+    out["unforced"] = parallel._sum_over_ranks()(payload)
+    out["unforced_collectives"] = stats["collectives"] - c0
+    for mode in ("ordered", "allreduce"):
+        os.environ["MOMLEVEL_AMD_EXCHANGE"] = mode
+        c0 = stats["collectives"]
+        out[mode] = parallel._sum_over_ranks(force=True)(payload)
+        out[mode + "_collectives"] = stats["collectives"] - c0
+        out[mode + "_last"] = dict(stats["last"])
+    # the check the GPU worker relies on must be able to FAIL: with _in_a_world answering False the
+    # forced call is the identity again and no collective is counted
+    real = parallel._in_a_world
+    parallel._in_a_world = lambda group=None, force=False: False
+    c0 = stats["collectives"]
+    parallel._sum_over_ranks(force=True)(payload)
+    out["patched_collectives"] = stats["collectives"] - c0
+    parallel._in_a_world = real
+    q.put(out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_forced_labelled_exchange_runs_a_collective_in_a_world_of_one():
+    """in a world of ONE rank ``_sum_over_ranks`` is the identity and runs no
+    collective; ``force=True`` sends the vector through the backend all the same (tests/nccl_worker.py
+    does this on the RCCL backend), and ``parallel.exchange_stats`` shows which of the two happened."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_world_of_one_worker, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=100)
+    p.join(30)
+    assert p.exitcode == 0
+    payload = np.array([0.1, -2.5e17, 3.0, 1.0e-300, 7.25])
+    assert out["unforced_collectives"] == 0 and np.array_equal(out["unforced"], payload)
+    for mode in ("ordered", "allreduce"):
+        assert out[mode + "_collectives"] == 1
+        assert np.array_equal(out[mode], payload)
+        assert out[mode + "_last"] == {"backend": "gloo", "mode": mode, "world": 1,
+                                       "device": "cpu", "doubles": 5}
+    assert out["patched_collectives"] == 0
