@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MLX_ABI_VERSION 7 /* 2: mlx_eos_map takes flags; mlx_steric_global_decomp, mlx_steric_local_decomp,
+#define MLX_ABI_VERSION 8 /* 2: mlx_eos_map takes flags; mlx_steric_global_decomp, mlx_steric_local_decomp,
                              mlx_stream_probe;
                              MLX_FLAG_FMA, MLX_FLAG_TCHUNK; MLX_P_FULL4D in K1/K2
                              3: mlx_build_kind; a NULL p (linear EOS) requires p_mode MLX_P_SCALAR
@@ -46,7 +46,8 @@ extern "C" {
                              5: mlx_stream_probe_mix, mlx_valu_probe, mlx_last_kernel
                              6: mlx_host_copy; mlx_stratification, mlx_adjust_negative_n2,
                                 mlx_wave_speed_where_time0
-                             7: mlx_host_copy_masked */
+                             7: mlx_host_copy_masked
+                             8: mlx_host_prefault; MLX_FUNC_DENSITY_REF in mlx_eos_map_promote */
 
 /* argument-error codes (negative) */
 #define MLX_E_NULL     (-1) /* a required pointer is NULL                      */
@@ -66,6 +67,7 @@ extern "C" {
 #define MLX_FUNC_ALPHA      3 /* eos/wright.py:122-142 */
 #define MLX_FUNC_BETA       4 /* eos/wright.py:145-165 */
 #define MLX_FUNC_IBH        5 /* dynamic.py:34-36, via mlx_inverse_barometer only */
+#define MLX_FUNC_DENSITY_REF 6 /* eos/linear.py:55-56 with rho_ref given; mlx_eos_map_promote only */
 
 /* how the pressure argument is laid out */
 #define MLX_P_SCALAR  0 /* p[0] for every cell (calc_pdens, scalar calls)            */
@@ -168,7 +170,11 @@ int mlx_eos_map(const void *T, const void *S, int dtype,
  *                                during the call; stride ignored.
  * func: any MLX_FUNC_* (MLX_FUNC_IBH: out = p * (-1.0 / (rho * gravity)), dynamic.py:34-36, gravity a
  * python float; ignored otherwise).  The linear EOS never reads p: it may be NULL there and takes no
- * part in the promotion.  The result comes back IN NUMPY'S RESULT DTYPE: out is a device buffer of
+ * part in the promotion -- except for MLX_FUNC_DENSITY_REF (MLX_EOS_LINEAR only, MLX_E_ENUM
+ * otherwise): eos.linear.density(T, S, p, rho_ref) with rho_ref given, whose constant term
+ * c = RHO_T0_S0 - rho_ref (src/momlevel/eos/linear.py:55; a python float, or a numpy scalar when
+ * rho_ref is one) arrives IN THE p OPERAND with its kind, and out = c + ((-0.2*T) + (0.8*S)) under
+ * numpy's promotion (:56).  The result comes back IN NUMPY'S RESULT DTYPE: out is a device buffer of
  * n*8 bytes, 8-byte aligned; *out_kind (host, required) receives MLX_KIND_F32 when numpy's result
  * is float32 -- out then holds n float32 values (its first n*4 bytes) -- and MLX_KIND_F64 when out
  * holds n float64 values.  (The kind depends on the operand kinds, eos and func only.)
@@ -423,6 +429,19 @@ int mlx_host_copy(void *dst, const void *src, size_t nbytes, int threads, int st
  * MLX_E_ENUM.  Touches no device. */
 int mlx_host_copy_masked(void *dst, const void *src, const unsigned char *mask, size_t n,
                          int elem_size, int threads);
+
+/* Make the pages of [addr, addr + nbytes) of WRITABLE host memory present WITHOUT changing a byte of
+ * it, front to back, on `threads` (1..64) threads of its own (not the copy team: it runs beside the
+ * copies).  For the fresh result arrays of the local variants (momlevel_amd/hostio.py result_array:
+ * 2 MiB-aligned anonymous mappings advised MADV_HUGEPAGE): the reference's `delta_rho` is a 4-D
+ * float64 field (src/momlevel/steric.py:150-157) and the first touch of 27 GB of new pages by the
+ * threads that copy results out of the staging ring ran at 47-57 GB/s, below the host link; faulted
+ * in AHEAD of the copy, while the first time chunk is uploaded and computed, the copy-out finds warm
+ * pages (105-190 GB/s).  Linux: madvise(MADV_POPULATE_WRITE) per block; where the kernel does not
+ * know it (< 5.14; or on demand: environment MOMLEVEL_AMD_PREFAULT=touch), an atomic `or 0` per page
+ * -- either way safe against the copy threads writing the same pages concurrently.  Blocks are handed out in ascending order, so the front of the range is
+ * ready first.  nbytes == 0: nothing.  Touches no device. */
+int mlx_host_prefault(void *addr, size_t nbytes, int threads);
 
 #ifdef __cplusplus
 }

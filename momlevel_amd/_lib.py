@@ -18,9 +18,10 @@ LIB_PATH = os.environ.get("MOMLEVEL_AMD_LIB") or os.path.join(HERE, "libmomlevel
 _ORACLE_DIR = os.path.join(os.path.dirname(HERE), "oracle")
 
 # ---- constants mirrored from include/momlevel_hip.h --------------------------------
-ABI_VERSION = 7
+ABI_VERSION = 8
 EOS_WRIGHT, EOS_LINEAR = 0, 1
 FUNC_DENSITY, FUNC_DRHO_DTEMP, FUNC_DRHO_DSAL, FUNC_ALPHA, FUNC_BETA, FUNC_IBH = 0, 1, 2, 3, 4, 5
+FUNC_DENSITY_REF = 6  # eos.linear.density(..., rho_ref=x): mlx_eos_map_promote only
 P_SCALAR, P_ZPROF, P_FULL3D, P_FULL4D = 0, 1, 2, 3
 DTYPE_F64, DTYPE_F32, DTYPE_F32_UPCAST = 0, 1, 2
 DTYPE_T32_S64, DTYPE_T64_S32 = 3, 4  # theta / salinity of different dtypes (K1 / K2 only)
@@ -104,6 +105,7 @@ SIGNATURES = {
     "mlx_calc_dz": (_int, [_vp, _vp, _i64, _i64, _dbl, _dbl, _int, _int, _vp, _vp]),
     "mlx_host_copy": (_int, [_vp, _vp, _sz, _int, _int]),
     "mlx_host_copy_masked": (_int, [_vp, _vp, _vp, _sz, _int, _int]),
+    "mlx_host_prefault": (_int, [_vp, _sz, _int]),
     "mlx_stratification": (_int, [_vp, _vp, _int, _vp, _i64, _i64, _i64, _int, _int, _vp, _int,
                                   _dbl, _dbl, _i64, _i64, _i64, _vp, _vp]),
     "mlx_adjust_negative_n2": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),

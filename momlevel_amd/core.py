@@ -252,12 +252,13 @@ def eos_map_promote(T, S, p, eos="wright", func="density", gravity=9.8):
     combinations mlx_eos_map does not cover.  Each operand is a python float / int (a WEAK scalar:
     it takes the dtype of the arrays it meets) or a float32 / float64 device tensor of n elements or
     of ONE element (used for every cell); ``p`` may be None for the linear EOS.  ``func`` may also
-    be "inverse_barometer" (``gravity`` a python float).  Returns a device tensor of n elements in
+    be "inverse_barometer" (``gravity`` a python float) or, for the linear EOS, "density_ref" (``p``
+    then carries the constant term RHO_T0_S0 - rho_ref of eos/linear.py:55).  Returns a device tensor of n elements in
     numpy's result dtype (float32 when no float64 array takes part) holding numpy's values."""
     import ctypes
 
     require_device()
-    if p is None and (eos.lower() != "linear" or func == "inverse_barometer"):
+    if p is None and (eos.lower() != "linear" or func in ("inverse_barometer", "density_ref")):
         raise TypeError("p must not be None (only the linear EOS ignores the pressure)")
     tensors = [x for x in (T, S, p) if isinstance(x, torch.Tensor)]
     if not tensors:
@@ -285,7 +286,9 @@ def eos_map_promote(T, S, p, eos="wright", func="density", gravity=9.8):
             w = ctypes.c_double(float(x))
             keep.append(w)
             args += [ctypes.addressof(w), _lib.KIND_WEAK, 0]
-    fid = _lib.FUNC_IBH if func == "inverse_barometer" else FUNC_IDS[func]
+    fid = {"inverse_barometer": _lib.FUNC_IBH, "density_ref": _lib.FUNC_DENSITY_REF}.get(func)
+    if fid is None:
+        fid = FUNC_IDS[func]
     out = torch.empty(n, dtype=torch.float64, device=device)
     kind = ctypes.c_int(-1)
     with _on(device):

@@ -701,6 +701,8 @@ __device__ __forceinline__ void add_skipna(double& c, double term) {
   }
 }
 
+// (The fused form tests its OPERANDS, not the product: inf * 0 would slip through -- K1 therefore
+//  turns zero volumes into NaN volumes when it loads them, momlevel_hip.hip.)
 template <typename Ops, bool PREDICATED>
 __device__ __forceinline__ void accumulate(double& c, double rho, double vol) {
   if constexpr (Ops::contracts && MLX_TUNE_FMA_ACC) {

@@ -160,6 +160,12 @@ template <typename TT, typename TS>
 MLX_NP_FN auto linear_density(TT T, TS S) {
   return W(RHO_T0_S0) + ((W(DRHO_DT) * T) + (W(DRHO_DS) * S));
 }
+// eos/linear.py:55-56 with rho_ref given: c = RHO_T0_S0 - rho_ref (formed by the caller, in
+// python: a float, or a numpy scalar when rho_ref is one), then c + ((DRHO_DT * T) + (DRHO_DS * S))
+template <typename TT, typename TS, typename TC>
+MLX_NP_FN auto linear_density_ref(TT T, TS S, TC c) {
+  return c + ((W(DRHO_DT) * T) + (W(DRHO_DS) * S));
+}
 template <typename TT, typename TS>
 MLX_NP_FN auto linear_alpha(TT T, TS S) {
   return W(-1.0) * (FullLike<TT>::of(DRHO_DT) / linear_density(T, S));
@@ -172,7 +178,7 @@ MLX_NP_FN auto linear_beta(TT T, TS S) {
 // ---- dispatch by (eos, func): the values of MLX_EOS_* / MLX_FUNC_* -------------------------------
 constexpr int kEosWright = 0, kEosLinear = 1;
 constexpr int kFnDensity = 0, kFnDrhoDtemp = 1, kFnDrhoDsal = 2, kFnAlpha = 3, kFnBeta = 4,
-              kFnIbh = 5;
+              kFnIbh = 5, kFnDensityRef = 6;
 
 // One cell.  The result is returned widened to double (exact) and *is_f32 says whether numpy's
 // result dtype is float32.  dynamic.py:34-36: ibh = pso * (-1.0 / (rho_conv * gravity)), gravity a
@@ -192,6 +198,7 @@ MLX_NP_FN double eval(int eos, int func, TT T, TS S, TP p, double gravity, bool*
       case kFnDrhoDsal: MLX_NP_RETURN(W(DRHO_DS));
       case kFnAlpha: MLX_NP_RETURN(linear_alpha(T, S));
       case kFnBeta: MLX_NP_RETURN(linear_beta(T, S));
+      case kFnDensityRef: MLX_NP_RETURN(linear_density_ref(T, S, p));  // (p carries the constant)
       default: MLX_NP_RETURN(p * (W(-1.0) / (linear_density(T, S) * W(gravity))));
     }
   }

@@ -242,6 +242,16 @@ __global__ __launch_bounds__(kBlock) void k_steric_global(
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       vol[u][k] = valid ? v.v[k] : canonical_nan();
+      // The fused accumulate (eos_device.hpp accumulate<>: c = fma(rho, vol, c) unless rho or vol
+      // is NaN) never forms the product the reference tests (derived.py:435: the skipna sum of
+      // rho * volcello): rho = +-inf on a cell of ZERO volume is NaN there, and skipped, where the
+      // fma would poison the sum.  A zero-volume cell never changes the reference's sum -- its term
+      // is +-0 or a skipped NaN -- so it is made a NaN-volume cell HERE, once per block and cell
+      // (the volume is time-invariant: nothing in the time loop), and the fused sum is the
+      // reference's for every operand class but rho = +-0 on a cell of INFINITE volume
+      // (tests/test_gpu_kernels.py::test_fused_sum_skips_what_the_reference_skips).
+      if constexpr (Ops::contracts && MLX_TUNE_FMA_ACC)
+        vol[u][k] = (vol[u][k] == 0.0) ? canonical_nan() : vol[u][k];
       any_wet = any_wet || !is_nan(vol[u][k]);
     }
     alive[u] = !SKIP || any_wet;

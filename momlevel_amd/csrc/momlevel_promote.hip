@@ -30,7 +30,8 @@ namespace mlx {
 static_assert(np::kEosWright == MLX_EOS_WRIGHT && np::kEosLinear == MLX_EOS_LINEAR, "eos enum");
 static_assert(np::kFnDensity == MLX_FUNC_DENSITY && np::kFnDrhoDtemp == MLX_FUNC_DRHO_DTEMP &&
                   np::kFnDrhoDsal == MLX_FUNC_DRHO_DSAL && np::kFnAlpha == MLX_FUNC_ALPHA &&
-                  np::kFnBeta == MLX_FUNC_BETA && np::kFnIbh == MLX_FUNC_IBH,
+                  np::kFnBeta == MLX_FUNC_BETA && np::kFnIbh == MLX_FUNC_IBH &&
+                      np::kFnDensityRef == MLX_FUNC_DENSITY_REF,
               "func enum");
 
 constexpr int kPromoteBlock = 256;
@@ -248,13 +249,16 @@ extern "C" int mlx_eos_map_promote(const void* T, int kind_T, int64_t stride_T, 
                                    void* out, int* out_kind, void* stream) {
   using namespace mlx;
   if (eos != MLX_EOS_WRIGHT && eos != MLX_EOS_LINEAR) return detail::fail(MLX_E_ENUM, "unknown eos");
-  if (func < MLX_FUNC_DENSITY || func > MLX_FUNC_IBH) return detail::fail(MLX_E_ENUM, "unknown func");
+  if (func < MLX_FUNC_DENSITY || func > MLX_FUNC_DENSITY_REF)
+    return detail::fail(MLX_E_ENUM, "unknown func");
+  if (func == MLX_FUNC_DENSITY_REF && eos != MLX_EOS_LINEAR)
+    return detail::fail(MLX_E_ENUM, "MLX_FUNC_DENSITY_REF is eos.linear.density's rho_ref form");
   if (n <= 0) return detail::fail(MLX_E_SHAPE, "n must be > 0");
   if (n > ((int64_t)1 << 38)) return detail::fail(MLX_E_SHAPE, "n too large");
   if (!out || !out_kind) return detail::fail(MLX_E_NULL, "out and out_kind must not be NULL");
   if (reinterpret_cast<uintptr_t>(out) % 8) return detail::fail(MLX_E_ALIGN, "out not 8-byte aligned");
   PromoteCall c;
-  const bool p_read = (eos == MLX_EOS_WRIGHT) || func == MLX_FUNC_IBH;
+  const bool p_read = (eos == MLX_EOS_WRIGHT) || func == MLX_FUNC_IBH || func == MLX_FUNC_DENSITY_REF;
   if (int rc = promote_operand(T, kind_T, stride_T, "T", &c.T)) return rc;
   if (int rc = promote_operand(S, kind_S, stride_S, "S", &c.S)) return rc;
   if (p_read) {

@@ -19,11 +19,12 @@ DRHO_DS = 0.8
 
 def density(T, S, p=None, rho_ref=None):
     """In-situ density of the linear EOS; pressure is ignored (eos/linear.py:26-58)."""
-    rho = evaluate("linear", "density", T, S, None)
-    if rho_ref is not None:
-        # reference: rho = (1000 - rho_ref) + (...); only the rho_ref=None form is bit-exact here
-        rho = rho - rho_ref
-    return rho
+    if rho_ref is None:
+        return evaluate("linear", "density", T, S, None)
+    # eos/linear.py:55-56: the constant term is formed first, in python -- a float, or a numpy scalar
+    # when rho_ref is one -- and then meets the arrays: c + ((DRHO_DT * T) + (DRHO_DS * S)); the
+    # kernel takes c where the other functions take the pressure (MLX_FUNC_DENSITY_REF)
+    return evaluate("linear", "density_ref", T, S, RHO_T0_S0 - rho_ref)
 
 
 def drho_dtemp(T=None, S=None, p=None):

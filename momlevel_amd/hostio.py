@@ -326,6 +326,201 @@ def pinned_array(shape, dtype=np.float64):
     return np.empty(shape, dtype=dtype)
 
 
+# Results of at least this size (the 4-D delta_rho fields and the (time, yh, xh) heights of the local
+# variants at real sizes) are handed out in 2 MiB-aligned anonymous mappings advised MADV_HUGEPAGE and
+# faulted in AHEAD of the copy-out (Prefaulter).  0 disables (np.empty, first touch by the copy
+# threads: 47-57 GB/s, below the 57 GB/s link -- profiles/r04_result_alloc_probe.log).
+HUGE_RESULT_BYTES = int(os.environ.get("MOMLEVEL_AMD_HUGE_RESULT_MIB", "64")) << 20
+_HUGE_PAGE = 2 << 20
+# (0: result pages are NOT faulted in ahead of the copy-out -- the default since it measured
+#  slower end to end with 1, 2, 4 and 8 threads: profiles/r06_result_prefault_negative.log)
+PREFAULT_THREADS = int(os.environ.get("MOMLEVEL_AMD_PREFAULT_THREADS", "0"))
+
+
+def _pool_cap_bytes():
+    """Bytes of freed result mappings kept for re-use: MOMLEVEL_AMD_RESULT_POOL_GIB, default a quarter
+    of the memory this process may use (cgroup limit or MemTotal), 0 disables."""
+    env = os.environ.get("MOMLEVEL_AMD_RESULT_POOL_GIB")
+    if env is not None:
+        return int(float(env) * (1 << 30))
+    total = None
+    try:
+        with open("/sys/fs/cgroup/memory.max") as f:
+            v = f.read().strip()
+        if v != "max":
+            total = int(v)
+    except (OSError, ValueError):
+        pass
+    if total is None:
+        try:
+            with open("/proc/meminfo") as f:
+                total = int(f.readline().split()[1]) << 10
+        except (OSError, ValueError, IndexError):
+            total = 0
+    return total // 4
+
+
+class _ResultPool:
+    """Result mappings whose arrays have died, kept MAPPED for the next call's results instead of
+    going back to the OS at once.  Why: a fresh anonymous page costs the kernel a zeroing pass before
+    the copy-out writes it -- two passes over the bytes where the host cores' path to DRAM is the
+    bottleneck (47-57 GB/s into fresh pages, 105-190 GB/s into pages that exist; faulting the pages
+    in AHEAD of the copy from other threads measured slower still, profiles/r06_result_prefault_
+    negative.log) -- while a caller that walks a long record calls steric() again and again, freeing
+    each result after writing it out.  The kept pages are advised MADV_FREE: they count as this
+    process's until the kernel wants memory, which then takes them without swapping (a later re-use
+    finds zero pages there, as in a fresh mapping); so the pool cannot cause an out-of-memory kill.
+    Bounded by bytes (_pool_cap_bytes) and count; hostio.trim_result_pool() empties it."""
+
+    MAX_MAPPINGS = 12
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.free = []  # [(capacity in bytes, mmap object, aligned offset)], oldest first
+        self.reused = 0
+        self.mapped = 0
+
+    def take(self, nbytes):
+        with self.lock:
+            best = None
+            for i, (cap, _m, _off) in enumerate(self.free):
+                if nbytes <= cap <= nbytes + max(nbytes // 2, _HUGE_PAGE):
+                    if best is None or cap < self.free[best][0]:
+                        best = i
+            if best is None:
+                return None
+            self.reused += 1
+            return self.free.pop(best)
+
+    def give(self, cap, m, off):
+        import mmap
+
+        limit = _pool_cap_bytes()
+        if cap > limit:
+            return  # (not kept: the mapping goes when `m` does)
+        try:
+            m.madvise(getattr(mmap, "MADV_FREE", 8), off, cap)
+        except (OSError, ValueError):
+            pass
+        with self.lock:
+            self.free.append((cap, m, off))
+            while (sum(c for c, _m, _o in self.free) > limit or len(self.free) > self.MAX_MAPPINGS):
+                self.free.pop(0)  # (unmapped when its mmap object is collected: now)
+
+    def trim(self):
+        with self.lock:
+            self.free.clear()
+
+
+_result_pool = _ResultPool()
+
+
+def trim_result_pool():
+    """Give the kept result mappings (_ResultPool) back to the OS now."""
+    _result_pool.trim()
+
+
+def result_array(shape, dtype=np.float64):
+    """The host array a bulk result is copied into.  Large results: an anonymous mapping of our
+    own, 2 MiB-aligned and advised MADV_HUGEPAGE -- an ordinary writable numpy array to the caller,
+    whose ``base`` chain ends in the mapping; when the last view of the array dies the mapping goes
+    into a bounded pool for the next call's results (_ResultPool; pages the kernel may take back
+    whenever it wants memory) or, beyond the pool's bounds, back to the OS at once.  Contents are
+    UNDEFINED, as np.empty's.  Small ones, and everything when the caller opted into page-locked
+    results: pinned_array()."""
+    import weakref
+
+    dtype = np.dtype(dtype)
+    count = int(np.prod(shape, dtype=np.int64))
+    nbytes = count * dtype.itemsize
+    if HUGE_RESULT_BYTES <= 0 or nbytes < HUGE_RESULT_BYTES or 0 < nbytes <= PINNED_RESULT_LIMIT:
+        return pinned_array(shape, dtype)
+    import mmap
+
+    kept = _result_pool.take(nbytes)
+    if kept is not None:
+        cap, m, off = kept
+    else:
+        cap = (nbytes + _HUGE_PAGE - 1) // _HUGE_PAGE * _HUGE_PAGE
+        try:
+            m = mmap.mmap(-1, cap + _HUGE_PAGE, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
+        except (OSError, ValueError, OverflowError):
+            return pinned_array(shape, dtype)
+        probe = np.frombuffer(m, dtype=np.uint8, count=1)
+        off = (-probe.ctypes.data) % _HUGE_PAGE
+        del probe
+        try:  # advice only: without it (a kernel without THP) the pages are small ones
+            m.madvise(mmap.MADV_HUGEPAGE, off, cap)
+        except (AttributeError, OSError, ValueError):
+            pass
+        _result_pool.mapped += 1
+    root = np.frombuffer(m, dtype=dtype, count=count, offset=off)
+    # (every view of `root` keeps `root` alive: this fires when the LAST of them is gone)
+    weakref.finalize(root, _result_pool.give, cap, m, off).atexit = False
+    _log_range("result array (anonymous huge-page mapping, ours; written by host memcpy only)",
+               root.ctypes.data, nbytes)
+    return root.reshape(shape)
+
+
+def owns_mapping(a):
+    """True for an array handed out by result_array() as a mapping of its own"""
+    import mmap
+
+    while isinstance(a, np.ndarray):
+        a = a.base
+    return isinstance(a, memoryview) and isinstance(a.obj, mmap.mmap)
+
+
+class Prefaulter:
+    """Fault the pages of fresh result arrays in, in the order the downloads will write them -- for
+    every time chunk, every array's rows of that chunk -- on a thread of its own that calls
+    mlx_host_prefault (PREFAULT_THREADS native threads, the GIL released): it starts while the first
+    chunk is still being uploaded and computed and stays ahead of the copy-out, which then finds warm
+    pages.  Contents are never changed (it may fall behind the copy: harmless).  Only arrays that
+    result_array() mapped are touched; numpy's own allocations are left to numpy.
+
+        with hostio.Prefaulter(arrays, bounds): ...chunk loop...
+    """
+
+    def __init__(self, arrays, bounds):
+        self._arrays = [a for a in arrays if a is not None and owns_mapping(a)]
+        self._bounds = list(bounds)
+        self._stop = False
+        self._thread = None
+        if self._arrays and PREFAULT_THREADS > 0:
+            self._thread = threading.Thread(target=self._run, name="mlx-prefault", daemon=True)
+            self._thread.start()
+
+    def _run(self):
+        from . import _lib
+
+        try:
+            fn = _lib.load().mlx_host_prefault
+        except Exception:  # (no library: nothing to do ahead of time)
+            return
+        for t0, t1 in self._bounds:
+            for a in self._arrays:
+                if self._stop:
+                    return
+                part = a[t0:t1]
+                if part.size and fn(part.ctypes.data, part.nbytes, PREFAULT_THREADS) != 0:
+                    return
+
+    def close(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+        self._arrays = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+
 def _drain_one(ring, pending):
     """Oldest enqueued piece: wait for its DMA, copy it out of the staging buffer."""
     dst, n, i = pending.pop(0)
@@ -555,8 +750,11 @@ def to_host(t):
     t = t.detach()
     if t.dtype not in (torch.float32, torch.float64) or t.numel() * t.element_size() < SMALL_BYTES:
         return t.cpu().numpy()
-    out = pinned_array(tuple(t.shape), np.float32 if t.dtype == torch.float32 else np.float64)
+    out = result_array(tuple(t.shape), np.float32 if t.dtype == torch.float32 else np.float64)
     stream = torch.cuda.current_stream(t.device)
-    download_into(out, t, stream)
-    stream.synchronize()
+    flat = out.reshape(-1)
+    step = max(1, (4 * PIECE_BYTES) // out.itemsize)
+    with Prefaulter([flat], [(i, min(i + step, flat.size)) for i in range(0, flat.size, step)]):
+        download_into(out, t, stream)
+        stream.synchronize()
     return out

@@ -27,6 +27,21 @@ def pressure_field(dset, zcoord, patm):
     return (dset[zcoord] * 1.0e4) + patm
 
 
+def refuse_float32_pressure(pres, thetao, so, zcoord):
+    """steric.py:96 / reference.py:53-54 form ``pres = dset[zcoord] * 1e4 + patm`` in the
+    COORDINATE's dtype.  A float32 ``z_l`` gives a float32 pressure; against float64 (or mixed)
+    theta / S numpy widens it exactly where it meets them -- which is what the kernels do with it --
+    but with float32 theta AND S numpy evaluates the WHOLE equation of state in float32, result
+    included, and no steric kernel restates that (``derived.calc_rho`` does: mlx_eos_map_promote).
+    Rather than answer in other bits (the silent float64 upcast of rounds 3-5), such a call is
+    refused, like float16 fields (labeled.check_field_dtype)."""
+    if all(str(x.dtype) == "float32" for x in (pres, thetao, so)):
+        raise TypeError(
+            f"float32 thetao / so with a float32 pressure (a float32 {zcoord!r} coordinate): numpy "
+            "would evaluate the whole equation of state in float32, which the steric kernels do "
+            f"not restate; convert the coordinate to float64 (dset[{zcoord!r}].astype('float64'))")
+
+
 def pressure_operand(pres, tcoord, cdims):
     """Raw pressure for the kernels in canonical dim order: a scalar, the z profile, a
     (z,y,x)-broadcastable array (``patm`` given as a (yh,xh) DataArray, steric.py:58-60), or --
@@ -46,9 +61,13 @@ def _f32_mode():
     return os.environ.get("MOMLEVEL_AMD_F32_MODE", "faithful")
 
 
-def _setup(dset, patm, eos, coord_names, time_index, defer_masso):
+def _setup(dset, patm, eos, coord_names, time_index, defer_masso, twins=None):
     """setup_reference_state, optionally leaving masso / rhoga to the caller (steric() with
-    domain="global" reads them off its own K1 launch: engine.reference_state)."""
+    domain="global" reads them off its own K1 launch: engine.reference_state).
+    ``twins``: a dict that receives the DEVICE tensors of the state's (z,y,x) slabs in canonical
+    dim order -- thetao, so, volcello (float64) and rho -- for a caller that goes straight on to
+    the kernels (steric()): the host arrays of the returned Dataset are for the user, and moving
+    them to the device a second time is 1.1 GB of the host link on the reference's recorded call."""
     coords = default_coords(coord_names)
     tcoord = coords[0]
     zcoord = coords[1]
@@ -56,6 +75,7 @@ def _setup(dset, patm, eos, coord_names, time_index, defer_masso):
     eos_func_from_str(eos)  # unknown EOS -> ValueError, as calc_rho raises it (util.py:247)
 
     pres = pressure_field(dset, zcoord, patm)
+    refuse_float32_pressure(pres, dset["thetao"], dset["so"], zcoord)
 
     reference = Dataset()
     for name in ("thetao", "so", "volcello"):
@@ -93,10 +113,20 @@ def _setup(dset, patm, eos, coord_names, time_index, defer_masso):
         masso_dims, masso_val = tdim, masso_h
         rhoga_val = masso_h / np.float64(volo_h)
     else:
+        T0d, S0d, V0d = T0.data, S0.data, V0.data
+        if twins is not None:  # (the uploads engine.reference_state would make, kept)
+            import torch
+
+            dev = engine.device_of(T0d, S0d, V0d)
+            T0d = engine.to_device(T0d, dev, engine._stream_dtype(T0d))
+            S0d = engine.to_device(S0d, dev, engine._stream_dtype(S0d))
+            V0d = engine.to_device(V0d, dev, torch.float64)
         rho0, volo, masso0 = engine.reference_state(
-            T0.data, S0.data, V0.data, p, eos=eos.lower(), f32_mode=_f32_mode(),
+            T0d, S0d, V0d, p, eos=eos.lower(), f32_mode=_f32_mode(),
             with_masso=not defer_masso,
         )
+        if twins is not None:
+            twins.update(thetao=T0d, so=S0d, volcello=V0d, rho=rho0)
         rho = DataArray(rho0 if on_device else hostio.to_host(rho0), cdims, T0.coords, rho_attrs)
         reference["rho"] = rho.transpose(*reference["thetao"].dims)
         # derived.py:789: volcello.sum() has volcello's dtype -- float32 for the float32 volumes MOM6

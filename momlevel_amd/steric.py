@@ -27,6 +27,7 @@ from .reference import (
     canonical_dims,
     pressure_field,
     pressure_operand,
+    refuse_float32_pressure,
     set_reference_masso,
 )
 from .util import (
@@ -125,10 +126,11 @@ def _global_results(ops, reference, variants, dtype, tcoord, coords_for, deferre
     return out
 
 
-def _local_results(ops, dset, reference, variants, dtype, rhozero, names, cdims3, coords_for,
+def _local_results(ops, dset, rho0, variants, dtype, rhozero, names, cdims3, coords_for,
                    plan=None):
-    """steric.py:150-166 -- delta_rho and the column integral from K2.  ``plan`` (an
-    util.AnnualPlan): the annual means are taken on the device, fused behind K2."""
+    """steric.py:150-166 -- delta_rho and the column integral from K2.  ``rho0``: the reference
+    state's density in canonical (z,y,x) order.  ``plan`` (an util.AnnualPlan): the annual means
+    are taken on the device, fused behind K2."""
     T, S, T0, S0, vol0, p, eos = ops
     tcoord, zcoord, zbounds = names
     hdims = cdims3[1:]
@@ -139,7 +141,7 @@ def _local_results(ops, dset, reference, variants, dtype, rhozero, names, cdims3
     # out of the result -- the kernel then skips its 8 B/cell store and nothing 4-D comes back
     want_delta_rho = os.environ.get("MOMLEVEL_AMD_DELTA_RHO", "1") != "0"
     fields = engine.local_steric_variants(
-        T, S, T0, S0, reference["rho"].transpose(*cdims3).data, vol0, p, rhozero, variants,
+        T, S, T0, S0, rho0, vol0, p, rhozero, variants,
         z_i=dset[zbounds].data, deptho=deptho.data, eos=eos, f32_mode=_f32_mode(),
         want_delta_rho=want_delta_rho, annual_weights=None if plan is None else plan.weights,
     )
@@ -236,14 +238,17 @@ def _steric_many(dset, variants, reference, coord_names, varname_map, rhozero, p
     # (with the global area every rank reaches the same verdict on the range check)
     validate_dataset(dset, strict=strict, additional_vars=extra_vars, area_total=area_total)
     pres = pressure_field(dset, zcoord, patm)  # 1 m of depth ~ 1 dbar = 1e4 Pa, plus patm
+    _, err = _attempt(refuse_float32_pressure, pres, dset["thetao"], dset["so"], zcoord)
+    all_ranks_ok(exchange, err)  # (every rank sees the same dtypes: they all raise, or none)
 
     # (not with a time-dependent patm: that reference state is time dependent itself and is
     #  rejected by the validation below, as in momlevel)
     deferred = reference is None and domain == "global" and tcoord not in pres.dims
+    twins = {}  # device tensors of a self-made reference state's slabs (reference._setup)
     if reference is None:
         # domain="global": masso0 is masso(t=0) of the K1 launch below (same kernel, same bits)
         reference, err = _attempt(_setup, dset, patm, equation_of_state, coord_names, 0,
-                                  defer_masso=deferred)
+                                  defer_masso=deferred, twins=twins)
         all_ranks_ok(exchange, err)
         if exchange is not None and not deferred:
             globalise_reference(reference, exchange)
@@ -267,12 +272,17 @@ def _steric_many(dset, variants, reference, coord_names, varname_map, rhozero, p
     def coords_for(dims):
         return {d: dset[d] for d in dims if d in dset.variables}
 
+    def slab(name):
+        """a (z,y,x) field of the reference state in canonical order: the device tensor the state
+        was computed from when it was made in this call, else the Dataset's array"""
+        return twins[name] if name in twins else reference[name].transpose(*cdims3).data
+
     ops = (
         dset["thetao"].transpose(*cdims4).data,
         dset["so"].transpose(*cdims4).data,
-        reference["thetao"].transpose(*cdims3).data,
-        reference["so"].transpose(*cdims3).data,
-        reference["volcello"].transpose(*cdims3).data,
+        slab("thetao"),
+        slab("so"),
+        slab("volcello"),
         pressure_operand(pres, tcoord, cdims3),
         equation_of_state.lower(),
     )
@@ -288,7 +298,7 @@ def _steric_many(dset, variants, reference, coord_names, varname_map, rhozero, p
     else:
         if heat_cp is not None:
             raise ValueError("heat_content is a global integral: use domain='global'")
-        results = _local_results(ops, dset, reference, variants, dtype, rhozero, names, cdims3,
+        results = _local_results(ops, dset, slab("rho"), variants, dtype, rhozero, names, cdims3,
                                  coords_for, plan)
 
     for variant, result in results.items():

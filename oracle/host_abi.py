@@ -121,7 +121,9 @@ def eos_map_promote(T, S, p, eos="wright", func="density", gravity=9.8):
     args = [(1 if (v.size == n and n > 1) else 0) if isinstance(v, np.ndarray) else v for v in args]
     out = np.empty(n)
     kind = ctypes.c_int(-1)
-    fid = abi.FUNC_IBH if func == "inverse_barometer" else abi.FUNC_IDS[func]
+    fid = {"inverse_barometer": abi.FUNC_IBH, "density_ref": abi.FUNC_DENSITY_REF}.get(func)
+    if fid is None:
+        fid = abi.FUNC_IDS[func]
     _check(load().mlx_eos_map_promote(*args, abi.EOS_IDS[eos], fid, float(gravity), n, _p(out),
                                       ctypes.byref(kind), None), "mlx_eos_map_promote")
     return out.view(np.float32)[:n].copy() if kind.value == abi.KIND_F32 else out

@@ -95,7 +95,9 @@ extern "C" int mlx_eos_map_promote(const void *T, int kind_T, int64_t stride_T, 
                                    void *out, int *out_kind, void *stream) {
   (void)stream;
   if (eos != MLX_EOS_WRIGHT && eos != MLX_EOS_LINEAR) return mlxh_fail(MLX_E_ENUM, "unknown eos");
-  if (func < MLX_FUNC_DENSITY || func > MLX_FUNC_IBH) return mlxh_fail(MLX_E_ENUM, "unknown func");
+  if (func < MLX_FUNC_DENSITY || func > MLX_FUNC_DENSITY_REF) return mlxh_fail(MLX_E_ENUM, "unknown func");
+  if (func == MLX_FUNC_DENSITY_REF && eos != MLX_EOS_LINEAR)
+    return mlxh_fail(MLX_E_ENUM, "MLX_FUNC_DENSITY_REF is eos.linear.density's rho_ref form");
   if (n <= 0) return mlxh_fail(MLX_E_SHAPE, "n must be > 0");
   if (n > ((int64_t)1 << 38)) return mlxh_fail(MLX_E_SHAPE, "n too large");
   if (!out || !out_kind) return mlxh_fail(MLX_E_NULL, "out and out_kind must not be NULL");
@@ -103,7 +105,7 @@ extern "C" int mlx_eos_map_promote(const void *T, int kind_T, int64_t stride_T, 
   Call c;
   if (int rc = operand(T, kind_T, stride_T, &c.T)) return rc;
   if (int rc = operand(S, kind_S, stride_S, &c.S)) return rc;
-  if (eos == MLX_EOS_WRIGHT || func == MLX_FUNC_IBH) {
+  if (eos == MLX_EOS_WRIGHT || func == MLX_FUNC_IBH || func == MLX_FUNC_DENSITY_REF) {
     if (int rc = operand(p, kind_p, stride_p, &c.p)) return rc;
   } else {  // eos/linear.py never reads the pressure
     static const double zero = 0.0;

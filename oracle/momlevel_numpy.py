@@ -93,10 +93,10 @@ LIN_DRHO_DT = -0.2
 LIN_DRHO_DS = 0.8
 
 
-def linear_density(T, S, p=None):
-    """Linear EOS density, src/momlevel/eos/linear.py:26-58 (rho_ref=None)."""
-    rho = LIN_RHO_T0_S0
-    return rho + ((LIN_DRHO_DT * T) + (LIN_DRHO_DS * S))
+def linear_density(T, S, p=None, rho_ref=None):
+    """Linear EOS density, src/momlevel/eos/linear.py:26-58."""
+    rho = LIN_RHO_T0_S0 if rho_ref is None else (LIN_RHO_T0_S0 - rho_ref)  # :55
+    return rho + ((LIN_DRHO_DT * T) + (LIN_DRHO_DS * S))  # :56
 
 
 def linear_drho_dtemp(T=None, S=None, p=None):
@@ -157,8 +157,10 @@ def nansum(x, axis=None):
 
 
 def pressure_from_depth(z_l, patm=101325.0):
-    """src/momlevel/steric.py:93-96 / reference.py:53-54: 1e4 Pa per metre + patm."""
-    return (np.asarray(z_l, dtype=np.float64) * 1.0e4) + patm
+    """src/momlevel/steric.py:93-96 / reference.py:53-54: 1e4 Pa per metre + patm -- IN THE
+    COORDINATE'S DTYPE, as ``dset[zcoord] * 1e4 + patm`` is: a float32 z_l gives a float32 pressure
+    (and float32 theta / S then a float32 density throughout)."""
+    return (np.asarray(z_l) * 1.0e4) + patm
 
 
 def calc_rho(thetao, so, pres, eos="Wright"):

@@ -168,6 +168,28 @@ def main():
     assert out["mix_ffw_density"].dtype == np.float32 and out["mix_fff_alpha"].dtype == np.float32
     assert out["mix_fdd_density"].dtype == np.float64 and out["mix_wfd_density"].dtype == np.float64
 
+    # (9) round 6: eos.linear.density with rho_ref GIVEN (eos/linear.py:55-56): the constant term is
+    # (1000 - rho_ref), formed first -- a python float, or a numpy scalar when rho_ref is one -- and
+    # then meets the arrays; float64 and float32 fields
+    out["linref_values"] = np.array([1035.0, 1027.3, 1035.5, 1035.25])
+    refs = {"py": 1035.0, "py2": 1027.3, "np64": np.float64(1035.5), "np32": np.float32(1035.25)}
+    for tag, (T, S) in {"tw": (out["tw_T"], out["tw_S"]), "f32": (T32, S32)}.items():
+        for rk, rv in refs.items():
+            out[f"linref_{tag}_{rk}"] = np.asarray(lin.density(T, S, None, rv))
+    assert out["linref_f32_py"].dtype == np.float32 and out["linref_f32_np32"].dtype == np.float32
+    assert out["linref_f32_np64"].dtype == np.float64 and out["linref_tw_np32"].dtype == np.float64
+
+    # (10) round 6: a float32 DEPTH coordinate.  steric.py:96 / reference.py:53-54 form
+    # pres = dset[zcoord] * 1e4 + patm in the coordinate's dtype: with float32 z_l the pressure is
+    # float32, and with float32 theta / S numpy then evaluates the WHOLE equation of state in float32
+    z32 = z_l.astype(np.float32)
+    out["f32z_z"] = z32
+    out["f32z_pres"] = z32 * 1.0e4 + 101325.0
+    assert out["f32z_pres"].dtype == np.float32
+    out["f32z_density"] = ref.density(T32, S32, out["f32z_pres"][:, None, None])
+    out["f32z_density_f64fields"] = ref.density(out["blk_T"], out["blk_S"], out["f32z_pres"][:, None, None])
+    assert out["f32z_density"].dtype == np.float32 and out["f32z_density_f64fields"].dtype == np.float64
+
     # scalars of tests/test_wright.py:11-12,30-31,50-51,70-71,120-121
     out["scalar_args"] = np.array([18.0, 35.0, 200000.0])
     out["scalar_out"] = np.array(

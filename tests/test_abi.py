@@ -7,6 +7,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 from momlevel_amd import _lib
 
@@ -218,3 +219,143 @@ def test_plain_and_masked_copies_share_the_team_concurrently():
     [j.start() for j in jobs]
     [j.join() for j in jobs]
     assert errors == []
+
+
+def _resident_fraction(addr, nbytes):
+    """fraction of the pages of [addr, addr+nbytes) that are resident (mincore)"""
+    page = os.sysconf("SC_PAGESIZE")
+    lo = addr // page * page
+    n = -(-(addr + nbytes - lo) // page)
+    vec = (ctypes.c_ubyte * n)()
+    libc = ctypes.CDLL(None, use_errno=True)
+    libc.mincore.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    assert libc.mincore(lo, n * page, vec) == 0, ctypes.get_errno()
+    return sum(b & 1 for b in vec) / n
+
+
+@pytest.mark.parametrize("how", ["populate", "touch"])
+def test_host_prefault_needs_no_gpu(how, monkeypatch):
+    """mlx_host_prefault (v8): the pages of a fresh mapping become resident, no byte changes -- not
+    even while another thread is writing the same pages -- for any alignment and thread count; by
+    madvise(MADV_POPULATE_WRITE) and by the atomic touch older kernels get."""
+    import mmap
+    import threading
+
+    if how == "touch":
+        monkeypatch.setenv("MOMLEVEL_AMD_PREFAULT", "touch")
+    lib = _lib.load()
+    n = 48 << 20
+    m = mmap.mmap(-1, n, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
+    a = np.frombuffer(m, dtype=np.uint8)
+    assert _resident_fraction(a.ctypes.data, n) < 0.01
+    assert lib.mlx_host_prefault(a.ctypes.data + 4097, (40 << 20) - 4097, 3) == 0
+    assert _resident_fraction(a.ctypes.data + 4097, (40 << 20) - 4097) == 1.0
+    assert _resident_fraction(a.ctypes.data + (41 << 20), 7 << 20) < 0.01  # nothing beyond the range
+    assert not a[: 40 << 20].any()  # fresh anonymous pages read as zero: untouched
+    # contents survive, with a writer racing the prefault over the same pages
+    want = np.random.default_rng(3).integers(1, 255, n, dtype=np.uint8)
+    m2 = mmap.mmap(-1, n, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
+    b = np.frombuffer(m2, dtype=np.uint8)
+    writer = threading.Thread(
+        target=lambda: lib.mlx_host_copy(b.ctypes.data, want.ctypes.data, n, 4, 1))
+    writer.start()
+    for threads in (1, 4, 64):
+        assert lib.mlx_host_prefault(b.ctypes.data, n, threads) == 0
+    writer.join()
+    assert np.array_equal(b, want)
+    assert lib.mlx_host_prefault(b.ctypes.data + 5, 1, 1) == 0 and np.array_equal(b, want)
+    assert lib.mlx_host_prefault(None, 0, 1) == 0
+    assert lib.mlx_host_prefault(None, 8, 1) == -1
+    assert lib.mlx_host_prefault(b.ctypes.data, 8, 0) == -2
+    assert lib.mlx_host_prefault(b.ctypes.data, 8, 65) == -2
+    assert lib.mlx_host_prefault(ctypes.c_void_p(2**64 - 16), 64, 1) == -2
+    del a, b
+
+
+def test_result_arrays_own_their_mapping_and_are_faulted_in_ahead(monkeypatch):
+    """hostio.result_array: large results live in a 2 MiB-aligned anonymous mapping of their own
+     -- a writable numpy array whose memory goes back to the OS when the last view
+    dies -- and hostio.Prefaulter makes its pages resident chunk by chunk without writing them."""
+    import gc
+    import weakref
+
+    from momlevel_amd import hostio
+
+    monkeypatch.setattr(hostio, "HUGE_RESULT_BYTES", 8 << 20)
+    monkeypatch.setenv("MOMLEVEL_AMD_RESULT_POOL_GIB", "0")  # first without the pool of kept mappings
+    monkeypatch.setattr(hostio, "PREFAULT_THREADS", 2)
+    small = hostio.result_array((100, 100), np.float64)
+    assert type(small) is np.ndarray and small.base is None and not hostio.owns_mapping(small)
+    shape = (6, 3, 40, 2048)  # 11.8 MB of float64
+    out = hostio.result_array(shape, np.float64)
+    assert out.shape == shape and out.dtype == np.float64 and out.flags["C_CONTIGUOUS"]
+    assert out.flags["WRITEABLE"] and out.flags["ALIGNED"] and out.ctypes.data % (2 << 20) == 0
+    assert hostio.owns_mapping(out) and hostio.owns_mapping(out[2:4, 1])
+    assert not hostio.owns_mapping(np.frombuffer(bytearray(64), dtype=np.uint8))
+    f32 = hostio.result_array((5, 1 << 20), np.float32)
+    assert f32.dtype == np.float32 and hostio.owns_mapping(f32)
+    # the mapping dies with the last view of the array, not before
+    root = out
+    while isinstance(root, np.ndarray):
+        root = root.base
+    mapping = weakref.ref(root.obj)
+    addr, nbytes = out.ctypes.data, out.nbytes
+    view = out[1:3]
+    del out, root
+    gc.collect()
+    assert mapping() is not None
+    view[...] = 7.0  # still mapped, still writable
+    assert float(view.sum()) == 7.0 * view.size
+    del view
+    gc.collect()
+    assert mapping() is None
+    with open("/proc/self/maps") as f:
+        assert not any(line.startswith(f"{addr:x}-") for line in f), "the result mapping is still there"
+    # the prefaulter: rows [t0, t1) of every mapped array, chunk by chunk; numpy's own arrays skipped
+    out = hostio.result_array(shape, np.float64)
+    eta = np.empty((6, 40, 2048))
+    assert _resident_fraction(out.ctypes.data, out.nbytes) < 0.05
+    with hostio.Prefaulter([eta, out, None], [(0, 2), (2, 4)]) as p:
+        assert [a is out for a in p._arrays] == [True]
+        p._thread.join()
+    assert _resident_fraction(out.ctypes.data, out[:4].nbytes) == 1.0
+    # (nothing beyond the chunks asked for, up to the huge page that straddles their end)
+    beyond = -(-out[4:].ctypes.data // (2 << 20)) * (2 << 20)
+    assert _resident_fraction(beyond, out.ctypes.data + out.nbytes - beyond) < 0.01
+    assert not out[:4].any()
+    del out
+    gc.collect()
+    # the pool of kept mappings: a dead result's mapping serves the next result of that size (warm
+    # pages: no zeroing pass before the copy-out), bounded in bytes, emptied on request
+    monkeypatch.setenv("MOMLEVEL_AMD_RESULT_POOL_GIB", "0.02")  # 21 MB: one 11.8 MB mapping fits
+    pool = hostio._result_pool
+    assert pool.free == []
+    first = hostio.result_array(shape, np.float64)
+    addr = first.ctypes.data
+    first[...] = 3.0
+    keep = first[5]
+    del first
+    gc.collect()
+    assert pool.free == []  # a view is alive: the mapping is still the caller's
+    other = hostio.result_array(shape, np.float64)
+    assert other.ctypes.data != addr
+    del keep
+    gc.collect()
+    assert len(pool.free) == 1
+    reused_before = pool.reused
+    again = hostio.result_array((5,) + shape[1:], np.float64)  # a little smaller: still fits
+    assert again.ctypes.data == addr and pool.reused == reused_before + 1 and pool.free == []
+    assert hostio.owns_mapping(again) and again.flags["WRITEABLE"]
+    tiny = hostio.result_array((2,) + shape[1:], np.float64)  # far smaller: a mapping of its own
+    assert tiny.ctypes.data != addr
+    del again, other
+    gc.collect()
+    assert len(pool.free) == 1  # the byte bound: the older mapping went back to the OS
+    hostio.trim_result_pool()
+    assert pool.free == []
+    del tiny
+    gc.collect()
+    hostio.trim_result_pool()
+    # disabled: numpy's allocation as before
+    monkeypatch.setattr(hostio, "HUGE_RESULT_BYTES", 0)
+    assert hostio.result_array(shape, np.float64).base is None

@@ -920,7 +920,8 @@ def test_lazy_inputs_are_read_one_time_chunk_at_a_time(domain, order, monkeypatc
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("domain", ["local", "global"])
-@pytest.mark.parametrize("container", ["masked", "lazy_masked", "lazy_masked_transposed"])
+@pytest.mark.parametrize("container", ["masked", "masked_deferred", "masked_deferred_transposed",
+                                       "lazy_masked", "lazy_masked_transposed"])
 def test_masked_arrays_mean_nan(container, domain, dtype, monkeypatch):
     """What netCDF4 hands over where a file declares ``_FillValue``: numpy masked arrays holding
     1e20 under the mask -- for a whole in-memory variable ("masked") and for every slice of a lazily
@@ -931,22 +932,38 @@ def test_masked_arrays_mean_nan(container, domain, dtype, monkeypatch):
     from lazy_array import FILL, MaskedLazy, as_masked
     from momlevel_amd import engine
 
+    from momlevel_amd import hostio, labeled
+
     d = _masked_dataset(nt=7, dtype=dtype)
     assert np.isnan(d["thetao"].values).any()
     base, bref = steric(d, domain=domain)
     dm = d.copy()
     dims = d["thetao"].dims
     order = ("time", "yh", "xh", "z_l") if container.endswith("transposed") else dims
+    deferred = container.startswith("masked_deferred")
+    if deferred:
+        # "masked_deferred": the in-memory masked array is big enough (here: the threshold is made
+        # small enough) to be kept as data + mask -- labeled.MaskedSource -- and NaN-filled only
+        # while its time chunks are copied into the staging ring
+        monkeypatch.setattr(labeled, "_NATIVE_FILL_BYTES", 1 << 10)
+        monkeypatch.setattr(hostio, "SMALL_BYTES", 1 << 10)
+        fused = []
+        real = hostio._host_copy_masked
+        monkeypatch.setattr(hostio, "_host_copy_masked",
+                            lambda dst, src, mask, elem: fused.append(dst.numel()) or real(dst, src, mask, elem))
     for k in ("thetao", "so", "volcello"):
         arr = np.ascontiguousarray(d[k].transpose(*order).values)
-        held = as_masked(arr) if container == "masked" else MaskedLazy(arr)
-        if container == "masked":
+        held = as_masked(arr) if container.startswith("masked") else MaskedLazy(arr)
+        if container.startswith("masked"):
             assert held.data[np.isnan(arr)][0] == arr.dtype.type(FILL)
         dm[k] = DataArray(held, order)
+        assert isinstance(dm[k].data, labeled.MaskedSource) == deferred
     for k in ("areacello", "deptho"):
         dm[k] = DataArray(as_masked(d[k].values), d[k].dims)
     monkeypatch.setattr(engine, "chunk_steps", lambda nt, b, dev, budget_bytes=None: 2)
     res, ref = steric(dm, domain=domain)
+    if container == "masked_deferred":
+        assert fused, "the chunks of a MaskedSource must be NaN-filled by the staging copy"
     assert_bit_equal(res["steric"].values, base["steric"].values, "masked vs NaN-filled inputs")
     assert_bit_equal(ref["rho"].transpose(*bref["rho"].dims).values, bref["rho"].values)
     assert float(ref["volo"]) == float(bref["volo"]) and float(ref["masso"]) == float(bref["masso"])
@@ -1250,3 +1267,62 @@ def test_annual_average_of_device_resident_results():
     ann = util.annual_average(monthly)
     assert ann["steric"].is_device
     assert_bit_equal(ann["steric"].values, base["steric"].values)
+
+
+@pytest.mark.parametrize("domain", ["local", "global"])
+def test_a_float32_depth_coordinate_is_followed_or_refused_never_widened(domain, wright_vectors):
+    """steric.py:96 / reference.py:53-54: ``pres = dset[zcoord] * 1e4 + patm`` has the COORDINATE's
+    dtype.  float32 z_l against float64 theta / S: numpy widens the float32 pressure exactly where it
+    meets them -- followed bit for bit.  float32 z_l against float32 theta AND S: numpy evaluates the
+    whole equation of state in float32 -- refused on the steric path (no kernel restates it), and
+    followed by derived.calc_rho (mlx_eos_map_promote), pinned to the REFERENCE module's own output
+    (tests/golden/wright_vectors.npz f32z_*).  Rounds 3-5 widened the coordinate silently
+    (VERDICT r5 item 5)."""
+    from momlevel_amd import derived
+
+    setup_reference_state = reference_mod.setup_reference_state
+
+    d = _masked_dataset(nt=4)
+    z32 = d["z_l"].values.astype(np.float32)
+    assert not np.array_equal(z32.astype(np.float64) * 1.0e4 + 101325.0,
+                              (z32 * 1.0e4 + 101325.0).astype(np.float64))  # float32 rounding shows
+    d32z = d.copy()
+    d32z["z_l"] = DataArray(z32, ("z_l",))
+    # float64 fields: followed -- the oracle on the same float32 coordinate, bit for bit
+    res, ref = steric(d32z, domain=domain)
+    pres32 = o.pressure_from_depth(z32)
+    assert pres32.dtype == np.float32
+    rho0 = o.calc_rho(d["thetao"].values[0], d["so"].values[0], pres32)
+    assert rho0.dtype == np.float64
+    assert_bit_equal(ref["rho"].values, rho0, "rho0 with a float32 depth coordinate")
+    wide, wref = steric(d, domain=domain)
+    assert not np.array_equal(ref["rho"].values, wref["rho"].values, equal_nan=True)
+    if domain == "local":
+        ores, _ = o.steric(d["thetao"].values, d["so"].values, d["volcello"].values,
+                           d["areacello"].values, z32, d["z_i"].values, d["deptho"].values)
+        assert_bit_equal(res["delta_rho"].values, ores["delta_rho"], "delta_rho, float32 z_l")
+        assert_bit_equal(res["steric"].values, ores["steric"], "eta, float32 z_l")
+    # float32 fields too: refused, with a message that says what numpy would do
+    f32 = d32z.copy()
+    for k in ("thetao", "so"):
+        f32[k] = DataArray(d[k].values.astype(np.float32), d[k].dims)
+    with pytest.raises(TypeError, match="float32.*whole equation of state in float32"):
+        steric(f32, domain=domain)
+    with pytest.raises(TypeError, match="convert the coordinate to float64"):
+        setup_reference_state(f32)
+    # ... one float64 field, or a float64 patm DataArray, and numpy promotes: accepted
+    mixed = f32.copy()
+    mixed["so"] = d["so"]
+    steric(mixed, domain=domain)
+    steric(f32, domain=domain, patm=DataArray(np.float64(101325.0), ()))
+    # calc_rho FOLLOWS: float32 throughout, the reference module's own bits
+    v = wright_vectors
+    T32, S32 = v["f32_T"], v["f32_S"]
+    dims = ("time", "z_l", "yh", "xh")
+    coords = {"z_l": DataArray(v["f32z_z"], ("z_l",))}
+    pres = DataArray(v["f32z_pres"], ("z_l",), coords)
+    rho = derived.calc_rho(DataArray(T32, dims, coords), DataArray(S32, dims, coords), pres)
+    assert rho.values.dtype == np.float32
+    assert_bit_equal(rho.values, v["f32z_density"], "calc_rho, float32 fields and pressure")
+    rho = derived.calc_rho(DataArray(v["blk_T"], dims, coords), DataArray(v["blk_S"], dims, coords), pres)
+    assert_bit_equal(rho.values, v["f32z_density_f64fields"], "calc_rho, float64 fields, float32 pressure")

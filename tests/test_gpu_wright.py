@@ -258,6 +258,27 @@ def test_linear_eos_bit_exact(wright_vectors, tag, func):
     assert_bit_equal(got, v[f"lin_{tag}_{func}"].astype(np.float64), f"linear {tag}/{func}")
 
 
+@pytest.mark.parametrize("tag", ["tw", "f32"])
+def test_linear_density_with_a_reference_density_bit_exact(wright_vectors, tag):
+    """eos/linear.py:55-56 with rho_ref given: (1000 - rho_ref) + ((-0.2*T) + (0.8*S)), the constant
+    formed first; python-float and numpy-scalar reference densities, float64 and float32 fields;
+    value AND result dtype against the reference module's own outputs (rounds
+    3-5 returned density(T, S) - rho_ref, other bits)."""
+    v = wright_vectors
+    T, S = (v["tw_T"], v["tw_S"]) if tag == "tw" else (v["f32_T"], v["f32_S"])
+    py, py2, n64, n32 = (float(x) for x in v["linref_values"])
+    for rk, rv in {"py": py, "py2": py2, "np64": np.float64(n64), "np32": np.float32(n32)}.items():
+        want = v[f"linref_{tag}_{rk}"]
+        got = linear.density(T, S, None, rv)
+        assert got.dtype == want.dtype, (tag, rk, got.dtype)
+        assert_bit_equal(got, want, f"linear density with rho_ref ({rk}), {tag}")
+        dev = linear.density(torch.from_numpy(T).cuda(), torch.from_numpy(S).cuda(), None, rv)
+        assert dev.is_cuda
+        assert_bit_equal(dev.cpu().numpy(), want, f"device operands, rho_ref ({rk}), {tag}")
+    assert_bit_equal(linear.density(T, S, 2.0e5, None), v[f"lin_{tag}_density"].astype(np.float64)
+                     if tag == "tw" else linear.density(T, S))  # rho_ref=None: unchanged
+
+
 def test_calc_alpha_beta_with_the_linear_eos():
     from momlevel_amd import derived
     from momlevel_amd.labeled import DataArray

@@ -46,6 +46,27 @@ def test_eos_bit_identical_to_reference_vectors(wright_vectors, tag, func):
     assert_bit_equal(got, v[f"{tag}_{func}"], f"host {tag}/{func}")
 
 
+def test_linear_density_with_a_reference_density_through_the_host_build(wright_vectors):
+    """MLX_FUNC_DENSITY_REF (ABI v8): eos.linear.density's rho_ref form -- the constant term rides in
+    the p operand with its kind -- against the reference module's outputs, dtype included; refused
+    for the Wright EOS (which has no such argument)."""
+    v = wright_vectors
+    py, py2, n64, n32 = (float(x) for x in v["linref_values"])
+    for tag, (T, S) in {"tw": (v["tw_T"], v["tw_S"]), "f32": (v["f32_T"], v["f32_S"])}.items():
+        for rk, rv in {"py": py, "py2": py2, "np64": np.float64(n64), "np32": np.float32(n32)}.items():
+            base = 1000.0 - rv  # eos/linear.py:55, as python / numpy form it
+            if isinstance(base, np.generic):
+                base = np.asarray(base).reshape(1)
+            got = h.eos_map_promote(T.reshape(-1), S.reshape(-1), base, eos="linear", func="density_ref")
+            want = v[f"linref_{tag}_{rk}"]
+            assert got.dtype == want.dtype, (tag, rk)
+            assert_bit_equal(got.reshape(want.shape), want, f"host density_ref {tag}/{rk}")
+    with pytest.raises(RuntimeError, match="rho_ref"):
+        h.eos_map_promote(v["tw_T"].reshape(-1), v["tw_S"].reshape(-1), 1.0, eos="wright", func="density_ref")
+    with pytest.raises(RuntimeError):  # the constant is required
+        h.eos_map_promote(v["tw_T"].reshape(-1), v["tw_S"].reshape(-1), None, eos="linear", func="density_ref")
+
+
 @pytest.mark.parametrize("func", ["density", "drho_dtemp", "drho_dsal", "alpha", "beta"])
 def test_float32_mixed_precision_and_held_fields(wright_vectors, func):
     v = wright_vectors
