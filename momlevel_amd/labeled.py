@@ -452,7 +452,10 @@ class DataArray:
             coords = dict(other.coords)
             coords.update(self.coords)
         else:
-            a, b, dims, coords = self.values, _to_numpy(other), self.dims, self.coords
+            # (a python number stays one: numpy lets it take the ARRAY's dtype -- float32 z_l * 1e4
+            #  is float32, steric.py:96 -- whereas np.asarray(1e4) is a float64 array and promotes)
+            weak = isinstance(other, (bool, int, float)) and not isinstance(other, np.generic)
+            a, b, dims, coords = self.values, other if weak else _to_numpy(other), self.dims, self.coords
         res = op(b, a) if reflexive else op(a, b)
         return DataArray(res, dims, {k: v for k, v in coords.items() if set(v.dims) <= set(dims)})
 

@@ -238,8 +238,8 @@ def _steric_many(dset, variants, reference, coord_names, varname_map, rhozero, p
     # (with the global area every rank reaches the same verdict on the range check)
     validate_dataset(dset, strict=strict, additional_vars=extra_vars, area_total=area_total)
     pres = pressure_field(dset, zcoord, patm)  # 1 m of depth ~ 1 dbar = 1e4 Pa, plus patm
-    _, err = _attempt(refuse_float32_pressure, pres, dset["thetao"], dset["so"], zcoord)
-    all_ranks_ok(exchange, err)  # (every rank sees the same dtypes: they all raise, or none)
+    # (a property of the dataset's dtypes, the same on every rank of a tiled run: all raise, or none)
+    refuse_float32_pressure(pres, dset["thetao"], dset["so"], zcoord)
 
     # (not with a time-dependent patm: that reference state is time dependent itself and is
     #  rejected by the validation below, as in momlevel)

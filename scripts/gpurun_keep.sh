@@ -25,7 +25,11 @@ GPURUN=${GPURUN:-/usr/local/graft/bin/gpurun}
   echo "# gpurun exit code: $?"
 } | tee gpurun_out/${TAG}_call.log | tail -40
 rc=$(sed -n 's/^# gpurun exit code: //p' gpurun_out/${TAG}_call.log | tail -1)
-if [ "${rc:-1}" != "0" ]; then
+# gpurun's own verdict line: "status=ok" / "status=fail" = the command ran to its end (a failing test
+# is an ordinary failure, its log is under gpurun_out/); anything else -- a time limit, the process
+# guard, the memory cap, a lost box -- ended it by force
+status=$(sed -n 's/^\[gpurun\] status=\([a-z_]*\).*/\1/p' gpurun_out/${TAG}_call.log | tail -1)
+if [ "${rc:-1}" != "0" ] && [ "$status" != "fail" ]; then
   {
     echo "# call '${TAG}' did not end cleanly (gpurun exit code ${rc:-?}); its record, unedited:"
     cat gpurun_out/${TAG}_call.log

@@ -867,11 +867,20 @@ def test_fused_sum_skips_what_the_reference_skips(arith, skip_dry):
     weak 1e).  K1 now turns zero volumes into NaN volumes as it loads them -- a zero-volume cell
     never changes the reference's sum -- so both arithmetics return what the reference's expression
     returns on the kernel's own densities: rho = +-inf with volume 0 (skipped), NaN (skipped) and 2
-    (the sum is +-inf, as numpy's).  Left outside the contract, and said so in DESIGN 3.1: rho = +-0
-    on a cell of INFINITE volume under the fused policy (the exact policy follows there too)."""
+    (the sum is +-inf, as numpy's).  Infinite densities exist in EXACT arithmetic only (see below):
+    there the cells are planted; under the fused policy the zero / NaN volume equivalence is checked
+    on ordinary cells.  Left outside the contract, and said so in DESIGN 3.1: rho = +-0 on a cell of
+    INFINITE volume under the fused policy (the exact policy follows there too)."""
     T, S, p, rho = _cancelling_cells(arith)
     hits = np.argwhere(np.isinf(rho[0, 0]))
-    assert len(hits) >= 3, f"no exact cancellation found in {arith} arithmetic"
+    if arith == "exact":
+        assert len(hits) >= 3, "no exact cancellation found"
+    else:
+        # the fused denominator fma(al0, p + p0, lam) is rounded ONCE: it vanishes only where the
+        # exact value does, and no candidate within 512 ulps of the root of eight (theta, S) pairs
+        # does -- an infinite density is not constructible there; the volume classes are checked on
+        # ordinary cells (and on whatever non-finite densities the scan did produce)
+        assert len(hits) == 0
     ny, nx = rho.shape[2:]
     Td, Sd, pd = (torch.from_numpy(a).cuda() for a in (T, S, p))
 
@@ -888,24 +897,34 @@ def test_fused_sum_skips_what_the_reference_skips(arith, skip_dry):
     got, want = masso(base)
     assert np.isfinite(got).all()
     assert_rel(got, want, 1e-12, "finite cells only")
-    for fill in (0.0, -0.0, np.nan):  # +-inf * +-0 = NaN: skipped, like a NaN volume
+    cells = [tuple(h) for h in hits] + [(j, 3 + 11 * j) for j in range(ny)]
+    results = {}
+    for fill in (np.nan, 0.0, -0.0):  # +-inf * +-0 = NaN: skipped, like a NaN volume; x * +-0 = +-0
+        vol = base.copy()
+        for (j, i) in cells:
+            vol[0, j, i] = fill
+        results[repr(fill)], want2 = masso(vol)
+        assert np.isfinite(want2).all()
+        assert_rel(results[repr(fill)], want2, 1e-12, f"volume {fill!r} on the chosen cells")
+    assert np.array_equal(results["0.0"], results["nan"]) and np.array_equal(results["-0.0"], results["nan"])
+    if len(hits):  # (only the infinite-density cells were changed: the sum is the base case's)
         vol = base.copy()
         for (j, i) in hits:
-            vol[0, j, i] = fill
+            vol[0, j, i] = 0.0
         got2, want2 = masso(vol)
-        assert np.isfinite(want2).all() and np.array_equal(want2, want)
-        assert np.array_equal(got2, got), (arith, fill, got2, got)
+        assert np.array_equal(want2, want) and np.array_equal(got2, got)
     # zero volumes on ordinary cells change nothing either (+-0 terms), whatever the arithmetic
     vol = base.copy()
     vol[0, :, ::7] = np.where(finite[:, ::7], 0.0, np.nan)
     got3, want3 = masso(vol)
     assert_rel(got3, want3, 1e-12, "zero volumes on ordinary cells")
     # an infinite density on a cell WITH volume is added, as numpy adds it: the sum is +-inf
-    j, i = hits[0]
-    vol = base.copy()
-    vol[0, j, i] = 2.0
-    got4, want4 = masso(vol)
-    assert np.isinf(want4).all() and np.array_equal(got4, want4)
+    if len(hits):
+        j, i = hits[0]
+        vol = base.copy()
+        vol[0, j, i] = 2.0
+        got4, want4 = masso(vol)
+        assert np.isinf(want4).all() and np.array_equal(got4, want4)
     # the one class left out under the fused policy: rho == +-0 on a cell of infinite volume
     # (p = -p0: the numerator vanishes) -- the exact policy follows the reference there as well
     if arith == "exact":
