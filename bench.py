@@ -91,9 +91,9 @@ def kernel_source_sha():
 
 
 # (earlier rounds' summaries carry the sha of fewer files and can never match again)
-PROFILE_SUMMARIES = ("r05_summary.json",)
-VARIANT_SUMMARIES = ("r05_variants_summary.json", "r05_f32_variants_summary.json",
-                     "r05_strat_variants_summary.json")
+PROFILE_SUMMARIES = ("r06_summary.json",)
+VARIANT_SUMMARIES = ("r06_variants_summary.json", "r06_f32_variants_summary.json",
+                     "r06_strat_variants_summary.json")
 
 
 def measured_traffic(cells_per_launch):
@@ -143,8 +143,9 @@ def valu_profiles():
                 continue
             prefix = "config5_f32." if "f32" in name else ""
             for k in summ["kernels"]:
-                if k.get("bench_key") and "valu_wave_instr_per_cell" in k:
-                    found[prefix + k["bench_key"]] = k["valu_wave_instr_per_cell"]
+                for key in k.get("bench_keys") or ([k["bench_key"]] if k.get("bench_key") else []):
+                    if "valu_wave_instr_per_cell" in k:
+                        found[prefix + key] = k["valu_wave_instr_per_cell"]
             sources.append(f"profiles/{name}")
         except (OSError, KeyError, ValueError):
             pass
@@ -264,7 +265,8 @@ def compact_line(line, detail_bytes):
     ex = line.get("reference_example_call")
     if isinstance(ex, dict):
         out["reference_example_call"] = {k: ex[k] for k in (
-            "wall_s", "GB/s_host_link_in_plus_out", "step_bit_identical_to_oracle", "error") if k in ex}
+            "wall_s", "GB/s_host_link_in_plus_out", "link_duplex_floor_s", "frac_of_link_duplex_floor",
+            "step_bit_identical_to_oracle", "error") if k in ex}
     if "valu_roofline" in line:
         out["f64_fma_probe_lane_instr_per_s"] = line["valu_roofline"].get(
             "f64_fma_probe_lane_instr_per_s")
@@ -844,8 +846,24 @@ def example_call():
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         torch.cuda.empty_cache()
-        out = mod.run(checker=_example_call_checker)
+        out = mod.run(reps=4, checker=_example_call_checker)
         torch.cuda.empty_cache()
+        # the link's own floor for this byte mix, both directions at once, no host work at all
+        # (scripts/link_duplex_probe.py): what the wall time is to be held against -- not
+        # bytes / 57 GB/s: beside the uploads the downloads run at ~52 GB/s
+        spec = importlib.util.spec_from_file_location(
+            "link_duplex_probe", os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts",
+                                              "link_duplex_probe.py"))
+        probe = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(probe)
+        floor = probe.run(out["host_bytes_streamed_in_GB"], out["host_bytes_out_GB"], reps=3)
+        torch.cuda.empty_cache()
+        out["link_duplex_floor_s"] = floor["floor_s_for_this_byte_mix"]
+        out["link_d2h_GB/s_alone_and_beside_h2d"] = [max(floor["d2h_alone"]["d2h_GB/s"]),
+                                                     max(floor["both_at_once"]["d2h_GB/s"])]
+        out["frac_of_link_duplex_floor"] = round(out["link_duplex_floor_s"] / min(out["wall_s"]), 3)
+        out["note"] = ("wall_s[0] is the process's first call (page-locked rings and result mappings "
+                       "are made there); from the second call on the results land in pooled mappings")
         return out
     except Exception as exc:  # reported, never fatal for the bench line
         return {"error": f"{type(exc).__name__}: {exc}"}

@@ -47,7 +47,7 @@ extern "C" {
                              6: mlx_host_copy; mlx_stratification, mlx_adjust_negative_n2,
                                 mlx_wave_speed_where_time0
                              7: mlx_host_copy_masked
-                             8: mlx_host_prefault; MLX_FUNC_DENSITY_REF in mlx_eos_map_promote */
+                             8: MLX_FUNC_DENSITY_REF in mlx_eos_map_promote */
 
 /* argument-error codes (negative) */
 #define MLX_E_NULL     (-1) /* a required pointer is NULL                      */
@@ -429,19 +429,6 @@ int mlx_host_copy(void *dst, const void *src, size_t nbytes, int threads, int st
  * MLX_E_ENUM.  Touches no device. */
 int mlx_host_copy_masked(void *dst, const void *src, const unsigned char *mask, size_t n,
                          int elem_size, int threads);
-
-/* Make the pages of [addr, addr + nbytes) of WRITABLE host memory present WITHOUT changing a byte of
- * it, front to back, on `threads` (1..64) threads of its own (not the copy team: it runs beside the
- * copies).  For the fresh result arrays of the local variants (momlevel_amd/hostio.py result_array:
- * 2 MiB-aligned anonymous mappings advised MADV_HUGEPAGE): the reference's `delta_rho` is a 4-D
- * float64 field (src/momlevel/steric.py:150-157) and the first touch of 27 GB of new pages by the
- * threads that copy results out of the staging ring ran at 47-57 GB/s, below the host link; faulted
- * in AHEAD of the copy, while the first time chunk is uploaded and computed, the copy-out finds warm
- * pages (105-190 GB/s).  Linux: madvise(MADV_POPULATE_WRITE) per block; where the kernel does not
- * know it (< 5.14; or on demand: environment MOMLEVEL_AMD_PREFAULT=touch), an atomic `or 0` per page
- * -- either way safe against the copy threads writing the same pages concurrently.  Blocks are handed out in ascending order, so the front of the range is
- * ready first.  nbytes == 0: nothing.  Touches no device. */
-int mlx_host_prefault(void *addr, size_t nbytes, int threads);
 
 #ifdef __cplusplus
 }

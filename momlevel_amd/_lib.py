@@ -105,7 +105,6 @@ SIGNATURES = {
     "mlx_calc_dz": (_int, [_vp, _vp, _i64, _i64, _dbl, _dbl, _int, _int, _vp, _vp]),
     "mlx_host_copy": (_int, [_vp, _vp, _sz, _int, _int]),
     "mlx_host_copy_masked": (_int, [_vp, _vp, _vp, _sz, _int, _int]),
-    "mlx_host_prefault": (_int, [_vp, _sz, _int]),
     "mlx_stratification": (_int, [_vp, _vp, _int, _vp, _i64, _i64, _i64, _int, _int, _vp, _int,
                                   _dbl, _dbl, _i64, _i64, _i64, _vp, _vp]),
     "mlx_adjust_negative_n2": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),

@@ -20,14 +20,11 @@
 #include <immintrin.h>
 #endif
 #include <pthread.h>
-#include <sys/mman.h>
-#include <unistd.h>
 
 #include <atomic>
 #include <condition_variable>
 #include <cstddef>
 #include <cstdint>
-#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -345,78 +342,4 @@ extern "C" int mlx_host_copy_masked(void* dst, const void* src, const unsigned c
   return 0;
 }
 
-// Fault in [addr, addr + nbytes) without changing it (include/momlevel_hip.h).  Threads of its own,
-// joined before returning: a call covers one result array, of which there are a handful per steric()
-// call, and it must not queue behind -- or in front of -- the copy team's slices.
-namespace {
-#ifndef MADV_POPULATE_WRITE
-#define MADV_POPULATE_WRITE 23  // (Linux 5.14; older headers do not carry it)
-#endif
-constexpr size_t kPrefaultBlock = size_t(32) << 20;  // 16 huge pages per hand-out
-
-volatile unsigned char g_zero = 0;  // (volatile: the compiler must not know the operand is 0 --
-                                    //  it turns an idempotent atomic RMW into a fence + LOAD)
-void touch_pages(unsigned char* p, size_t n, size_t page) {
-  // an atomic read-modify-write that writes back what it read: a write fault, no change of value,
-  // and no lost update if a copy thread stores to the same word meanwhile
-  const unsigned char zero = g_zero;
-  for (size_t off = 0; off < n; off += page)
-    __atomic_fetch_or(reinterpret_cast<unsigned char*>(p + off), zero, __ATOMIC_RELAXED);
-}
-
-// `base` is the range's start aligned DOWN to a page (madvise wants that), `head` the bytes in
-// front of the range in that first page: the touch fallback never accesses them.
-void prefault_blocks(unsigned char* base, size_t nbytes, size_t head, std::atomic<size_t>* next,
-                     size_t page, std::atomic<int>* populate_ok) {
-  for (;;) {
-    const size_t off = next->fetch_add(kPrefaultBlock, std::memory_order_relaxed);
-    if (off >= nbytes) return;
-    const size_t n = (off + kPrefaultBlock <= nbytes) ? kPrefaultBlock : nbytes - off;
-    if (populate_ok->load(std::memory_order_relaxed)) {
-      // (madvise wants a page-aligned start: `base` is aligned down by the caller below)
-      if (madvise(base + off, n, MADV_POPULATE_WRITE) == 0) continue;
-      populate_ok->store(0, std::memory_order_relaxed);  // EINVAL on an old kernel, or not ours
-    }
-    if (off == 0) {  // the first page from the range's first byte, the others from their start
-      touch_pages(base + head, 1, page);
-      if (n > page) touch_pages(base + page, n - page, page);
-    } else {
-      touch_pages(base + off, n, page);
-    }
-  }
-}
-}  // namespace
-
-extern "C" int mlx_host_prefault(void* addr, size_t nbytes, int threads) {
-  if (nbytes == 0) return 0;
-  if (addr == nullptr) return mlx::detail::fail(MLX_E_NULL, "addr must not be NULL");
-  if (threads < 1 || threads > kMaxThreads)
-    return mlx::detail::fail(MLX_E_SHAPE, "threads must be in 1..64");
-  uintptr_t a = reinterpret_cast<uintptr_t>(addr);
-  if (nbytes > UINTPTR_MAX - a)
-    return mlx::detail::fail(MLX_E_SHAPE, "the range wraps around the address space");
-  long pg = sysconf(_SC_PAGESIZE);
-  const size_t page = pg > 0 ? static_cast<size_t>(pg) : 4096;
-  const uintptr_t lo = a & ~(uintptr_t)(page - 1);  // whole pages: the first one from its start
-  const size_t head = a - lo;
-  nbytes += head;
-  auto* base = reinterpret_cast<unsigned char*>(lo);
-  std::atomic<size_t> next(0);
-  // MOMLEVEL_AMD_PREFAULT=touch: the fallback of kernels without MADV_POPULATE_WRITE, on demand (tests)
-  const char* how = std::getenv("MOMLEVEL_AMD_PREFAULT");
-  std::atomic<int> populate_ok(how != nullptr && std::strcmp(how, "touch") == 0 ? 0 : 1);
-  const size_t blocks = (nbytes + kPrefaultBlock - 1) / kPrefaultBlock;
-  int extra = threads - 1;
-  if (static_cast<size_t>(extra) > blocks - 1) extra = static_cast<int>(blocks - 1);
-  std::thread pool[kMaxThreads];
-  int started = 0;
-  try {
-    for (; started < extra; ++started)
-      pool[started] = std::thread(prefault_blocks, base, nbytes, head, &next, page, &populate_ok);
-  } catch (...) {  // no more threads to be had: the ones there are (and this one) do it
-  }
-  prefault_blocks(base, nbytes, head, &next, page, &populate_ok);
-  for (int i = 0; i < started; ++i) pool[i].join();
-  return 0;
-}
 #endif  // !__HIP_DEVICE_COMPILE__

@@ -299,8 +299,8 @@ def sum_dtype(x):
 # ---------------------------------------------------------------------------------------
 def _host_output(shape):
     """float64 host array for results copied back from the device, filled through the staging ring:
-    a huge-page mapping of our own when large (faulted in ahead of the copy-out, hostio.Prefaulter),
-    an ordinary numpy array when small, page-locked memory when the caller opted in; see
+    a huge-page mapping of our own when large (pooled across calls, hostio._ResultPool), an ordinary
+    numpy array when small, page-locked memory when the caller opted in; see
     hostio.result_array."""
     return hostio.result_array(shape, np.float64)
 
@@ -353,7 +353,7 @@ def local_steric(T, S, rho0, vol0, pres, rhozero, z_i=None, deptho=None, dz=None
                               delta_rho_out=drho[t0:t1] if want_delta_rho else None,
                               eta_out=eta[t0:t1])
         return drho, eta
-    with hostio.Prefaulter([eta, drho], chunks.bounds()), hostio.Downloader(dev) as results:
+    with hostio.Downloader(dev) as results:
         for t0, t1, Tc, Sc in chunks:
             pc = pressure_chunk(pres, t0, t1, dev)
             d, e = core.steric_local(Tc, Sc, rho0m, surface, pc, neg_inv, dz=dz, z_i=z_i,
@@ -501,12 +501,8 @@ def local_steric_variants(T, S, T0, S0, rho0, vol0, pres, rhozero, variants, z_i
               want_delta_rho=want_delta_rho)
     import contextlib
 
-    # host results leave on a stream and a worker thread of their own (hostio.Downloader), into
-    # pages that are faulted in ahead of them, in the order the chunks arrive (hostio.Prefaulter)
-    out_bounds = [((t0 // 12, t1 // 12) if annual else (t0, t1)) for t0, t1 in chunks.bounds()]
-    ahead = (hostio.Prefaulter([a for v in variants for a in (eta[v], drho[v])], out_bounds)
-             if out_host else contextlib.nullcontext())
-    with ahead, (hostio.Downloader(dev) if out_host else contextlib.nullcontext()) as results:
+    # host results leave on a stream and a worker thread of their own (hostio.Downloader)
+    with (hostio.Downloader(dev) if out_host else contextlib.nullcontext()) as results:
         for t0, t1, Tc, Sc in chunks:
             o0, o1 = (t0 // 12, t1 // 12) if annual else (t0, t1)
             pc = pressure_chunk(pres, t0, t1, dev)

@@ -105,7 +105,7 @@ def _evaluate_host_chunked(eos, func, T, S, p, gravity):
         ops = [part(arrs[0], i0, i1), part(arrs[1], i0, i1), None if p is None else part(arrs[2], i0, i1)]
         return ops, [k for k, x in enumerate(ops) if x is not None and not _is_weak(x)]
 
-    out, ahead = None, None
+    out = None
     up = hostio.Uploader(device)
     try:
         with hostio.Downloader(device) as results:
@@ -122,16 +122,12 @@ def _evaluate_host_chunked(eos, func, T, S, p, gravity):
                     cur[k] = t
                 res = evaluate(eos, func, cur[0], cur[1], cur[2], gravity=gravity)  # device tensor
                 if out is None:
-                    # (a huge-page mapping of our own when large, its pages faulted in ahead of the
-                    # copy-out piece by piece: hostio.result_array / Prefaulter)
+                    # (a mapping of our own when large, pooled across calls: hostio.result_array)
                     out = hostio.result_array(shape, np.float32 if res.dtype == torch.float32
                                               else np.float64)
-                    ahead = hostio.Prefaulter([out], bounds)
                 results.submit([(out[i0:i1], res.reshape(out[i0:i1].shape))])
     finally:
         up.close()
-        if ahead is not None:
-            ahead.close()
     return out
 
 

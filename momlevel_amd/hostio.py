@@ -327,14 +327,11 @@ def pinned_array(shape, dtype=np.float64):
 
 
 # Results of at least this size (the 4-D delta_rho fields and the (time, yh, xh) heights of the local
-# variants at real sizes) are handed out in 2 MiB-aligned anonymous mappings advised MADV_HUGEPAGE and
-# faulted in AHEAD of the copy-out (Prefaulter).  0 disables (np.empty, first touch by the copy
-# threads: 47-57 GB/s, below the 57 GB/s link -- profiles/r04_result_alloc_probe.log).
+# variants at real sizes) are handed out in 2 MiB-aligned anonymous mappings of our own, advised
+# MADV_HUGEPAGE, which a bounded pool keeps for the next call when their arrays die (_ResultPool).
+# 0 disables (np.empty).
 HUGE_RESULT_BYTES = int(os.environ.get("MOMLEVEL_AMD_HUGE_RESULT_MIB", "64")) << 20
 _HUGE_PAGE = 2 << 20
-# (0: result pages are NOT faulted in ahead of the copy-out -- the default since it measured
-#  slower end to end with 1, 2, 4 and 8 threads: profiles/r06_result_prefault_negative.log)
-PREFAULT_THREADS = int(os.environ.get("MOMLEVEL_AMD_PREFAULT_THREADS", "0"))
 
 
 def _pool_cap_bytes():
@@ -469,56 +466,6 @@ def owns_mapping(a):
     while isinstance(a, np.ndarray):
         a = a.base
     return isinstance(a, memoryview) and isinstance(a.obj, mmap.mmap)
-
-
-class Prefaulter:
-    """Fault the pages of fresh result arrays in, in the order the downloads will write them -- for
-    every time chunk, every array's rows of that chunk -- on a thread of its own that calls
-    mlx_host_prefault (PREFAULT_THREADS native threads, the GIL released): it starts while the first
-    chunk is still being uploaded and computed and stays ahead of the copy-out, which then finds warm
-    pages.  Contents are never changed (it may fall behind the copy: harmless).  Only arrays that
-    result_array() mapped are touched; numpy's own allocations are left to numpy.
-
-        with hostio.Prefaulter(arrays, bounds): ...chunk loop...
-    """
-
-    def __init__(self, arrays, bounds):
-        self._arrays = [a for a in arrays if a is not None and owns_mapping(a)]
-        self._bounds = list(bounds)
-        self._stop = False
-        self._thread = None
-        if self._arrays and PREFAULT_THREADS > 0:
-            self._thread = threading.Thread(target=self._run, name="mlx-prefault", daemon=True)
-            self._thread.start()
-
-    def _run(self):
-        from . import _lib
-
-        try:
-            fn = _lib.load().mlx_host_prefault
-        except Exception:  # (no library: nothing to do ahead of time)
-            return
-        for t0, t1 in self._bounds:
-            for a in self._arrays:
-                if self._stop:
-                    return
-                part = a[t0:t1]
-                if part.size and fn(part.ctypes.data, part.nbytes, PREFAULT_THREADS) != 0:
-                    return
-
-    def close(self):
-        self._stop = True
-        if self._thread is not None:
-            self._thread.join()
-            self._thread = None
-        self._arrays = []
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        self.close()
-        return False
 
 
 def _drain_one(ring, pending):
@@ -752,9 +699,6 @@ def to_host(t):
         return t.cpu().numpy()
     out = result_array(tuple(t.shape), np.float32 if t.dtype == torch.float32 else np.float64)
     stream = torch.cuda.current_stream(t.device)
-    flat = out.reshape(-1)
-    step = max(1, (4 * PIECE_BYTES) // out.itemsize)
-    with Prefaulter([flat], [(i, min(i + step, flat.size)) for i in range(0, flat.size, step)]):
-        download_into(out, t, stream)
-        stream.synchronize()
+    download_into(out, t, stream)
+    stream.synchronize()
     return out

@@ -712,22 +712,6 @@ int mlx_host_copy_masked(void *dst, const void *src, const unsigned char *mask, 
   return 0;
 }
 
-int mlx_host_prefault(void *addr, size_t nbytes, int threads) {
-  /* the checker's build: one thread, one atomic `or 0` per page -- same contract: pages present,
-     no byte changed (include/momlevel_hip.h) */
-  if (nbytes == 0) return 0;
-  if (!addr) return fail(MLX_E_NULL, "addr must not be NULL");
-  if (threads < 1 || threads > 64) return fail(MLX_E_SHAPE, "threads must be in 1..64");
-  if (nbytes > UINTPTR_MAX - (uintptr_t)addr)
-    return fail(MLX_E_SHAPE, "the range wraps around the address space");
-  unsigned char *p = (unsigned char *)addr;
-  static volatile unsigned char zero_operand = 0; /* (not a constant: an `or 0` may become a load) */
-  const unsigned char zero = zero_operand;
-  for (size_t off = 0; off < nbytes; off += 4096) __atomic_fetch_or(p + off, zero, __ATOMIC_RELAXED);
-  __atomic_fetch_or(p + nbytes - 1, zero, __ATOMIC_RELAXED);
-  return 0;
-}
-
 static inline uint64_t splitmix64(uint64_t x) {
   uint64_t z = x + 0x9E3779B97F4A7C15ULL;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;

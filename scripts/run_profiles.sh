@@ -17,7 +17,7 @@ BENCH="python3 bench.py --steps 5 --warmup 1 --no-extras --cpu-seconds 0"
 echo "== bench: kernel trace + stats"; rocprofv3 --output-format csv --kernel-trace --stats -d $B/trace -o run -- $BENCH > $B/bench_trace.log 2>&1
 echo "== bench: FETCH_SIZE";           rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $B/pmc_fetch -o run -- $BENCH > $B/bench_pmc_fetch.log 2>&1
 echo "== bench: WRITE_SIZE";           rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $B/pmc_write -o run -- $BENCH > $B/bench_pmc_write.log 2>&1
-VAR="python3 scripts/profile_variants.py --nt 40 --reps 2"
+VAR="python3 scripts/profile_variants.py --nt ${NT:-120} --nt-out ${NT_OUT:-24} --reps 2"
 echo "== variants: plain";             $VAR --plan-out $V/plan.json > $V/plain.log 2>&1
 echo "== variants: kernel trace";      rocprofv3 --output-format csv --kernel-trace --stats -d $V/trace -o run -- $VAR > $V/trace.log 2>&1
 echo "== variants: FETCH_SIZE";        rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $V/pmc_fetch -o run -- $VAR > $V/pmc_fetch.log 2>&1
@@ -34,7 +34,7 @@ if [ "$PART" = "f64" ]; then exit 0; fi
 # --- float32 theta/S (BASELINE.json configs[4]): the same variants, half the bytes per cell
 W=gpurun_out/prof_${TAG}v32
 mkdir -p $W
-VAR32="python3 scripts/profile_variants.py --nt 40 --reps 2 --dtype f32"
+VAR32="python3 scripts/profile_variants.py --nt ${NT:-120} --nt-out ${NT_OUT32:-48} --reps 2 --dtype f32"
 echo "== f32 variants: plain";        $VAR32 --plan-out $W/plan.json > $W/plain.log 2>&1
 echo "== f32 variants: kernel trace"; rocprofv3 --output-format csv --kernel-trace --stats -d $W/trace -o run -- $VAR32 > $W/trace.log 2>&1
 echo "== f32 variants: FETCH_SIZE";   rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $W/pmc_fetch -o run -- $VAR32 > $W/pmc_fetch.log 2>&1

@@ -19,7 +19,8 @@ import shutil
 import sys
 
 # the kernels whose dispatches the plan lists (MLX_SUMMARY_MAIN overrides: run_profiles_strat.sh)
-MAIN = tuple(os.environ.get("MLX_SUMMARY_MAIN", "k_steric_global,k_steric_local").split(","))
+MAIN = tuple(os.environ.get("MLX_SUMMARY_MAIN",
+                            "k_steric_global,k_steric_local,k_eos_map,k_eos_promote").split(","))
 
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -59,6 +60,7 @@ def main(src, prefix):
     cells = plan["cells_per_launch"]
     summary = {
         "grid": "{}x{}x{}, nt={} resident, {}".format(*plan["grid"], plan["nt"], plan["dtype"]),
+        "nt_of_cases_with_a_4d_output": plan.get("nt_of_cases_with_a_4d_output", plan["nt"]),
         # bench.py quotes these instruction counts only while the kernel sources are the profiled ones
         "kernel_source_sha": kernel_source_sha(),
         "strat_source_sha": strat_source_sha() if "k_stratification" in MAIN else None,
@@ -90,8 +92,14 @@ def main(src, prefix):
         if f:
             passes[tag] = chunk(by_dispatch(f, counter), plan)
     for i, c in enumerate(plan["cases"]):
+        if c.get("setup"):  # (a dispatch of the set-up, listed so that the order matches; no row)
+            continue
+        cells = c.get("cells", plan["cells_per_launch"])  # (per case since round 6)
+        keys = c.get("bench_key")
         k = {"kernel": c["case"], "algorithmic_bytes_per_cell": c["algorithmic_bytes_per_cell"],
-             "bench_key": c.get("bench_key")}
+             "cells_per_launch": cells,
+             "bench_key": keys[0] if isinstance(keys, list) else keys,
+             "bench_keys": keys if isinstance(keys, list) else ([keys] if keys else [])}
         if tr:
             part = tr[i][1:] or tr[i]  # first launch of a case is the warm-up
             ms = sum(d["ns"] for d in part) / len(part) / 1e6

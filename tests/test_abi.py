@@ -233,49 +233,10 @@ def _resident_fraction(addr, nbytes):
     return sum(b & 1 for b in vec) / n
 
 
-@pytest.mark.parametrize("how", ["populate", "touch"])
-def test_host_prefault_needs_no_gpu(how, monkeypatch):
-    """mlx_host_prefault (v8): the pages of a fresh mapping become resident, no byte changes -- not
-    even while another thread is writing the same pages -- for any alignment and thread count; by
-    madvise(MADV_POPULATE_WRITE) and by the atomic touch older kernels get."""
-    import mmap
-    import threading
-
-    if how == "touch":
-        monkeypatch.setenv("MOMLEVEL_AMD_PREFAULT", "touch")
-    lib = _lib.load()
-    n = 48 << 20
-    m = mmap.mmap(-1, n, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
-    a = np.frombuffer(m, dtype=np.uint8)
-    assert _resident_fraction(a.ctypes.data, n) < 0.01
-    assert lib.mlx_host_prefault(a.ctypes.data + 4097, (40 << 20) - 4097, 3) == 0
-    assert _resident_fraction(a.ctypes.data + 4097, (40 << 20) - 4097) == 1.0
-    assert _resident_fraction(a.ctypes.data + (41 << 20), 7 << 20) < 0.01  # nothing beyond the range
-    assert not a[: 40 << 20].any()  # fresh anonymous pages read as zero: untouched
-    # contents survive, with a writer racing the prefault over the same pages
-    want = np.random.default_rng(3).integers(1, 255, n, dtype=np.uint8)
-    m2 = mmap.mmap(-1, n, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
-    b = np.frombuffer(m2, dtype=np.uint8)
-    writer = threading.Thread(
-        target=lambda: lib.mlx_host_copy(b.ctypes.data, want.ctypes.data, n, 4, 1))
-    writer.start()
-    for threads in (1, 4, 64):
-        assert lib.mlx_host_prefault(b.ctypes.data, n, threads) == 0
-    writer.join()
-    assert np.array_equal(b, want)
-    assert lib.mlx_host_prefault(b.ctypes.data + 5, 1, 1) == 0 and np.array_equal(b, want)
-    assert lib.mlx_host_prefault(None, 0, 1) == 0
-    assert lib.mlx_host_prefault(None, 8, 1) == -1
-    assert lib.mlx_host_prefault(b.ctypes.data, 8, 0) == -2
-    assert lib.mlx_host_prefault(b.ctypes.data, 8, 65) == -2
-    assert lib.mlx_host_prefault(ctypes.c_void_p(2**64 - 16), 64, 1) == -2
-    del a, b
-
-
-def test_result_arrays_own_their_mapping_and_are_faulted_in_ahead(monkeypatch):
+def test_result_arrays_own_their_mapping_and_a_pool_keeps_dead_ones(monkeypatch):
     """hostio.result_array: large results live in a 2 MiB-aligned anonymous mapping of their own
      -- a writable numpy array whose memory goes back to the OS when the last view
-    dies -- and hostio.Prefaulter makes its pages resident chunk by chunk without writing them."""
+    dies, or into a bounded pool that serves the next result of that size (warm pages)."""
     import gc
     import weakref
 
@@ -283,7 +244,6 @@ def test_result_arrays_own_their_mapping_and_are_faulted_in_ahead(monkeypatch):
 
     monkeypatch.setattr(hostio, "HUGE_RESULT_BYTES", 8 << 20)
     monkeypatch.setenv("MOMLEVEL_AMD_RESULT_POOL_GIB", "0")  # first without the pool of kept mappings
-    monkeypatch.setattr(hostio, "PREFAULT_THREADS", 2)
     small = hostio.result_array((100, 100), np.float64)
     assert type(small) is np.ndarray and small.base is None and not hostio.owns_mapping(small)
     shape = (6, 3, 40, 2048)  # 11.8 MB of float64
@@ -311,18 +271,8 @@ def test_result_arrays_own_their_mapping_and_are_faulted_in_ahead(monkeypatch):
     assert mapping() is None
     with open("/proc/self/maps") as f:
         assert not any(line.startswith(f"{addr:x}-") for line in f), "the result mapping is still there"
-    # the prefaulter: rows [t0, t1) of every mapped array, chunk by chunk; numpy's own arrays skipped
     out = hostio.result_array(shape, np.float64)
-    eta = np.empty((6, 40, 2048))
-    assert _resident_fraction(out.ctypes.data, out.nbytes) < 0.05
-    with hostio.Prefaulter([eta, out, None], [(0, 2), (2, 4)]) as p:
-        assert [a is out for a in p._arrays] == [True]
-        p._thread.join()
-    assert _resident_fraction(out.ctypes.data, out[:4].nbytes) == 1.0
-    # (nothing beyond the chunks asked for, up to the huge page that straddles their end)
-    beyond = -(-out[4:].ctypes.data // (2 << 20)) * (2 << 20)
-    assert _resident_fraction(beyond, out.ctypes.data + out.nbytes - beyond) < 0.01
-    assert not out[:4].any()
+    assert _resident_fraction(out.ctypes.data, out.nbytes) < 0.05  # fresh: nothing touched yet
     del out
     gc.collect()
     # the pool of kept mappings: a dead result's mapping serves the next result of that size (warm
