@@ -501,7 +501,18 @@ __global__ __launch_bounds__(kBlock) void k_reduce_rows(const double* __restrict
   __shared__ double red[kBlock];
   const double* row = partials + (int64_t)blockIdx.x * n;
   double c = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += kBlock) c += row[i];
+  // eight loads in flight, then the eight adds IN THE ORDER of the plain loop (the same bits): one
+  // load per dependent add left a 24-row launch -- a time chunk of the tiled walk -- at 85 us for
+  // 11 MB (latency, not bandwidth), paid once per chunk (profiles/r06_forced_collective_trace.txt)
+  int64_t i = threadIdx.x;
+  for (; i + 7 * (int64_t)kBlock < n; i += 8 * (int64_t)kBlock) {
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = row[i + (int64_t)k * kBlock];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c += v[k];
+  }
+  for (; i < n; i += kBlock) c += row[i];
   red[threadIdx.x] = c;
   __syncthreads();
 #pragma unroll
@@ -583,6 +594,7 @@ __global__ __launch_bounds__(kBlock) void k_nansum_partial(const double* __restr
 // 6.0, and the kernel it was meant to bound ran at 5.1: a probe slower than the kernel is not a
 // ceiling.  (Beyond 2^23 tiles the blocks stride over the tiles: a HIP grid holds < 2^32 threads.)
 constexpr int64_t kProbeMaxBlocks = (int64_t)1 << 23;
+constexpr int64_t kK2MaxBlocks1D = ((int64_t)1 << 24) - 1;  // x kBlock (256) threads < 2^32
 // VEC: elements per lane and pack -- 16 bytes' worth, except float32 in / float64 out, where TWO
 // floats per lane (an 8-byte load, ONE 16-byte store: the access widths of K2's two-column float32
 // shape) read 6.6 / 6.1 TB/s where four floats and two stores per lane read 5.9 / 5.7
@@ -1622,7 +1634,9 @@ int steric_local_impl(const void* T, const void* S, const void* T0, const void* 
   {  // time blocks of a tile side by side on one XCD (see the kernel) when there is more than one
     const int64_t ntb = ceil_div(nt, nti);
     const int64_t blocks = ceil_div(gx, 8) * 8 * ntb;
-    if (MLX_TUNE_K2_TBMAJOR && ntb > 1 && blocks <= 2147483647LL) {
+    // (a HIP grid holds fewer than 2^32 THREADS: beyond 2^24 - 1 blocks of kBlock the 1-D form
+    //  would not launch where the (tiles, time blocks) grid does -- ADVICE r5)
+    if (MLX_TUNE_K2_TBMAJOR && ntb > 1 && blocks <= kK2MaxBlocks1D) {
       a.grid = dim3((unsigned)blocks);
       a.ntb_major = (int)ntb;
     }

@@ -375,11 +375,17 @@ def steric_global_tile_streamed(source, vol0, areacello, pres, variants=("steric
     names = list(variants) + (["heat"] if heat else [])
     walker, nt = _chunk_source(source, dev, steps)
     exchange = ChunkedExchange(len(names), group=group, force=force_collective)
+    # the held fields of the reference state (time level 0 of the record) are read by the
+    # thermosteric / halosteric rows only; a chunk of a RESIDENT record is a view of memory that
+    # stays, anything else (uploaded or generated chunks, whose buffers are reused) is cloned --
+    # for the steric row of a resident record nothing is copied (2 x 0.93 GB per pass at 0.25 deg)
+    need_held = one_pass or variants[0] != "steric"
+    views_stay = engine._is_device(source[0]) and engine._is_device(source[1])
     T0 = S0 = None
+    first = True
     for t0, t1, Tc, Sc in walker:
-        first = T0 is None
-        if first:  # reference state = time level 0 of the record (cloned: chunks may be reused)
-            T0, S0 = Tc[0].clone(), Sc[0].clone()
+        if first and need_held:
+            T0, S0 = (Tc[0], Sc[0]) if views_stay else (Tc[0].clone(), Sc[0].clone())
         pc = engine.pressure_chunk(pres, t0, t1, dev)
         ev = None
         if events is not None:
@@ -395,6 +401,7 @@ def steric_global_tile_streamed(source, vol0, areacello, pres, variants=("steric
                                             skip_dry=skip_dry, events=ev).reshape(1, -1)
         tail = None
         if first:
+            first = False
             # masso0 = masso(t=0) of this very launch: every variant sees (theta0, S0) there, the
             # same kernel, tiling and operands -> steric[t=0] == 0 exactly, for any world size
             area = core.nansum(engine.to_device(areacello, dev, torch.float64))

@@ -478,6 +478,16 @@ def test_k2_block_mapping_covers_every_tile_and_time_block_once():
     assert re.search(r"const int64_t q = blockIdx\.x >> 3;\s*tb = \(int\)\(q % ntb_major\);\s*"
                      r"tile = \(q / ntb_major\) \* 8 \+ \(blockIdx\.x & 7\);", src)
     assert "const int64_t blocks = ceil_div(gx, 8) * 8 * ntb;" in src
+    # a HIP grid holds fewer than 2^32 threads, so the 1-D form is taken only up to
+    # 2^24 - 1 blocks of 256; beyond it the (tiles, time blocks) grid -- gx <= 2^31 - 1 on grid.x,
+    # ntb <= 65535 on grid.y -- launches as before
+    assert "constexpr int64_t kK2MaxBlocks1D = ((int64_t)1 << 24) - 1;" in src
+    assert "ntb > 1 && blocks <= kK2MaxBlocks1D" in src
+    assert re.search(r"constexpr int kBlock = 256;", src)
+    for gx, ntb, one_d in ((3038, 15, True), (2097144, 8, True), (2097151, 8, False),
+                           (1 << 21, 9, False), (8, 2097151, True), (9, 2097151, False)):
+        blocks = -(-gx // 8) * 8 * ntb
+        assert (blocks <= (1 << 24) - 1) == one_d and (not one_d or blocks * 256 < 1 << 32)
     for tiles in (1, 7, 8, 9, 64, 3038):
         for ntb in (2, 3, 10, 15):
             blocks = -(-tiles // 8) * 8 * ntb
