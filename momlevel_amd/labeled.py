@@ -63,7 +63,16 @@ def check_field_dtype(dt, what="theta / salinity"):
     """numpy evaluates the equation of state on float16 (or long double) arrays IN that precision --
     the python-float constants of eos/wright.py take the arrays' dtype -- which no kernel here
     restates; rather than answer in other bits (a silent float64 upcast), such fields are refused.
-    float32 / float64 pass; integers and booleans compute as float64, as in numpy."""
+    float32 / float64 pass; integers and booleans compute as float64, as in numpy.
+
+    One known deviation, parity unpinned (no reference fixture holds such a field): a
+    LAZILY read integer field of 16 bits or fewer whose slices come back MASKED (an int16
+    netCDF4.Variable with a _FillValue and no scale_factor).  xarray decodes such a variable to
+    float32 (``maybe_promote``), so the reference would evaluate its part of the polynomial in
+    float32; the declared dtype of a lazy source says "int16", which streams as float64 here (the
+    masked slices are promoted to float32 by as_plain and then widened exactly).  An IN-MEMORY masked
+    int16 array is float32 from the moment it is wrapped, as in xarray.  Convert such a variable to
+    float32 before the call to get the reference's bits."""
     name = dtype_name(dt)
     if name in _UNSUPPORTED:
         raise TypeError(f"{name} {what} are not supported: numpy evaluates their part of the "

@@ -721,3 +721,37 @@ def test_element_misaligned_masked_data_fall_back_to_numpy():
     assert np.array_equal(np.isnan(got), mask) and not got[~mask].any()
     plain, mk = hostio.split_masked(m)
     assert mk is None and np.array_equal(np.isnan(plain), mask)
+
+
+def test_small_integer_masked_sources_in_memory_follow_xarray_lazy_ones_are_documented():
+    """xarray promotes a masked int16 variable to float32 (dtypes.maybe_promote), so
+    the reference computes such a field in float32.  In memory that is what happens here too -- the
+    DataArray holds float32 from the moment the masked array is wrapped.  A LAZY int16 source only
+    declares "int16": it streams as float64 (its masked slices, float32 after as_plain, widen
+    exactly) -- the deviation documented at labeled.check_field_dtype, parity unpinned."""
+    import torch
+    from lazy_array import MaskedLazy
+    from momlevel_amd import engine, hostio
+    from momlevel_amd.labeled import DataArray, check_field_dtype
+
+    a = np.arange(24, dtype=np.int16).reshape(2, 3, 4)
+    m = np.ma.masked_array(a, mask=(a % 5 == 0))
+    da = DataArray(m, ("t", "y", "x"))
+    assert da.dtype == np.float32 and np.isnan(da.values[0, 0, 0]) and da.values[0, 0, 1] == 1.0
+    assert engine._stream_dtype(da.data) == torch.float32
+    assert DataArray(a, ("t", "y", "x")).dtype == np.int16  # unmasked: numpy's int * float is float64
+    assert engine._stream_dtype(a) == torch.float64
+    lazy = MaskedLazy(a.astype(np.float64))  # (the stand-in masks NaNs: build the int16 case by hand)
+
+    class Int16Lazy:
+        shape, dtype, ndim = a.shape, a.dtype, a.ndim
+
+        def __getitem__(self, key):
+            return m[key]
+
+    src = Int16Lazy()
+    assert engine._stream_dtype(src) == torch.float64  # the documented deviation
+    plain, mask = hostio.split_masked(src[0:1], np.dtype(np.float64))
+    assert mask is None and plain.dtype == np.float64 and np.isnan(plain[0, 0, 0]) and plain[0, 0, 1] == 1.0
+    assert "int16" in check_field_dtype.__doc__ and "parity unpinned" in check_field_dtype.__doc__
+    del lazy
