@@ -82,8 +82,18 @@ class TimeChunks:
     A (nz,ny,nx) operand (a held field) is uploaded once and yielded with every chunk.
     """
 
-    def __init__(self, T, S, device, steps=None, extra_bytes_per_step=0):
+    def __init__(self, T, S, device, steps=None, extra_bytes_per_step=0, ramp=False,
+                 first_step=None):
+        """``ramp``: a SHORT first chunk (a quarter of the others, at least one step) when the fields
+        are streamed from the host -- for the passes whose results go back to the host: the first
+        result starts down the link a few milliseconds after the first upload instead of after a
+        whole chunk's, and the download direction is the one that bounds such a call.
+        ``first_step``: ``(T[0], S[0])`` as (z,y,x) DEVICE tensors (or None each) when the caller
+        has them already -- steric() made its reference state from time level 0 of this very
+        record: the first chunk is then that ONE step and is not uploaded a second time."""
         self.device = device
+        self.ramp = bool(ramp)
+        self._first_step = list(first_step) if first_step is not None else [None, None]
         self.fields = [T, S]
         self.nt = max(f.shape[0] for f in self.fields if f.ndim == 4) if any(
             f.ndim == 4 for f in self.fields
@@ -138,13 +148,23 @@ class TimeChunks:
             dev.record_stream(self._copy_stream)
         return dev, ev
 
+    def _have_first_step(self):
+        """is time level 0 of every field that would be uploaded on the device already?"""
+        need = [i for i, (f, res) in enumerate(zip(self.fields, self.resident)) if not res]
+        return bool(need) and all(
+            _is_device(self._first_step[i]) and self._first_step[i].dtype == _stream_dtype(self.fields[i])
+            and tuple(self._first_step[i].shape) == tuple(self.fields[i].shape[1:]) for i in need)
+
     def _stage(self, t0, t1):
         cur, events = [], []
-        for f, res, held in zip(self.fields, self.resident, self._held):
+        known = (t0, t1) == (0, 1) and self._have_first_step()
+        for i, (f, res, held) in enumerate(zip(self.fields, self.resident, self._held)):
             if f.ndim == 3:
                 cur.append(held)
             elif res:
                 cur.append(f[t0:t1])
+            elif known:
+                cur.append(self._first_step[i].unsqueeze(0))  # (already there: nothing to move)
             else:
                 dev, ev = self._upload(f, t0, t1)
                 cur.append(dev)
@@ -154,7 +174,11 @@ class TimeChunks:
 
     def bounds(self):
         """[(t0, t1)] of the chunks, in iteration order"""
-        return [(t0, min(t0 + self.steps, self.nt)) for t0 in range(0, self.nt, self.steps)]
+        first = 0
+        if self.ramp and not all(self.resident) and 1 < self.steps < self.nt:
+            first = 1 if self._have_first_step() else max(1, self.steps // 4)
+        out = [(0, first)] if first else []
+        return out + [(t0, min(t0 + self.steps, self.nt)) for t0 in range(first, self.nt, self.steps)]
 
     def __iter__(self):
         bounds = self.bounds()
@@ -331,7 +355,7 @@ def local_steric(T, S, rho0, vol0, pres, rhozero, z_i=None, deptho=None, dz=None
     if out_host is None:
         out_host = not (_is_device(T) or _is_device(S))
     extra = (n3 * 8 if (want_delta_rho and out_host) else 0) + _pressure_bytes_per_step(pres)
-    chunks = TimeChunks(T, S, dev, steps=steps, extra_bytes_per_step=extra)
+    chunks = TimeChunks(T, S, dev, steps=steps, extra_bytes_per_step=extra, ramp=out_host)
     nt = chunks.nt
     if out_host:
         eta = _host_output((nt, ny, nx))
@@ -433,12 +457,15 @@ def global_masso_variants(T, S, T0, S0, vol0, pres, variants, eos="wright", f32_
 
 def local_steric_variants(T, S, T0, S0, rho0, vol0, pres, rhozero, variants, z_i=None,
                           deptho=None, dz=None, eos="wright", f32_mode="faithful",
-                          want_delta_rho=True, out_host=None, steps=None, annual_weights=None):
+                          want_delta_rho=True, out_host=None, steps=None, annual_weights=None,
+                          reference_is_step0=False):
     """{variant: (delta_rho, eta)}; theta/S chunks are uploaded once and reused.
 
     ``annual_weights`` (nt,), nt a multiple of 12, whole years back to back: the days-in-month
     weighted annual means (util.annual_average) are taken ON THE DEVICE, chunk by chunk, so only
     1/12 of delta_rho / eta is ever stored or copied back; the outputs are (nt/12, ...).
+    ``reference_is_step0``: (T0, S0) ARE time level 0 of (T, S) -- a reference state steric() made
+    itself: the first chunk of a host record is then that step, taken from the device.
     """
     dev = device_of(T, S, rho0, vol0)
     vol0 = to_device(vol0, dev, torch.float64)
@@ -474,7 +501,10 @@ def local_steric_variants(T, S, T0, S0, rho0, vol0, pres, rhozero, variants, z_i
         if steps is None:
             steps = chunk_steps(nt, per_step, dev)
         steps = max(12, (int(steps) // 12) * 12)
-    chunks = TimeChunks(Ts, Ss, dev, steps=steps, extra_bytes_per_step=extra)
+    # (annual means need whole years per chunk: no short first chunk there)
+    chunks = TimeChunks(Ts, Ss, dev, steps=steps, extra_bytes_per_step=extra,
+                        ramp=out_host and not annual,
+                        first_step=(T0, S0) if reference_is_step0 else None)
     nt_out = nt // 12 if annual else nt
 
     def alloc(shape):

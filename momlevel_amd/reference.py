@@ -127,7 +127,19 @@ def _setup(dset, patm, eos, coord_names, time_index, defer_masso, twins=None):
         )
         if twins is not None:
             twins.update(thetao=T0d, so=S0d, volcello=V0d, rho=rho0)
-        rho = DataArray(rho0 if on_device else hostio.to_host(rho0), cdims, T0.coords, rho_attrs)
+        if on_device:
+            rho_data = rho0
+        elif twins is not None and rho0.numel() * 8 >= hostio.SMALL_BYTES:
+            # the caller goes straight on to the time loop: rho0 leaves for the host on a stream and a
+            # worker of its own WHILE the first chunk is uploaded (the other direction of the link)
+            # instead of holding the loop back for its 0.43 GB; the caller completes it before it
+            # returns (steric._steric_many: twins["pending"].finish())
+            rho_data = hostio.result_array(tuple(rho0.shape), np.float64)
+            twins["pending"] = hostio.Downloader(rho0.device)
+            twins["pending"].submit([(rho_data, rho0)])
+        else:
+            rho_data = hostio.to_host(rho0)
+        rho = DataArray(rho_data, cdims, T0.coords, rho_attrs)
         reference["rho"] = rho.transpose(*reference["thetao"].dims)
         # derived.py:789: volcello.sum() has volcello's dtype -- float32 for the float32 volumes MOM6
         # writes: the float64 device sum of the same values, rounded once; masso and

@@ -127,7 +127,7 @@ def _global_results(ops, reference, variants, dtype, tcoord, coords_for, deferre
 
 
 def _local_results(ops, dset, rho0, variants, dtype, rhozero, names, cdims3, coords_for,
-                   plan=None):
+                   plan=None, reference_is_step0=False):
     """steric.py:150-166 -- delta_rho and the column integral from K2.  ``rho0``: the reference
     state's density in canonical (z,y,x) order.  ``plan`` (an util.AnnualPlan): the annual means
     are taken on the device, fused behind K2."""
@@ -144,6 +144,7 @@ def _local_results(ops, dset, rho0, variants, dtype, rhozero, names, cdims3, coo
         T, S, T0, S0, rho0, vol0, p, rhozero, variants,
         z_i=dset[zbounds].data, deptho=deptho.data, eos=eos, f32_mode=_f32_mode(),
         want_delta_rho=want_delta_rho, annual_weights=None if plan is None else plan.weights,
+        reference_is_step0=reference_is_step0,
     )
     def result_coords(dims):
         coords = coords_for(dims)
@@ -206,11 +207,27 @@ def globalise_reference(reference, exchange):
     set_reference_masso(reference, vec[1])
 
 
-def _steric_many(dset, variants, reference, coord_names, varname_map, rhozero, patm,
+def _steric_many(*args, **kwargs):
+    """_steric_body with what the reference state left in flight completed before anything is
+    returned or raised (reference._setup sends rho0 to the host asynchronously)."""
+    twins = {}
+    try:
+        return _steric_body(twins, *args, **kwargs)
+    finally:
+        pending = twins.pop("pending", None)
+        if pending is not None:
+            import sys
+
+            pending.__exit__(*sys.exc_info())  # (finish(); on an error: drain, keep the error)
+
+
+def _steric_body(twins, dset, variants, reference, coord_names, varname_map, rhozero, patm,
                  equation_of_state, domain, dtype, strict, annual, verbose, heat_cp=None,
                  exchange=None):
     """The body of steric() for one or several variants sharing one reference state and one
     pass of theta/S through the device.  Returns ({variant: result}, reference).
+    ``twins``: the caller's dict for the device tensors of a self-made reference state (and its
+    pending rho0 download).
     ``exchange``: None, or -- when ``dset`` is ONE RANK'S horizontal tile of a multi-GPU run
     (momlevel_amd.parallel.steric) -- a callable summing a float64 vector over the ranks; the
     global sums (sum of areacello, volo, masso) then go through it, everything else is local."""
@@ -244,7 +261,6 @@ def _steric_many(dset, variants, reference, coord_names, varname_map, rhozero, p
     # (not with a time-dependent patm: that reference state is time dependent itself and is
     #  rejected by the validation below, as in momlevel)
     deferred = reference is None and domain == "global" and tcoord not in pres.dims
-    twins = {}  # device tensors of a self-made reference state's slabs (reference._setup)
     if reference is None:
         # domain="global": masso0 is masso(t=0) of the K1 launch below (same kernel, same bits)
         reference, err = _attempt(_setup, dset, patm, equation_of_state, coord_names, 0,
@@ -298,8 +314,9 @@ def _steric_many(dset, variants, reference, coord_names, varname_map, rhozero, p
     else:
         if heat_cp is not None:
             raise ValueError("heat_content is a global integral: use domain='global'")
+        # (twins: the reference state was made in this call from time level 0 of this record)
         results = _local_results(ops, dset, slab("rho"), variants, dtype, rhozero, names, cdims3,
-                                 coords_for, plan)
+                                 coords_for, plan, reference_is_step0="thetao" in twins)
 
     for variant, result in results.items():
         if variant == "heat":

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Where inside the recorded call (scripts/example_call.py) does the wall time go BEFORE the first
+result piece starts down the link and AFTER the last one arrives?  Timestamps (ms from the call's
+start) of the phases of steric(): validation, reference state, first upload done, first download
+submitted, last kernel enqueued, results complete."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import example_call  # noqa: E402
+import momlevel_amd  # noqa: E402,F401
+from momlevel_amd import engine, hostio  # noqa: E402
+
+steric_mod = sys.modules["momlevel_amd.steric"]
+
+marks = []
+T0 = [0.0]
+
+
+def mark(name):
+    marks.append((name, round((time.perf_counter() - T0[0]) * 1e3, 1)))
+
+
+def wrap(mod, name, before=None, after=None):
+    fn = getattr(mod, name)
+
+    def w(*a, **k):
+        if before:
+            mark(before)
+        try:
+            return fn(*a, **k)
+        finally:
+            if after:
+                mark(after)
+    setattr(mod, name, w)
+
+
+wrap(steric_mod, "validate_dataset", "validate>", "validate<")
+wrap(steric_mod, "_setup", "setup>", "setup<")
+wrap(steric_mod, "_local_results", "local>", "local<")
+wrap(engine, "local_steric_variants", "engine>", "engine<")
+first = {"submit": True}
+sub = hostio.Downloader.submit
+
+
+def submit(self, pairs):
+    if first["submit"]:
+        first["submit"] = False
+        mark("first download submitted")
+    return sub(self, pairs)
+
+
+hostio.Downloader.submit = submit
+fin = hostio.Downloader.finish
+
+
+def finish(self):
+    mark("loop done, waiting for downloads")
+    fin(self)
+    mark("downloads complete")
+
+
+hostio.Downloader.finish = finish
+runs = []
+
+
+def before():
+    if marks:
+        runs.append(list(marks))
+    marks.clear()
+    first["submit"] = True
+    T0[0] = time.perf_counter()
+
+
+out = example_call.run(reps=5, before_call=before)
+runs.append(list(marks))
+print(json.dumps({"wall_s": out["wall_s"], "last_call_marks_ms": runs[-1], "call_3_marks_ms": runs[2]}))
