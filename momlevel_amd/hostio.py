@@ -372,13 +372,29 @@ class _ResultPool:
     MAX_MAPPINGS = 12
 
     def __init__(self):
+        import collections
+
         self.lock = threading.Lock()
         self.free = []  # [(capacity in bytes, mmap object, aligned offset)], oldest first
+        # mappings handed back by finalizers, not yet in `free`: a finalizer may run wherever the
+        # garbage collector does -- also inside take() on this very thread -- so it never WAITS for
+        # the lock: it appends here (atomic) and whoever holds or next takes the lock absorbs
+        self.returned = collections.deque()
         self.reused = 0
         self.mapped = 0
 
+    def _absorb(self):
+        """(lock held) returned mappings -> free list, then the bounds"""
+        while self.returned:
+            self.free.append(self.returned.popleft())
+        limit = _pool_cap_bytes()
+        while self.free and (sum(c for c, _m, _o in self.free) > limit
+                             or len(self.free) > self.MAX_MAPPINGS):
+            self.free.pop(0)  # (unmapped when its mmap object is collected: now)
+
     def take(self, nbytes):
         with self.lock:
+            self._absorb()
             best = None
             for i, (cap, _m, _off) in enumerate(self.free):
                 if nbytes <= cap <= nbytes + max(nbytes // 2, _HUGE_PAGE):
@@ -390,22 +406,25 @@ class _ResultPool:
             return self.free.pop(best)
 
     def give(self, cap, m, off):
+        """(a weakref finalizer: any thread, any moment) keep the mapping of a dead result"""
         import mmap
 
-        limit = _pool_cap_bytes()
-        if cap > limit:
+        if cap > _pool_cap_bytes():
             return  # (not kept: the mapping goes when `m` does)
         try:
             m.madvise(getattr(mmap, "MADV_FREE", 8), off, cap)
         except (OSError, ValueError):
             pass
-        with self.lock:
-            self.free.append((cap, m, off))
-            while (sum(c for c, _m, _o in self.free) > limit or len(self.free) > self.MAX_MAPPINGS):
-                self.free.pop(0)  # (unmapped when its mmap object is collected: now)
+        self.returned.append((cap, m, off))
+        if self.lock.acquire(blocking=False):  # (held already -- perhaps by this thread: they absorb)
+            try:
+                self._absorb()
+            finally:
+                self.lock.release()
 
     def trim(self):
         with self.lock:
+            self._absorb()
             self.free.clear()
 
 

@@ -303,6 +303,23 @@ def test_result_arrays_own_their_mapping_and_a_pool_keeps_dead_ones(monkeypatch)
     assert len(pool.free) == 1  # the byte bound: the older mapping went back to the OS
     hostio.trim_result_pool()
     assert pool.free == []
+    # a finalizer may fire wherever the garbage collector runs -- also while THIS thread holds the
+    # pool's lock (inside take()): it must never wait for it
+    late = hostio.result_array(shape, np.float64)
+    late_addr = late.ctypes.data
+    assert pool.lock.acquire(blocking=False)
+    try:
+        del late
+        gc.collect()  # give() runs here, the lock is held: the mapping is parked, nothing blocks
+        assert pool.free == [] and len(pool.returned) == 1
+    finally:
+        pool.lock.release()
+    again = hostio.result_array(shape, np.float64)  # take() absorbs what was parked
+    assert again.ctypes.data == late_addr and len(pool.returned) == 0
+    del again
+    gc.collect()
+    hostio.trim_result_pool()
+    assert pool.free == [] and len(pool.returned) == 0
     del tiny
     gc.collect()
     hostio.trim_result_pool()
