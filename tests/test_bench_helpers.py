@@ -222,7 +222,8 @@ def test_valu_roofline_fields_come_from_the_profile_of_these_sources():
                             "faithful_fused": {"one_pass": {"Mcells/s": 400000.0}}}}
     bench.add_valu_roofline(line, f64_probe=30.0e12)
     assert line["valu_roofline"]["peak_lane_instr_per_s"] == 256 * 4 * 16 * 2.4e9
-    path = os.path.join(ROOT, "profiles", "r05_variants_summary.json")
+    name = bench.VARIANT_SUMMARIES[0]  # the round's float64 variants profile
+    path = os.path.join(ROOT, "profiles", name)
     current = False
     if os.path.exists(path):
         with open(path) as f:
@@ -231,7 +232,11 @@ def test_valu_roofline_fields_come_from_the_profile_of_these_sources():
         assert not any(k for k in instr if "calc_n2" not in k)
         assert "valu_instr_per_cell" not in line["roofline"]
         return
-    assert "profiles/r05_variants_summary.json" in sources
+    assert f"profiles/{name}" in sources
+    # round 6: the two timings of the K2-with-delta_rho instantiation share one profile row, and K0's
+    # map has its row -- no per_kernel row of the float64 table is left without a VALU column
+    assert instr["local_with_delta_rho"] == instr["local_with_delta_rho_large_chunks"]
+    assert "calc_rho_map" in instr and "config5_f32.default.calc_pdens_map" in instr
     r = line["roofline"]  # 6400 GB/s at 16 B/cell = 400 Gcells/s
     assert r["valu_instr_per_cell"] == instr["roofline"]
     assert abs(r["frac_of_valu_peak"] - instr["roofline"] * 400e9 / (256 * 4 * 16 * 2.4e9)) < 1e-3
