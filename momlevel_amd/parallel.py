@@ -42,6 +42,16 @@ from . import engine
 from .adapters import accepts_xarray
 
 
+def choose_backend(gpus, local_world, requested=None):
+    """The torch.distributed backend of a multi-rank run on this node: what was asked for
+    (MOMLEVEL_AMD_DIST_BACKEND or the caller), else "nccl" (= RCCL) when every rank of the node has a
+    GPU of its own, else "gloo" -- a rehearsal: RCCL cannot put two ranks on one GPU ("Duplicate GPU
+    detected"), so ranks that share cards exchange through the host (bench.py says so in its line)."""
+    if requested:
+        return requested
+    return "nccl" if gpus and local_world <= gpus else "gloo"
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*.
 
@@ -58,10 +68,11 @@ def init_from_env(backend=None):
         # when HIP_VISIBLE_DEVICES hides it): a rank that sees no GPU never touches one here -- the
         # CPU rehearsals of 8 ranks must not put 8 processes on a card that admits 6
         gpus = torch.cuda.device_count()
-        if backend is None:
-            # MOMLEVEL_AMD_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer
-            # GPUs than ranks (device tensors are staged through the host for the exchange)
-            backend = os.environ.get("MOMLEVEL_AMD_DIST_BACKEND") or ("nccl" if gpus else "gloo")
+        # MOMLEVEL_AMD_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than
+        # ranks (device tensors are staged through the host for the exchange); so does, by itself, a
+        # launch of more ranks per node than the node has GPUs (torchrun sets LOCAL_WORLD_SIZE)
+        backend = choose_backend(gpus, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))),
+                                 backend or os.environ.get("MOMLEVEL_AMD_DIST_BACKEND"))
         if gpus:  # every backend: the rank's kernels go to ITS GPU
             torch.cuda.set_device(local_rank % gpus)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

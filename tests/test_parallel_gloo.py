@@ -331,3 +331,12 @@ def test_forced_labelled_exchange_runs_a_collective_in_a_world_of_one():
         assert out[mode + "_last"] == {"backend": "gloo", "mode": mode, "world": 1,
                                        "device": "cpu", "doubles": 5}
     assert out["patched_collectives"] == 0
+
+
+def test_backend_choice_rehearses_over_gloo_when_ranks_outnumber_gpus():
+    """`torchrun --nproc-per-node 2 bench.py --gpus 2` on a one-GPU box died in RCCL ("Duplicate GPU
+    detected", gpurun_out/r06_bench_torchrun2.err): ranks that share a card now rehearse over gloo by
+    themselves, as the self-launcher's ranks already did; a full node keeps RCCL."""
+    assert parallel.choose_backend(8, 8) == "nccl" and parallel.choose_backend(8, 2) == "nccl"
+    assert parallel.choose_backend(1, 2) == "gloo" and parallel.choose_backend(0, 4) == "gloo"
+    assert parallel.choose_backend(1, 2, "nccl") == "nccl" and parallel.choose_backend(8, 8, "gloo") == "gloo"
