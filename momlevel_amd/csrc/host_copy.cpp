@@ -89,6 +89,12 @@ void fill_masked_plain(U* __restrict__ d, const U* __restrict__ s,
 // destination -- a page-locked staging buffer the DMA engine reads next, or a fresh array -- written
 // with streaming stores once it is 32-byte aligned (as copy_stream_avx2 does).  The upload of a lazily
 // read masked field runs through here piece by piece and must keep up with the 57 GB/s host link.
+// Blocks of 32 elements by their 32 mask bytes: nothing masked (the ocean's interior) -> a plain
+// streaming copy; everything masked (land, below the bottom: a third of an ocean field) -> NaNs
+// stored, the source NOT READ; only mixed blocks (coast lines, the bottom's edge) take the
+// widen-compare-blend path.  Round 6: the blend on every element made the masked upload of the
+// reference's recorded call 10-13 % slower end to end than the plain one (it shares the copy team
+// with the result downloads); with the fast paths it moves fewer bytes than the plain copy.
 __attribute__((target("avx2"))) void fill_masked32_avx2(uint32_t* d, const uint32_t* s,
                                                           const unsigned char* m, size_t n) {
   const uint32_t nanv = 0x7FC00000u;
@@ -98,14 +104,23 @@ __attribute__((target("avx2"))) void fill_masked32_avx2(uint32_t* d, const uint3
     ++i;
   }
   const __m256i nan8 = _mm256_set1_epi32(static_cast<int>(nanv)), zero = _mm256_setzero_si256();
-  for (; i + 16 <= n; i += 16) {
-    const __m128i mb = _mm_loadu_si128(reinterpret_cast<const __m128i*>(m + i));  // 16 mask bytes
-    const __m256i k0 = _mm256_cmpeq_epi32(_mm256_cvtepu8_epi32(mb), zero);         // lanes 0..7: keep?
-    const __m256i k1 = _mm256_cmpeq_epi32(_mm256_cvtepu8_epi32(_mm_srli_si128(mb, 8)), zero);
-    const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i));
-    const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i + 8));
-    _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i), _mm256_blendv_epi8(nan8, a, k0));
-    _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i + 8), _mm256_blendv_epi8(nan8, b, k1));
+  for (; i + 32 <= n; i += 32) {
+    const __m256i mb = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(m + i));
+    const unsigned keep = static_cast<unsigned>(_mm256_movemask_epi8(_mm256_cmpeq_epi8(mb, zero)));
+    if (keep == 0xFFFFFFFFu) {  // no byte set: copy
+      for (int k = 0; k < 32; k += 8)
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i + k),
+                            _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i + k)));
+    } else if (keep == 0u) {  // every byte set: NaN, the source stays unread
+      for (int k = 0; k < 32; k += 8) _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i + k), nan8);
+    } else {
+      for (int k = 0; k < 32; k += 8) {
+        const __m128i m8 = _mm_loadl_epi64(reinterpret_cast<const __m128i*>(m + i + k));
+        const __m256i k0 = _mm256_cmpeq_epi32(_mm256_cvtepu8_epi32(m8), zero);  // lanes: keep?
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i + k));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i + k), _mm256_blendv_epi8(nan8, a, k0));
+      }
+    }
   }
   _mm_sfence();
   for (; i < n; ++i) d[i] = m[i] ? nanv : s[i];
@@ -119,16 +134,25 @@ __attribute__((target("avx2"))) void fill_masked64_avx2(uint64_t* d, const uint6
     ++i;
   }
   const __m256i nan4 = _mm256_set1_epi64x(static_cast<long long>(nanv)), zero = _mm256_setzero_si256();
-  for (; i + 8 <= n; i += 8) {
-    uint64_t raw;
-    std::memcpy(&raw, m + i, 8);  // 8 mask bytes
-    const __m128i mb = _mm_cvtsi64_si128(static_cast<long long>(raw));
-    const __m256i k0 = _mm256_cmpeq_epi64(_mm256_cvtepu8_epi64(mb), zero);
-    const __m256i k1 = _mm256_cmpeq_epi64(_mm256_cvtepu8_epi64(_mm_srli_si128(mb, 4)), zero);
-    const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i));
-    const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i + 4));
-    _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i), _mm256_blendv_epi8(nan4, a, k0));
-    _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i + 4), _mm256_blendv_epi8(nan4, b, k1));
+  for (; i + 32 <= n; i += 32) {
+    const __m256i mb = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(m + i));
+    const unsigned keep = static_cast<unsigned>(_mm256_movemask_epi8(_mm256_cmpeq_epi8(mb, zero)));
+    if (keep == 0xFFFFFFFFu) {
+      for (int k = 0; k < 32; k += 4)
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i + k),
+                            _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i + k)));
+    } else if (keep == 0u) {
+      for (int k = 0; k < 32; k += 4) _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i + k), nan4);
+    } else {
+      for (int k = 0; k < 32; k += 4) {
+        uint32_t raw;
+        std::memcpy(&raw, m + i + k, 4);  // 4 mask bytes
+        const __m128i m4 = _mm_cvtsi32_si128(static_cast<int>(raw));
+        const __m256i k0 = _mm256_cmpeq_epi64(_mm256_cvtepu8_epi64(m4), zero);
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i + k));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i + k), _mm256_blendv_epi8(nan4, a, k0));
+      }
+    }
   }
   _mm_sfence();
   for (; i < n; ++i) d[i] = m[i] ? nanv : s[i];

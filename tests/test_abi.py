@@ -132,6 +132,12 @@ def test_host_copy_masked_needs_no_gpu():
         mask = r.random(n) < 0.3
         mask[:5000] = True
         mask[5000:9000] = False
+        # runs of 1..300 equal mask bytes over the second half: whole 32-element blocks with nothing
+        # masked (plain copy), with everything masked (NaN stored, source unread) and mixed ones
+        # (the blend) at every phase against the 32-byte alignment of the destination
+        runs = r.integers(1, 300, 40000)
+        runmask = np.repeat(np.arange(runs.size) % 2 == 0, runs)[: n - n // 2]
+        mask[n // 2: n // 2 + runmask.size] = runmask
         want = np.where(mask, ut(nan_bits), src)
         for threads in (1, 3, 8):
             for lo, m in ((0, n), (7, n - 19), (4096, 4097), (11, 0), (100, 1)):
