@@ -126,3 +126,30 @@ def test_rccl_leg_runs_in_a_world_of_one(tmp_path):
         for k in ("masso", "eta", "volo", "masso0", "area_sum"):
             assert np.array_equal(r[f"{v}_{k}_plain"], r[f"{v}_{k}_forced"]), (v, k)
         assert r[f"{v}_eta_forced"][0] == 0.0
+
+
+@pytest.mark.timeout(600)
+def test_bench_force_collective_on_a_small_grid(tmp_path):
+    """`python bench.py --force-collective`: the `--gpus 8` step in a world of one
+    rank on the RCCL backend, beside the plain step.  Here on a small grid, as a fresh process: one
+    JSON line last on stdout (RCCL prints its banner first), every expected collective run, all on
+    device buffers, masso / eta bit-identical to the plain step, the contract keys in place."""
+    import json
+
+    env = dict(os.environ)
+    env.pop("MOMLEVEL_AMD_DIST_BACKEND", None)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-collective",
+                        "--grid", "9,48,128", "--nt", "13", "--chunks", "5", "--steps", "3",
+                        "--warmup", "1"], env=env, capture_output=True, text=True, timeout=500)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-4000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 1
+    assert line["config"]["forced_collective"] is True and line["config"]["backend"] == "nccl (RCCL)"
+    assert line["config"]["time_chunks"] == 5 and "--force-collective" in line["config"]["workload"]
+    fc = line["forced_collective"]
+    assert fc["collectives_run"] == fc["collectives_expected"] == fc["collectives_on_device"] == (3 + 1) * 5
+    assert fc["last_collective"]["backend"] == "nccl" and fc["last_collective"]["world"] == 1
+    assert fc["masso_bit_identical_to_plain_step"] and fc["eta_bit_identical_to_plain_step"]
+    assert line["eta_t0_is_zero"] is True and line["roofline"]["launches_per_step"] == 5
+    assert line["value"] > 0 and line["cpu_baseline"] is None  # (no CPU leg in this mode)
