@@ -118,6 +118,25 @@ def test_calc_rho_on_masked_arrays(monkeypatch):
     rho = derived.calc_rho(DataArray(as_masked(S), dims, coords),
                            DataArray(MaskedLazy(tl), ("z_l", "yh", "xh", "time")), pres)
     assert_bit_equal(rho.values, o.calc_rho(S, T, p))
+    # round 6: a LARGE in-memory masked array is held as data + mask (labeled.MaskedSource; here the
+    # threshold is lowered to the test's size) and read piece by piece like the lazy field above --
+    # NaN-filled by the staging copy -- also when it has to be transposed, and for float32
+    from momlevel_amd import hostio, labeled
+
+    monkeypatch.setattr(labeled, "_NATIVE_FILL_BYTES", 256)
+    monkeypatch.setattr(hostio, "SMALL_BYTES", 256)
+    held = DataArray(as_masked(T), dims, coords)
+    assert isinstance(held.data, labeled.MaskedSource)
+    rho = derived.calc_rho(held, DataArray(as_masked(S), dims, coords), pres)
+    assert_bit_equal(rho.values, ref)
+    rho = derived.calc_rho(DataArray(as_masked(S), dims, coords),
+                           DataArray(as_masked(tl), ("z_l", "yh", "xh", "time")), pres)
+    assert_bit_equal(rho.values, o.calc_rho(S, T, p))
+    T32, S32 = T.astype(np.float32), S.astype(np.float32)
+    held32 = DataArray(as_masked(T32), dims, coords)
+    assert isinstance(held32.data, labeled.MaskedSource) and held32.dtype == np.float32
+    rho = derived.calc_rho(held32, DataArray(as_masked(S32), dims, coords), pres)
+    assert_bit_equal(rho.values, o.calc_rho(T32, S32, p))
 
 
 def test_big_endian_fields_compute_in_their_own_precision():
