@@ -28,7 +28,7 @@ import threading
 import numpy as np
 import torch
 
-from .labeled import as_plain  # numpy masked arrays MEAN NaN (what xarray hands the reference)
+from .labeled import MaskedSource, as_plain  # numpy masked arrays MEAN NaN (what xarray hands the reference)
 
 _MIB = 1 << 20
 PIECE_BYTES = int(os.environ.get("MOMLEVEL_AMD_STAGING_PIECE_MIB", "64")) * _MIB
@@ -282,8 +282,12 @@ def to_device(x, device, dtype=None):
             t = x.to(device)
             return t if dtype is None or t.dtype == dtype else t.to(dtype)
         host = x.contiguous()
+        mask = None
     else:
-        a = as_plain(x)
+        # (a masked array -- or one held as data + mask, labeled.MaskedSource: the (z,y,x) slabs of
+        #  a reference state cut out of a masked field -- is NaN-filled by the staging copy, not
+        #  into an array of its own first)
+        a, mask = split_masked(x.array if isinstance(x, MaskedSource) else x)
         if a.dtype.byteorder not in ("=", "|"):
             a = a.astype(a.dtype.newbyteorder("="))
         if not a.flags["C_CONTIGUOUS"]:
@@ -294,9 +298,9 @@ def to_device(x, device, dtype=None):
             warnings.simplefilter("ignore", UserWarning)
             host = torch.from_numpy(a)
     if host.dtype not in (torch.float32, torch.float64):
-        host = host.to(torch.float64)
+        host = host.to(torch.float64)  # (never with a mask: split_masked keeps floating data only)
     dev = torch.empty(host.shape, dtype=host.dtype, device=device)
-    upload(host, dev)
+    upload(host, dev, mask=mask)
     return dev if dtype is None or dev.dtype == dtype else dev.to(dtype)
 
 

@@ -51,7 +51,13 @@ def run(nt=60, nz=35, reps=2, ny=1080, nx=1440, checker=None, before_call=None, 
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
         from lazy_array import PrebuiltMaskedLazy as MaskedLazy, as_masked
 
-        held = {name: (MaskedLazy(host[name]) if source == "masked_lazy" else as_masked(host[name]))
+        def one_cell(a):  # a full-size mask with ONE element set: what the masked route costs by itself
+            mask = np.zeros(a.shape, dtype=bool)
+            mask[0, 0, 0, 0] = True
+            return np.ma.masked_array(np.nan_to_num(a, nan=1e20), mask=mask)
+
+        held = {name: (MaskedLazy(host[name]) if source == "masked_lazy" else
+                       one_cell(host[name]) if source == "masked_onecell" else as_masked(host[name]))
                 for name in ("thetao", "so")}
         t_wrap = time.perf_counter()  # (an in-memory masked array is NaN-filled HERE, once: as_plain)
         for name in ("thetao", "so"):
@@ -100,7 +106,7 @@ def main():
     ap.add_argument("--nt", type=int, default=60)
     ap.add_argument("--nz", type=int, default=35)
     ap.add_argument("--reps", type=int, default=2)
-    ap.add_argument("--source", choices=["numpy", "masked", "masked_lazy"], default="numpy")
+    ap.add_argument("--source", choices=["numpy", "masked", "masked_lazy", "masked_onecell"], default="numpy")
     a = ap.parse_args()
     print(json.dumps(run(a.nt, a.nz, a.reps, source=a.source)), flush=True)
 
