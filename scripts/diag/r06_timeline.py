@@ -75,6 +75,7 @@ def before():
     T0[0] = time.perf_counter()
 
 
-out = example_call.run(reps=5, before_call=before)
+out = example_call.run(reps=int(os.environ.get("REPS", "5")), before_call=before)
 runs.append(list(marks))
-print(json.dumps({"wall_s": out["wall_s"], "first_call_marks_ms": runs[0], "last_call_marks_ms": runs[-1]}))
+slow = [r for r, w in zip(runs, out["wall_s"]) if w > 1.0]
+print(json.dumps({"wall_s": out["wall_s"], "first_call_marks_ms": runs[0], "last_call_marks_ms": runs[-1], "slow_calls_marks_ms": slow}))
