@@ -369,12 +369,12 @@ class _ResultPool:
     bottleneck (47-57 GB/s into fresh pages, 105-190 GB/s into pages that exist; faulting the pages
     in AHEAD of the copy from other threads measured slower still, profiles/r06_result_prefault_
     negative.log) -- while a caller that walks a long record calls steric() again and again, freeing
-    each result after writing it out.  The kept pages STAY this process's (like the blocks of
-    torch's caching allocators): bounded by bytes (_pool_cap_bytes: a quarter of the memory the
-    process may use, MOMLEVEL_AMD_RESULT_POOL_GIB) and count, emptied by hostio.trim_result_pool().
-    MOMLEVEL_AMD_RESULT_POOL_RECLAIMABLE=1 advises them MADV_FREE instead (the kernel may take them
-    whenever it wants memory) -- measured: on hosts under memory pressure that turns one call in
-    twelve into a 2.13 s call (see give())."""
+    each result after writing it out.  The kept pages are advised MADV_FREE: they count as this
+    process's until the kernel wants memory, which then takes them without swapping (a later re-use
+    finds zero pages there, as in a fresh mapping); so the pool cannot cause an out-of-memory kill
+    (MOMLEVEL_AMD_RESULT_POOL_RECLAIMABLE=0 keeps them outright).  Bounded by bytes
+    (_pool_cap_bytes: a quarter of the memory the process may use, MOMLEVEL_AMD_RESULT_POOL_GIB) and
+    count; hostio.trim_result_pool() empties it."""
 
     MAX_MAPPINGS = 12
 
@@ -418,12 +418,11 @@ class _ResultPool:
 
         if cap > _pool_cap_bytes():
             return  # (not kept: the mapping goes when `m` does)
-        if os.environ.get("MOMLEVEL_AMD_RESULT_POOL_RECLAIMABLE") == "1":
-            # opt-in: the kernel may take the kept pages back whenever it wants memory (MADV_FREE).
-            # NOT the default: on a host whose other tenants press for memory those pages go first,
-            # huge pages are scarce at the same moment, and the next call then faults its 27 GB of
-            # results in 4 KiB at a time -- 2.13 s instead of 0.55, one call in twelve on such hosts
-            # (profiles/r06_tail_latency.log)
+        if os.environ.get("MOMLEVEL_AMD_RESULT_POOL_RECLAIMABLE", "1") != "0":
+            # the kernel may take the kept pages back whenever it wants memory (MADV_FREE): they
+            # cannot cause an out-of-memory kill; a later re-use finds zero pages where it did.
+            # (=0 keeps them outright.  Suspected for a while of the rare 2.13 s calls of
+            # profiles/r06_tail_latency.log -- those occur with the pages kept as well.)
             try:
                 m.madvise(getattr(mmap, "MADV_FREE", 8), off, cap)
             except (OSError, ValueError):
@@ -453,8 +452,8 @@ def result_array(shape, dtype=np.float64):
     """The host array a bulk result is copied into.  Large results: an anonymous mapping of our
     own, 2 MiB-aligned and advised MADV_HUGEPAGE -- an ordinary writable numpy array to the caller,
     whose ``base`` chain ends in the mapping; when the last view of the array dies the mapping goes
-    into a bounded pool for the next call's results (_ResultPool) or, beyond the pool's bounds, back
-    to the OS at once.  Contents are
+    into a bounded pool for the next call's results (_ResultPool; pages the kernel may take back
+    whenever it wants memory) or, beyond the pool's bounds, back to the OS at once.  Contents are
     UNDEFINED, as np.empty's.  Small ones, and everything when the caller opted into page-locked
     results: pinned_array()."""
     import weakref

@@ -64,6 +64,25 @@ def finish(self):
 
 
 hostio.Downloader.finish = finish
+dinit = hostio.Downloader.__init__
+
+
+def downloader_init(self, *a, **k):
+    dinit(self, *a, **k)
+    mark("downloader stream " + hex(self.stream.cuda_stream))
+
+
+hostio.Downloader.__init__ = downloader_init
+tinit = engine.TimeChunks.__init__
+
+
+def chunks_init(self, *a, **k):
+    tinit(self, *a, **k)
+    if self._copy_stream is not None:
+        mark("upload stream " + hex(self._copy_stream.cuda_stream))
+
+
+engine.TimeChunks.__init__ = chunks_init
 runs = []
 
 
@@ -78,4 +97,5 @@ def before():
 out = example_call.run(reps=int(os.environ.get("REPS", "5")), before_call=before)
 runs.append(list(marks))
 slow = [r for r, w in zip(runs, out["wall_s"]) if w > 1.0]
-print(json.dumps({"wall_s": out["wall_s"], "first_call_marks_ms": runs[0], "last_call_marks_ms": runs[-1], "slow_calls_marks_ms": slow}))
+streams = [[m[0].split()[-1][-5:] for m in r if "stream" in m[0]] for r in runs]
+print(json.dumps({"wall_s": out["wall_s"], "first_call_marks_ms": runs[0], "last_call_marks_ms": runs[-1], "slow_calls_marks_ms": slow, "streams_per_call": streams}))
