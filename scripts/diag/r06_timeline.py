@@ -6,6 +6,7 @@ submitted, last kernel enqueued, results complete."""
 import json
 import os
 import sys
+import threading
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -73,6 +74,32 @@ def downloader_init(self, *a, **k):
 
 
 hostio.Downloader.__init__ = downloader_init
+# where does a result piece spend its time: waiting for its DMA, or being copied out of the ring?
+acc = {"drain_s": 0.0, "copy_out_s": 0.0, "copy_in_s": 0.0, "pieces": 0}
+drain = hostio._drain_one
+hcopy = hostio._host_copy
+in_drain = threading.local()
+
+
+def timed_copy(dst, src):
+    t0 = time.perf_counter()
+    hcopy(dst, src)
+    acc["copy_out_s" if getattr(in_drain, "on", False) else "copy_in_s"] += time.perf_counter() - t0
+
+
+def timed_drain(ring, pending):
+    in_drain.on = True
+    t0 = time.perf_counter()
+    try:
+        drain(ring, pending)
+    finally:
+        in_drain.on = False
+        acc["drain_s"] += time.perf_counter() - t0
+        acc["pieces"] += 1
+
+
+hostio._host_copy = timed_copy
+hostio._drain_one = timed_drain
 tinit = engine.TimeChunks.__init__
 
 
@@ -86,9 +113,15 @@ engine.TimeChunks.__init__ = chunks_init
 runs = []
 
 
+accs = []
+
+
 def before():
     if marks:
         runs.append(list(marks))
+        accs.append({k: round(v, 3) for k, v in acc.items()})
+    for k in acc:
+        acc[k] = 0
     marks.clear()
     first["submit"] = True
     T0[0] = time.perf_counter()
@@ -96,6 +129,8 @@ def before():
 
 out = example_call.run(reps=int(os.environ.get("REPS", "5")), before_call=before)
 runs.append(list(marks))
+accs.append({k: round(v, 3) for k, v in acc.items()})
 slow = [r for r, w in zip(runs, out["wall_s"]) if w > 1.0]
 streams = [[m[0].split()[-1][-5:] for m in r if "stream" in m[0]] for r in runs]
-print(json.dumps({"wall_s": out["wall_s"], "first_call_marks_ms": runs[0], "last_call_marks_ms": runs[-1], "slow_calls_marks_ms": slow, "streams_per_call": streams}))
+print(json.dumps({"wall_s": out["wall_s"], "first_call_marks_ms": runs[0], "last_call_marks_ms": runs[-1], "slow_calls_marks_ms": slow, "streams_per_call": streams,
+                  "download_pieces_per_call": accs}))
