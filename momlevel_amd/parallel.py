@@ -23,8 +23,11 @@ of the vector starting at rank k, so masso0 and masso(t=0) -- the same per-rank 
 positions of the vector -- came out 1 ulp apart in the round-5 rehearsal of the 8-rank 2x4 layout
 over gloo (``steric[t=0] = 1.7e-15`` instead of 0; 2 ranks cannot show it, a + b is commutative).
 With the ordered sum ``steric[t=0] == 0`` holds exactly for any world size, as on one GPU and in
-the reference, for every variant; the result is bit-identical on all ranks, from run to run, and
-between backends (what the gloo rehearsals compute is what RCCL will).  ``MOMLEVEL_AMD_EXCHANGE=
+the reference, for every variant; the result is bit-identical on all ranks and from run to run.
+The host sum does not depend on the backend, so the gloo rehearsals compute what RCCL computes
+provided its all-gather delivers every rank's vector intact -- UNVERIFIED at N>1: no multi-GPU run
+of this code exists (in a world of one rank the forced RCCL all-gather is bit-identical to the
+collective-free walk: tests/nccl_worker.py, bench.py --force-collective).  ``MOMLEVEL_AMD_EXCHANGE=
 allreduce`` selects the library's own ``all_reduce(SUM)`` instead (same bytes on the wire per rank
 up to the factor N; results within 1 ulp per element of the ordered sum, no exact-zero guarantee).
 
